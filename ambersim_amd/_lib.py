@@ -1,0 +1,69 @@
+"""ctypes binding of libamx.so (C ABI: include/amx.h).  No CPU fallback: if the HIP library is
+missing or a call fails, this raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+from ._desc import AmxModelDesc
+
+_CSRC = Path(__file__).resolve().parent / "csrc"
+_LIB_PATH = _CSRC / "libamx.so"
+_lib = None
+
+AMX_OK, AMX_EINVAL, AMX_EUNSUPPORTED, AMX_ENOMEM, AMX_EHIP, AMX_ECAPACITY = 0, -1, -2, -3, -4, -5
+
+
+class AmxForwardOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in [
+        "qacc_dev", "qacc_smooth_dev", "qfrc_bias_dev", "qfrc_constraint_dev", "qM_dev", "xpos_dev", "xquat_dev",
+        "contact_dist_dev", "nefc_dev"]]
+
+
+EXPORTS = ["amx_version", "amx_last_error", "amx_model_create", "amx_model_destroy", "amx_model_query",
+           "amx_forward", "amx_step", "amx_rollout", "amx_quadcost"]
+
+
+def build(force: bool = False) -> Path:
+    """Compiles csrc/ into libamx.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.run(["make", "-s", "-C", str(_CSRC), "clean"], check=True)
+    subprocess.run(["make", "-s", "-C", str(_CSRC), "libamx.so"], check=True)
+    return _LIB_PATH
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not _LIB_PATH.exists():
+            raise RuntimeError(
+                f"{_LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+                "ambersim_amd has no CPU fallback for the physics path.")
+        L = C.CDLL(str(_LIB_PATH))
+        L.amx_version.restype = C.c_int
+        L.amx_last_error.restype = C.c_char_p
+        L.amx_model_create.argtypes = [C.POINTER(AmxModelDesc), C.c_int, C.POINTER(C.c_void_p)]
+        L.amx_model_destroy.argtypes = [C.c_void_p]
+        L.amx_model_query.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]
+        L.amx_forward.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.POINTER(AmxForwardOut), C.c_void_p]
+        L.amx_step.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_void_p]
+        L.amx_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.amx_quadcost.argtypes = [C.c_int] * 4 + [C.c_void_p] * 7 + [C.c_void_p]
+        for name in EXPORTS:
+            getattr(L, name)
+        _lib = L
+    return _lib
+
+
+_EXC = {AMX_EINVAL: ValueError, AMX_EUNSUPPORTED: NotImplementedError, AMX_ENOMEM: MemoryError,
+        AMX_EHIP: RuntimeError, AMX_ECAPACITY: NotImplementedError}
+
+
+def check(code: int):
+    """Maps a C status to the exception type the reference's callers expect
+    (NotImplementedError for unsupported features: reference ambersim/utils/io_utils.py:228-241)."""
+    if code != AMX_OK:
+        msg = lib().amx_last_error().decode(errors="replace")
+        raise _EXC.get(code, RuntimeError)(f"amx error {code}: {msg}")

@@ -1,0 +1,132 @@
+/* amx.h — C ABI of the MI355X batched rigid-body rollout engine.
+ *
+ * This is the drop-in boundary for the hot path of Caltech-AMBER/ambersim: everything the
+ * reference reaches through `mujoco.mjx` is bound here.  The reference has no FFI of its own
+ * (it is pure Python over JAX); each entry point cites the Python call site it replaces:
+ *
+ *   amx_model_create   <- mjx.device_put(mj_model)        ambersim/utils/io_utils.py:225, rl/base.py:52
+ *   amx_forward        <- mjx.forward(sys, data)          ambersim/rl/base.py:85, trajopt/shooting.py:36
+ *   amx_step           <- lax.scan of mjx.step            ambersim/rl/base.py:88-96  (MjxEnv.pipeline_step)
+ *   amx_rollout        <- shoot(m, x0, us) under vmap     ambersim/trajopt/shooting.py:22-48,152
+ *   amx_quadcost       <- StaticGoalQuadraticCost.cost    ambersim/trajopt/cost.py:62-85 (batched over rollouts)
+ *
+ * Conventions: plain pointers and sizes only.  Pointers named *_dev are device (HBM)
+ * addresses owned by the caller (e.g. torch tensors); every other pointer is host memory.
+ * All batched arrays are env-major, contiguous, float32 (the reference physics' precision).
+ * Calls are asynchronous and ordered on the given HIP stream (`stream` is a hipStream_t
+ * passed as void*; NULL = the default stream).  Functions return 0 on success and a negative
+ * AMX_E* code otherwise; amx_last_error() gives a thread-local message.  Nothing throws
+ * across this boundary.  A model handle is immutable and may be shared between threads.
+ */
+#ifndef AMX_H
+#define AMX_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMX_VERSION 1
+
+enum {
+  AMX_OK = 0,
+  AMX_EINVAL = -1,      /* bad argument / inconsistent model description      -> ValueError */
+  AMX_EUNSUPPORTED = -2,/* feature outside the supported physics subset       -> NotImplementedError */
+  AMX_ENOMEM = -3,      /* host or device allocation failed                   -> MemoryError */
+  AMX_EHIP = -4,        /* HIP runtime error (message has hipGetErrorString)  -> RuntimeError */
+  AMX_ECAPACITY = -5    /* model exceeds a kernel capacity (LDS / lanes)      -> NotImplementedError */
+};
+
+/* Compiled host model: MuJoCo's field names, float64/int32 host arrays.  Produced by
+ * ambersim_amd/mjcf.py (the counterpart of mujoco.MjModel.from_xml_path). */
+typedef struct amx_model_desc {
+  int version;          /* AMX_VERSION */
+  int nq, nv, nu, nbody, njnt, ngeom, neq, npair, nconvexvert;
+  /* option / statistic */
+  double timestep, gravity[3], tolerance, ls_tolerance, impratio, meaninertia;
+  int iterations, ls_iterations, solver /*1 CG, 2 Newton*/, integrator /*0 Euler*/, disableflags;
+  /* bodies [nbody] */
+  const int *body_parentid, *body_rootid, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum;
+  const double *body_pos /*[nbody,3]*/, *body_quat /*[nbody,4]*/, *body_ipos, *body_iquat,
+      *body_mass, *body_inertia /*[nbody,3]*/, *body_invweight0 /*[nbody,2]*/;
+  /* joints [njnt] */
+  const int *jnt_type /*0 free 1 ball 2 slide 3 hinge*/, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid, *jnt_limited;
+  const double *jnt_pos, *jnt_axis, *jnt_range /*[njnt,2]*/, *jnt_margin, *jnt_stiffness,
+      *jnt_solref /*[njnt,2]*/, *jnt_solimp /*[njnt,5]*/;
+  const double *qpos0 /*[nq]*/, *qpos_spring /*[nq]*/;
+  /* dofs [nv] */
+  const int *dof_bodyid, *dof_jntid, *dof_parentid;
+  const double *dof_armature, *dof_damping, *dof_invweight0;
+  /* geoms [ngeom] */
+  const int *geom_type, *geom_bodyid;
+  const double *geom_pos, *geom_quat, *geom_size /*[ngeom,3]*/;
+  /* static collision pairs [npair] (contype/conaffinity/parent filters already applied) */
+  const int *pair_geom1, *pair_geom2, *pair_fn /*0 plane-sphere 1 plane-capsule 2 plane-convex
+      3 sphere-sphere 4 sphere-capsule 5 capsule-capsule*/, *pair_vertadr, *pair_vertnum;
+  const double *pair_friction /*[npair,3]*/, *pair_solref /*[npair,2]*/, *pair_solimp /*[npair,5]*/,
+      *pair_margin /*[npair] margin-gap*/, *convex_vert /*[nconvexvert,3] geom-local hull vertices*/;
+  /* actuators [nu] (joint transmissions) */
+  const int *actuator_trnid, *actuator_biastype /*0 none 1 affine*/, *actuator_ctrllimited, *actuator_forcelimited;
+  const double *actuator_gear, *actuator_gainprm /*[nu,3]*/, *actuator_biasprm /*[nu,3]*/,
+      *actuator_ctrlrange /*[nu,2]*/, *actuator_forcerange /*[nu,2]*/;
+  /* joint equalities [neq] */
+  const int *eq_obj1id, *eq_obj2id, *eq_active;
+  const double *eq_data /*[neq,5] polycoef*/, *eq_solref /*[neq,2]*/, *eq_solimp /*[neq,5]*/;
+} amx_model_desc;
+
+typedef struct amx_model amx_model; /* opaque: device-resident constant block + launch plan */
+
+/* Derived outputs of amx_forward; any pointer may be NULL to skip that field. */
+typedef struct amx_forward_out {
+  float *qacc_dev;            /* [nenv,nv]  constrained acceleration                        */
+  float *qacc_smooth_dev;     /* [nenv,nv]  unconstrained acceleration                      */
+  float *qfrc_bias_dev;       /* [nenv,nv]  Coriolis/centrifugal/gravity (RNE)              */
+  float *qfrc_constraint_dev; /* [nenv,nv]  J^T * efc_force                                 */
+  float *qM_dev;              /* [nenv,nv,nv] dense joint-space inertia (CRBA)              */
+  float *xpos_dev;            /* [nenv,nbody,3] body frame origins                          */
+  float *xquat_dev;           /* [nenv,nbody,4] body frame orientations                     */
+  float *contact_dist_dev;    /* [nenv,ncon] signed distance per contact slot               */
+  int *nefc_dev;              /* [nenv] number of active constraint rows                    */
+} amx_forward_out;
+
+/* Library / device probes (no GPU work). */
+int amx_version(void);
+const char *amx_last_error(void);
+
+/* Uploads a compiled model to `device` and builds the launch plan (tree levels, ancestor
+ * chains, constraint row tables).  Replaces mjx.device_put(mj_model). */
+int amx_model_create(const amx_model_desc *desc, int device, amx_model **out);
+int amx_model_destroy(amx_model *m);
+/* Static sizes of a created model: name in {"nq","nv","nu","nbody","ncon","nefc_max",
+ * "lds_bytes","lanes_per_env","envs_per_block"}. */
+int amx_model_query(const amx_model *m, const char *name, int *out);
+
+/* mjx.forward: derived quantities for the given state, no integration.  `qacc_warmstart_dev`
+ * may be NULL (cold start from qacc_smooth). */
+int amx_forward(const amx_model *m, int nenv, const float *qpos_dev, const float *qvel_dev,
+                const float *ctrl_dev, const float *qacc_warmstart_dev, const amx_forward_out *out,
+                void *stream);
+
+/* MjxEnv.pipeline_step: `nsub` physics steps with ctrl held, in place on
+ * qpos[nenv,nq], qvel[nenv,nv], qacc_warmstart[nenv,nv]; time[nenv] may be NULL. */
+int amx_step(const amx_model *m, int nenv, int nsub, float *qpos_dev, float *qvel_dev,
+             const float *ctrl_dev, float *qacc_warmstart_dev, float *time_dev, void *stream);
+
+/* vmap(shoot): xs[e,0,:] = x0[e], xs[e,t+1,:] = concat(qpos,qvel) after step t under us[e,t,:].
+ * x0 is [nenv,nq+nv] when x0_batched != 0, else one shared [nq+nv] row.  State stays on chip
+ * for the whole horizon; HBM traffic is us in, xs out.  xs_dev may be NULL when only the final
+ * state is wanted (xfinal_dev [nenv,nq+nv], may also be NULL). */
+int amx_rollout(const amx_model *m, int nenv, int nsteps, const float *x0_dev, int x0_batched,
+                const float *us_dev, float *xs_dev, float *xfinal_dev, void *stream);
+
+/* Batched StaticGoalQuadraticCost.cost over rollouts: cost[e] = 0.5*(sum_t<N (x_t-xg)'Q(x_t-xg)
+ * + (x_N-xg)'Qf(x_N-xg) + sum_t u_t'R u_t).  Q,Qf are [nx,nx], R is [nu,nu], xg is [nx]. */
+int amx_quadcost(int nenv, int nsteps, int nx, int nu, const float *xs_dev, const float *us_dev,
+                 const float *Q_dev, const float *Qf_dev, const float *R_dev, const float *xg_dev,
+                 float *cost_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMX_H */
