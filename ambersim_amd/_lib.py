@@ -34,9 +34,28 @@ def build(force: bool = False) -> Path:
     return _LIB_PATH
 
 
+def _load_hip_runtime():
+    """libamx.so is linked with -no-hip-rt: it binds to the HIP runtime of the host process.  Under PyTorch that is
+    the libamdhip64 inside the torch wheel (two runtimes in one process do not share devices), else the system one."""
+    cands = []
+    try:
+        import torch
+        cands.append(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    except Exception:
+        pass
+    cands += ["/opt/rocm/lib/libamdhip64.so.7", "/opt/rocm/lib/libamdhip64.so", "libamdhip64.so"]
+    for c in cands:
+        try:
+            return C.CDLL(c, mode=C.RTLD_GLOBAL)
+        except OSError:
+            continue
+    raise RuntimeError("no HIP runtime (libamdhip64) found for libamx.so")
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
+        _load_hip_runtime()
         if not _LIB_PATH.exists():
             raise RuntimeError(
                 f"{_LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "

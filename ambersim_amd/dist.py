@@ -1,0 +1,56 @@
+"""Multi-GPU sharding of the env axis: one process per GPU, contiguous env blocks, no
+collective during the rollout, one all-gather (RCCL over xGMI on GPUs, gloo on CPU tensors) for the
+returned trajectories."""
+from __future__ import annotations
+
+import os
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
+    """Initialises torch.distributed from RANK/WORLD_SIZE/LOCAL_RANK/MASTER_* (torchrun contract).
+    Returns (rank, world_size, local_rank); a single process needs no process group."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(nenv_total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block [lo, hi) of the env axis owned by `rank`; blocks differ by at most one env."""
+    base, rem = divmod(nenv_total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_trajectories(xs_local: torch.Tensor, nenv_total: int | None = None) -> torch.Tensor:
+    """All-gathers per-rank trajectory blocks [nenv_local, ...] into [nenv_total, ...] on every rank.
+    Equal blocks use one all_gather_into_tensor (a single RCCL all-gather); ragged blocks are padded."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return xs_local
+    world = dist.get_world_size()
+    n_local = torch.tensor([xs_local.shape[0]], dtype=torch.int64, device=xs_local.device)
+    sizes = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(sizes, n_local)
+    sizes = [int(s.item()) for s in sizes]
+    if len(set(sizes)) == 1:
+        out = torch.empty((world * sizes[0],) + tuple(xs_local.shape[1:]), dtype=xs_local.dtype, device=xs_local.device)
+        dist.all_gather_into_tensor(out, xs_local.contiguous())
+        return out
+    nmax = max(sizes)
+    pad = torch.zeros((nmax,) + tuple(xs_local.shape[1:]), dtype=xs_local.dtype, device=xs_local.device)
+    pad[: xs_local.shape[0]] = xs_local
+    out = torch.empty((world * nmax,) + tuple(xs_local.shape[1:]), dtype=xs_local.dtype, device=xs_local.device)
+    dist.all_gather_into_tensor(out, pad)
+    return torch.cat([out[r * nmax: r * nmax + sizes[r]] for r in range(world)], dim=0)

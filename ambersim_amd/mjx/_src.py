@@ -1,0 +1,227 @@
+from __future__ import annotations
+
+import copy
+import ctypes as C
+import dataclasses
+from typing import Any, Optional
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._desc import build_desc
+from ..mjcf import DisableBit, MjData, MjModel, recompile_options
+
+
+class SolverType:
+    PGS, CG, NEWTON = 0, 1, 2
+
+
+def _dev(device=None) -> torch.device:
+    if device is not None:
+        return torch.device(device)
+    if not torch.cuda.is_available():
+        raise RuntimeError("ambersim_amd.mjx needs a GPU (MI355X): no HIP device is visible and there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _stream_ptr(device: torch.device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+@dataclasses.dataclass(frozen=True)
+class Option:
+    """Counterpart of mjx.Option; `.replace` as used at reference tests/trajopt/test_predictive_sampler.py:22-31."""
+    timestep: float
+    iterations: int
+    ls_iterations: int
+    tolerance: float
+    ls_tolerance: float
+    impratio: float
+    gravity: Any
+    integrator: int
+    solver: int
+    disableflags: int
+    cone: int = 0
+
+    def replace(self, **kw) -> "Option":
+        return dataclasses.replace(self, **kw)
+
+
+class _Handle:
+    """Owns one amx_model* (freed with the last Model that shares it)."""
+
+    def __init__(self, mj: MjModel, device_index: int):
+        self.desc = build_desc(mj)
+        self.ptr = C.c_void_p()
+        _lib.check(_lib.lib().amx_model_create(C.byref(self.desc), device_index, C.byref(self.ptr)))
+
+    def query(self, name: str) -> int:
+        out = C.c_int()
+        _lib.check(_lib.lib().amx_model_query(self.ptr, name.encode(), C.byref(out)))
+        return out.value
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                _lib.lib().amx_model_destroy(self.ptr)
+        except Exception:
+            pass
+
+
+class Model:
+    """Device model.  Immutable; `replace(opt=...)` re-uploads the constant block."""
+
+    def __init__(self, mj: MjModel, device: torch.device, opt: Optional[Option] = None):
+        self.mj_model = mj
+        self.device = device
+        o = mj.opt
+        self.opt = opt if opt is not None else Option(
+            timestep=float(o.timestep), iterations=int(o.iterations), ls_iterations=int(o.ls_iterations),
+            tolerance=float(o.tolerance), ls_tolerance=float(o.ls_tolerance), impratio=float(o.impratio),
+            gravity=tuple(float(g) for g in o.gravity), integrator=int(o.integrator), solver=int(o.solver),
+            disableflags=int(o.disableflags))
+        self.nq, self.nv, self.nu, self.nbody, self.njnt, self.ngeom, self.neq = mj.nq, mj.nv, mj.nu, mj.nbody, mj.njnt, mj.ngeom, mj.neq
+        self.actuator_ctrlrange = torch.as_tensor(np.asarray(mj.actuator_ctrlrange, dtype=np.float32).reshape(-1, 2), device=device)
+        self.qpos0 = torch.as_tensor(np.asarray(mj.qpos0, dtype=np.float32), device=device)
+        self._h = _Handle(mj, device.index or 0)
+        self.ncon = self._h.query("ncon")
+        self.nefc_max = self._h.query("nefc_max")
+
+    def replace(self, **kw) -> "Model":
+        if set(kw) - {"opt"}:
+            raise NotImplementedError(f"Model.replace supports only opt= (got {sorted(kw)})")
+        opt: Option = kw["opt"]
+        mj = copy.copy(self.mj_model)
+        mj.opt = self.mj_model.opt.replace(
+            timestep=float(opt.timestep), iterations=int(opt.iterations), ls_iterations=int(opt.ls_iterations),
+            tolerance=float(opt.tolerance), ls_tolerance=float(opt.ls_tolerance), impratio=float(opt.impratio),
+            gravity=np.asarray(opt.gravity, dtype=float), integrator=int(opt.integrator), solver=int(opt.solver),
+            disableflags=int(opt.disableflags))
+        mj = recompile_options(mj)
+        return Model(mj, self.device, opt)
+
+
+_DATA_FIELDS = ("qpos", "qvel", "ctrl", "qacc", "qacc_warmstart", "time", "qacc_smooth", "qfrc_bias", "qfrc_constraint",
+                "xpos", "xquat")
+
+
+class Data:
+    """Physics state + derived quantities (subset of mjx.Data the reference reads: qpos, qvel, ctrl,
+    reference ambersim/rl/pendulum/swingup.py:64-76, ambersim/trajopt/shooting.py:42)."""
+    __slots__ = _DATA_FIELDS
+
+    def __init__(self, **kw):
+        for f in _DATA_FIELDS:
+            setattr(self, f, kw.get(f))
+
+    def replace(self, **kw) -> "Data":
+        out = Data(**{f: getattr(self, f) for f in _DATA_FIELDS})
+        for k, v in kw.items():
+            if k not in _DATA_FIELDS:
+                raise AttributeError(f"Data has no field '{k}'")
+            ref = getattr(self, k)
+            if ref is not None and not torch.is_tensor(v):
+                v = torch.as_tensor(v, dtype=torch.float32, device=ref.device)
+            elif torch.is_tensor(v) and ref is not None:
+                v = v.to(device=ref.device, dtype=torch.float32)
+            setattr(out, k, v)
+        return out
+
+    @property
+    def batched(self) -> bool:
+        return self.qpos.dim() == 2
+
+
+def put_model(mj: MjModel, device=None) -> Model:
+    if mj.opt.integrator != 0:
+        raise NotImplementedError("only the Euler integrator is implemented")
+    return Model(mj, _dev(device))
+
+
+def make_data(m: Model, nenv: Optional[int] = None) -> Data:
+    """mjx.make_data: zero state at qpos0 (reference ambersim/utils/io_utils.py:226).  `nenv` adds a batch axis."""
+    dev = m.device
+    shape = (lambda n: (n,)) if nenv is None else (lambda n: (nenv, n))
+    z = lambda n: torch.zeros(shape(n), dtype=torch.float32, device=dev)
+    qpos = m.qpos0.clone() if nenv is None else m.qpos0.expand(nenv, -1).clone()
+    time = torch.zeros((), dtype=torch.float32, device=dev) if nenv is None else torch.zeros(nenv, dtype=torch.float32, device=dev)
+    return Data(qpos=qpos, qvel=z(m.nv), ctrl=z(m.nu), qacc=z(m.nv), qacc_warmstart=z(m.nv), time=time,
+                qacc_smooth=z(m.nv), qfrc_bias=z(m.nv), qfrc_constraint=z(m.nv),
+                xpos=torch.zeros(shape(m.nbody) + (3,), dtype=torch.float32, device=dev),
+                xquat=torch.zeros(shape(m.nbody) + (4,), dtype=torch.float32, device=dev))
+
+
+def put_data(m: Model, d: MjData) -> Data:
+    out = make_data(m)
+    f = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32), device=m.device)
+    return out.replace(qpos=f(d.qpos), qvel=f(d.qvel), ctrl=f(d.ctrl), qacc_warmstart=f(d.qacc_warmstart),
+                       time=torch.tensor(float(d.time), dtype=torch.float32, device=m.device))
+
+
+def device_put(x, device=None):
+    """mjx.device_put for a host model (reference ambersim/rl/base.py:52).  A host MjData needs its model:
+    use `put_data(model, data)` (MjxEnv.pipeline_init does)."""
+    if isinstance(x, MjModel):
+        return put_model(x, device)
+    raise NotImplementedError("device_put accepts a host MjModel; for MjData use put_data(model, data)")
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t.contiguous() if not t.is_contiguous() else t
+
+
+def _batch(m: Model, d: Data):
+    b = d.batched
+    g = (lambda t: _c(t.to(torch.float32))) if b else (lambda t: _c(t.to(torch.float32).unsqueeze(0)))
+    return b, g
+
+
+def forward(m: Model, d: Data) -> Data:
+    """mjx.forward (reference ambersim/rl/base.py:85, ambersim/trajopt/shooting.py:36): derived quantities, no integration."""
+    b, g = _batch(m, d)
+    qpos, qvel, ctrl, warm = g(d.qpos).clone(), g(d.qvel), g(d.ctrl), g(d.qacc_warmstart)
+    n = qpos.shape[0]
+    dev = m.device
+    new = lambda *s: torch.empty((n,) + s, dtype=torch.float32, device=dev)
+    qacc, qs, fb, fc, xpos, xquat = new(m.nv), new(m.nv), new(m.nv), new(m.nv), new(m.nbody, 3), new(m.nbody, 4)
+    out = _lib.AmxForwardOut(qacc.data_ptr(), qs.data_ptr(), fb.data_ptr(), fc.data_ptr(), None, xpos.data_ptr(), xquat.data_ptr(), None, None)
+    _lib.check(_lib.lib().amx_forward(m._h.ptr, n, qpos.data_ptr(), qvel.data_ptr(), ctrl.data_ptr(), warm.data_ptr(),
+                                      C.byref(out), _stream_ptr(dev)))
+    s = (lambda t: t) if b else (lambda t: t[0])
+    # the solver's result becomes the next warm start, as in the reference physics
+    warm_out = qacc if m.nefc_max > 0 else warm
+    return d.replace(qacc=s(qacc), qacc_smooth=s(qs), qfrc_bias=s(fb), qfrc_constraint=s(fc), xpos=s(xpos), xquat=s(xquat),
+                     qacc_warmstart=s(warm_out))
+
+
+def step(m: Model, d: Data, nsub: int = 1) -> Data:
+    """mjx.step, `nsub` times with ctrl held (reference ambersim/rl/base.py:88-96).  Functional: returns new Data."""
+    b, g = _batch(m, d)
+    qpos, qvel, warm = g(d.qpos).clone(), g(d.qvel).clone(), g(d.qacc_warmstart).clone()
+    ctrl = g(d.ctrl)
+    n = qpos.shape[0]
+    time = (d.time if b else d.time.reshape(1)).to(torch.float32).clone()
+    time = _c(time.expand(n)) if time.numel() != n else time
+    _lib.check(_lib.lib().amx_step(m._h.ptr, n, int(nsub), qpos.data_ptr(), qvel.data_ptr(), ctrl.data_ptr(), warm.data_ptr(),
+                                   time.data_ptr(), _stream_ptr(m.device)))
+    s = (lambda t: t) if b else (lambda t: t[0])
+    return d.replace(qpos=s(qpos), qvel=s(qvel), qacc_warmstart=s(warm), qacc=s(warm) if m.nefc_max > 0 else d.qacc, time=s(time))
+
+
+def rollout(m: Model, x0: torch.Tensor, us: torch.Tensor, return_traj: bool = True):
+    """Fused shoot (reference ambersim/trajopt/shooting.py:22-48) for a batch: x0 [nx] or [S,nx], us [S,N,nu]
+    -> xs [S,N+1,nx] (or the final states [S,nx] when return_traj is False)."""
+    dev = m.device
+    us = _c(us.to(device=dev, dtype=torch.float32))
+    x0 = _c(x0.to(device=dev, dtype=torch.float32))
+    S, N = us.shape[0], us.shape[1]
+    nx = m.nq + m.nv
+    if us.shape[2] != m.nu or x0.shape[-1] != nx or (x0.dim() == 2 and x0.shape[0] != S):
+        raise ValueError(f"rollout: shapes x0 {tuple(x0.shape)}, us {tuple(us.shape)} do not match nx={nx}, nu={m.nu}")
+    xs = torch.empty((S, N + 1, nx), dtype=torch.float32, device=dev) if return_traj else None
+    xf = None if return_traj else torch.empty((S, nx), dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().amx_rollout(m._h.ptr, S, N, x0.data_ptr(), int(x0.dim() == 2), us.data_ptr(),
+                                      xs.data_ptr() if xs is not None else None, xf.data_ptr() if xf is not None else None,
+                                      _stream_ptr(dev)))
+    return xs if return_traj else xf
