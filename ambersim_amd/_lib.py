@@ -10,7 +10,7 @@ from pathlib import Path
 from ._desc import AmxModelDesc
 
 _CSRC = Path(__file__).resolve().parent / "csrc"
-_LIB_PATH = _CSRC / "libamx.so"
+_LIB_PATH = Path(os.environ.get("AMX_LIBRARY", _CSRC / "libamx.so"))  # AMX_LIBRARY: diagnostic builds only
 _lib = None
 
 AMX_OK, AMX_EINVAL, AMX_EUNSUPPORTED, AMX_ENOMEM, AMX_EHIP, AMX_ECAPACITY = 0, -1, -2, -3, -4, -5

@@ -16,6 +16,9 @@
 #include "amx_kernels.hip"  // single translation unit: kernels + launchers, no relocatable device code
 
 static thread_local char g_err[512] = "";
+#ifdef AMX_PROFILE
+static float *g_prof = nullptr;
+#endif
 static int fail(int code, const char *fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -273,6 +276,7 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
   L.actf = take(nu);
   L.D = take(m.nefc); L.aref = take(m.nefc); L.Jaref = take(m.nefc); L.jv = take(m.nefc); L.J = take(m.nefc * m.ldj);
   L.cdist = take(m.ncon); L.cpos = take(3 * m.ncon); L.cframe = take(9 * np); L.gpos = take(3 * m.ngc); L.gmat = take(9 * m.ngc);
+  L.prof = take(24);
   L.total = off;
   const int lds_bytes = off * (int)sizeof(float);
   if (lds_bytes > 160 * 1024) return fail(AMX_ECAPACITY, "model needs %d bytes of LDS per environment (limit 163840)", lds_bytes);
@@ -363,8 +367,16 @@ extern "C" int amx_rollout(const amx_model *m, int nenv, int nsteps, const float
   memset(&a, 0, sizeof(a));
   a.mode = AMX_MODE_ROLLOUT; a.nenv = nenv; a.nsteps = nsteps; a.x0_batched = x0_batched;
   a.x0 = x0; a.us = us; a.xs = xs; a.xfinal = xfinal;
+#ifdef AMX_PROFILE
+  a.prof = g_prof;
+#endif
   return launch(m, a, stream);
 }
+
+#ifdef AMX_PROFILE
+// Diagnostic build only (libamx_prof.so): where a rollout's cycles go.  Not part of include/amx.h.
+extern "C" int amx_prof_set(float *dev_counters /*[nenv,24]*/) { g_prof = dev_counters; return 0; }
+#endif
 
 extern "C" int amx_quadcost(int nenv, int nsteps, int nx, int nu, const float *xs, const float *us, const float *Q, const float *Qf,
                             const float *R, const float *xg, float *cost, void *stream) {

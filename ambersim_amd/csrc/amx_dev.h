@@ -54,6 +54,7 @@ struct LdsPlan {
   int actf;
   int D, aref, Jaref, jv, J;
   int cdist, cpos, cframe, gpos, gmat;
+  int prof;   // 24 floats, used by the diagnostic build only
   int total;  // floats per environment
 };
 
@@ -70,4 +71,5 @@ struct LaunchArgs {
   // forward outputs (any may be NULL)
   float *o_qacc, *o_qacc_smooth, *o_qfrc_bias, *o_qfrc_constraint, *o_qM, *o_xpos, *o_xquat, *o_cdist;
   int *o_nefc;
+  float *prof;  // diagnostic build only: per-env per-phase cycle sums [nenv,24]
 };

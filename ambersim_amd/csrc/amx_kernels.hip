@@ -219,6 +219,18 @@ DEV void kbi(const DevModel &m, float sr0, float sr1, const float *si, float pos
 
 struct LSPoint { float alpha, cost, d0, d1; };
 
+// Diagnostic build only (-DAMX_PROFILE, libamx_prof.so): per-phase cycle shares via s_memtime.  Never in the product build.
+#ifdef AMX_PROFILE
+#define PROF_N 24
+#define PROF_DECL unsigned prof_t;
+#define PROF_INIT()
+#define PROF(id) do { unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); if (lane == 0) s[p.prof + (id)] += (float)(t_ - prof_t); prof_t = t_; } while (0)
+#else
+#define PROF_DECL
+#define PROF_INIT()
+#define PROF(id)
+#endif
+
 // =====================================================================================================
 // One environment's physics.  All members index LDS through `s` (this wave's slab).
 // =====================================================================================================
@@ -227,7 +239,7 @@ struct Env {
   const LdsPlan &p;
   float *s;
   int lane;
-  int ne_active;  // rows [0, neq) are equality rows (always quadratic)
+  PROF_DECL
 
   DEV Env(const DevModel &m_, const LdsPlan &p_, float *s_, int lane_) : m(m_), p(p_), s(s_), lane(lane_) {}
 
@@ -917,6 +929,7 @@ struct Env {
       }
     }
     WSYNC();
+    PROF(14);
     chol_solve(m.nchol, H, ldm, nv, s + p.Lb, s + p.grad, s + p.Mgrad, true, lane);
   }
 
@@ -1024,11 +1037,14 @@ struct Env {
     if (use_warm || (m.disableflags & DIS_WARMSTART)) init_context(qacc);
     cost = constraint_cost(qacc, &gauss);
     prev_cost = INFINITY;
+    PROF(9);
     constraint_force_and_grad();
+    PROF(10);
     if (m.solver == 2) newton_direction();
     else chol_solve(m.nchol, s + p.M, m.ldm, nv, s + p.Lb, grad, Mgrad, false, lane);
     for (int i = lane; i < nv; i += AMX_WAVE) search[i] = -Mgrad[i];
     WSYNC();
+    PROF(11);
     int niter = 0;
     while (true) {
       if (m.iterations != 1 || niter > 0) {
@@ -1040,7 +1056,9 @@ struct Env {
         done = done || (sqrtf(gn) / m.scale < m.tolerance);
         if (done) break;
       }
+      PROF(12);
       linesearch(gauss);
+      PROF(13);
       float pg = 0;  // CG: keep grad.Mgrad of the previous iterate
       if (m.solver != 2) {
         for (int i = lane; i < nv; i += AMX_WAVE) { pg += grad[i] * Mgrad[i]; s[p.tmp + i] = Mgrad[i]; }
@@ -1049,8 +1067,10 @@ struct Env {
       prev_cost = cost;
       cost = constraint_cost(qacc, &gauss);
       constraint_force_and_grad();
+      PROF(10);
       if (m.solver == 2) {
         newton_direction();
+        PROF(11);
         for (int i = lane; i < nv; i += AMX_WAVE) search[i] = -Mgrad[i];
       } else {
         chol_solve(m.nchol, s + p.M, m.ldm, nv, s + p.Lb, grad, Mgrad, false, lane);
@@ -1070,15 +1090,24 @@ struct Env {
   // ------------------------------------------------------------------ forward (A9.1-A9.13)
   DEV void forward() {
     const int nv = m.nv;
+    PROF(0);
     kinematics();
+    PROF(1);
     com_pos();
+    PROF(2);
     crb_and_M();
+    PROF(3);
     if (m.ncon > 0 && !(m.disableflags & (DIS_CONTACT | DIS_CONSTRAINT))) collision();
+    PROF(4);
     if (m.nefc > 0) make_constraint();
+    PROF(5);
     velocity_and_bias();
+    PROF(6);
     smooth_forces();
+    PROF(7);
     // qacc_smooth = M^-1 qfrc_smooth; the factor of M stays in Lb for the CG preconditioner
     chol_solve(m.nchol, s + p.M, m.ldm, nv, s + p.Lb, s + p.fsmooth, s + p.asmooth, true, lane);
+    PROF(8);
     if (m.nefc == 0) {
       for (int i = lane; i < nv; i += AMX_WAVE) { s[p.qacc + i] = s[p.asmooth + i]; s[p.fcon + i] = 0; }
       WSYNC();
@@ -1088,6 +1117,7 @@ struct Env {
     solve(&niter);
     for (int i = lane; i < nv; i += AMX_WAVE) s[p.warm + i] = s[p.qacc + i];
     WSYNC();
+    PROF(15);
   }
 
   // ------------------------------------------------------------------ A9.14 semi-implicit Euler
@@ -1109,6 +1139,7 @@ struct Env {
       for (int i = lane; i < nv; i += AMX_WAVE) acc[i] = qacc[i];
       WSYNC();
     }
+    PROF(16);
     for (int i = lane; i < nv; i += AMX_WAVE) qvel[i] += acc[i] * m.dt;
     WSYNC();
     for (int j = lane; j < m.njnt; j += AMX_WAVE) {
@@ -1129,6 +1160,7 @@ struct Env {
       }
     }
     WSYNC();
+    PROF(17);
   }
 };
 
@@ -1145,6 +1177,9 @@ extern "C" __global__ void __launch_bounds__(AMX_WAVE) amx_env_kernel(const DevM
   for (int i = lane; i < p.total; i += AMX_WAVE) s[i] = 0.0f;
   WSYNC();
   Env env(m, p, s, lane);
+#ifdef AMX_PROFILE
+  env.prof_t = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
   if (a.mode == AMX_MODE_ROLLOUT) {
     const float *x0 = a.x0 + (a.x0_batched ? (size_t)e * nx : 0);
     for (int i = lane; i < nx; i += AMX_WAVE) {
@@ -1171,7 +1206,14 @@ extern "C" __global__ void __launch_bounds__(AMX_WAVE) amx_env_kernel(const DevM
         float *row = a.xs + ((size_t)e * (a.nsteps + 1) + t + 1) * nx;
         for (int i = lane; i < nx; i += AMX_WAVE) row[i] = i < nq ? s[p.qpos + i] : s[p.qvel + i - nq];
       }
+#ifdef AMX_PROFILE
+      { unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); if (lane == 0) s[p.prof + 18] += (float)(t_ - env.prof_t); env.prof_t = t_; }
+#endif
     }
+#ifdef AMX_PROFILE
+    WSYNC();
+    if (a.prof && lane < PROF_N) a.prof[(size_t)e * PROF_N + lane] = s[p.prof + lane];
+#endif
     if (a.xfinal)
       for (int i = lane; i < nx; i += AMX_WAVE) a.xfinal[(size_t)e * nx + i] = i < nq ? s[p.qpos + i] : s[p.qvel + i - nq];
     return;
