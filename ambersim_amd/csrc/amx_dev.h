@@ -1,75 +1,51 @@
-// amx_dev.h — device-side model/plan description shared by amx_api.cpp (host) and amx_kernels.hip.
+// amx_dev.h — device-side model image / launch plan shared by amx_api.cpp (host) and amx_kernels.hip.
 // Internal to ambersim_amd/csrc; the public C ABI is include/amx.h.
 #pragma once
 #include <stdint.h>
 
 #define AMX_WAVE 64
-#define AMX_MAX_NV 32  // register-row Cholesky capacity (one matrix row per lane, <=32 columns)
+#define AMX_WAVES_PER_BLOCK 4  // environments per workgroup; they share one LDS copy of the model constants
+#ifndef AMX_MIN_WAVES_PER_SIMD
+#define AMX_MIN_WAVES_PER_SIMD 3  // launch bound: caps VGPRs at 168; measured best of 2/3/4 on the quadruped and biped rollouts
+#endif
+#define AMX_MAX_NV 32           // register-row Cholesky capacity (one matrix row per lane, <=32 columns)
 
-// One pool of ints and one of floats in HBM; every array is an offset into its pool.
+// Record strides (floats) of the constant image.  All odd, so lane-per-record LDS reads are conflict free.
+// Record strides (floats) of the per-environment slab, also odd.
+enum { BODY_E = 45, JNT_E = 7, DOF_E = 23, ROW_E = 3, CON_E = 5, GEO_E = 13 };
+enum { BODY_S = 25, JNT_S = 13, DOF_S = 9, ACT_S = 13, GEOM_S = 13, PAIR_S = 29, LIM_S = 15, EQ_S = 21 };
+// BodyRec: 0 parent 1 level 2 rootslot 3 jntadr 4 jntnum 5 childadr 6 childnum 7-9 pos 10-13 quat 14-16 ipos 17-20 iquat 21 mass 22-24 inertia
+// JntRec : 0 type 1 qadr 2 dadr 3 body 4-6 pos 7-9 axis 10 qpos0 11 stiffness 12 springref
+// DofRec : 0 body 1 jnt 2 kind(0 free-trans,1 free/ball-rot,2 hinge,3 slide) 3 axis 4 armature 5 damping 6 actadr 7 actnum 8 rootslot
+// ActRec : 0 qadr 1 dadr 2 flags(1 ctrllimited,2 forcelimited,4 affine bias) 3 gear 4 gain 5-7 bias 8-9 ctrlrange 10-11 forcerange 12 pad
+// GeomRec: 0 body 1 type 2-4 pos 5-8 quat 9-11 size 12 pad
+// PairRec: 0 g1 1 g2 2 fn 3 conadr 4 ncon 5 vertadr 6 vertnum 7 root1 8 root2 9 dofadr 10 dofnum 11 mu 12 k 13 b 14 dmin 15 dmax
+//          16 width 17 mid 18 power 19 ca 20 cb 21 margin 22 invw 23 hadr 24 hnum 25-28 pad
+// LimRec : 0 qadr 1 dadr 2 range0 3 range1 4 margin 5 k 6 b 7 dmin 8 dmax 9 width 10 mid 11 power 12 ca 13 cb 14 invw
+// EqRec  : 0 q1 1 d1 2 q2 3 d2 4-8 polycoef 9 k 10 b 11 dmin 12 dmax 13 width 14 mid 15 power 16 ca 17 cb 18 invw 19 qref1 20 qref2
+
+// Everything the kernel needs besides the constant image: sizes, options, and a few base offsets.
 struct DevModel {
-  const int *ip;
-  const float *fp;
-  // sizes
-  int nq, nv, nu, nb, njnt, ngc, npair, ncon, neq, nlim, nefc, nlevel, nM, nroot, ldm, ldj, nchol;
+  const float *image;  // HBM copy of the constant image (ints stored bit-cast), nconst floats
+  int nconst;
+  int nq, nv, nu, nb, njnt, ngc, npair, ncon, neq, nlim, nefc, nlevel, nM, nroot, ldm, ldj, nchol, njac, nhent;
   int iterations, ls_iterations, solver, disableflags;
   float dt, gx, gy, gz, tolerance, ls_tolerance, impratio, scale /* meaninertia*max(1,nv) */;
-  // --- int pool offsets
-  int body_parent, body_root /*slot into com[]*/, body_jntadr, body_jntnum, body_dofadr, body_dofnum;
-  int level_adr /*[nlevel+1]*/, level_body /*[nb] bodies sorted by depth*/;
-  int child_adr /*[nb+1]*/, child_list;
-  int root_body /*[nroot]*/;
-  int jnt_type, jnt_qadr, jnt_dadr, jnt_body;
-  int dof_body, dof_jnt, dof_kind /*0 free-trans k,1 free/ball-rot,2 hinge,3 slide*/, dof_axis /*k within joint*/;
-  int dof_actadr /*[nv+1]*/, dof_actlist;
-  int M_i, M_j /*[nM] sparse entries (i, ancestor j)*/;
-  int act_qadr, act_dadr, act_flags /*bit0 ctrllimited bit1 forcelimited bit2 affine bias*/;
-  int gc_body, gc_type;
-  int pair_g1, pair_g2 /*indices into the collision-geom list*/, pair_fn, pair_conadr, pair_vertadr, pair_vertnum,
-      pair_body1, pair_body2, pair_dofadr /*[npair+1]*/, pair_doflist /*union of both ancestor chains*/,
-      pair_dofsign /*bit0: in chain of body2 (+), bit1: in chain of body1 (-)*/, pair_root1, pair_root2;
-  int con_pair /*[ncon]*/, con_slot /*[ncon] index within its pair*/;
-  int lim_qadr, lim_dadr;
-  int eq_q1, eq_d1, eq_q2, eq_d2 /* -1 when absent */;
-  // --- float pool offsets
-  int body_pos, body_quat, body_ipos, body_iquat, body_mass, body_inertia;
-  int jnt_pos, jnt_axis, jnt_stiff;
-  int qpos0, qpos_spring;
-  int dof_armature, dof_damping;
-  int act_gear, act_gain, act_bias /*[nu,3]*/, act_ctrlrange, act_forcerange;
-  int gc_pos, gc_quat, gc_size;
-  int pair_mu, pair_solref, pair_solimp, pair_margin, pair_invw /*body_invweight0 sum*/, convex_vert;
-  int lim_range, lim_margin, lim_solref, lim_solimp, lim_invw;
-  int eq_data, eq_solref, eq_solimp, eq_invw1, eq_invw2;
+  // bases inside the constant image (float offsets)
+  int c_body, c_jnt, c_dof, c_act, c_geom, c_pair, c_lim, c_eq;
+  int c_child, c_M /*packed i|j<<8*/, c_dofact, c_pairdof /*packed dof|sign<<8*/, c_jac /*packed contact|pairdofslot<<8*/,
+      c_hent /*packed i|j<<8*/, c_conpair /*[ncon]*/, c_vert, c_rootbody;
+  // bases inside one environment slab (float offsets from the slab start)
+  int e_qpos, e_qvel, e_ctrl, e_warm;
+  int e_body /* records [nb][BODY_E]: xpos 0-2 xquat 3-6 cinert 7-16 crb 17-26 cvel 27-32 cacc 33-38 cfrc 39-44 */;
+  int e_jnt  /* records [njnt][JNT_E]: xanchor 0-2 xaxis 3-5 */;
+  int e_dof  /* records [nv][DOF_E]: cdof 0-5 fcrb 6-11 fsmooth 12 asmooth 13 qacc 14 Ma 15 grad 16 Mgrad 17 search 18 mv 19 fcon 20 tmp 21 fbias 22 */;
+  int e_com, e_actf;
+  int e_M, e_H, e_Lb /* Lb only allocated for the CG solver */;
+  int e_row /* records [nefc][ROW_E]: Dact 0 frow 1 */;
+  int e_J;
+  int e_con /* records [ncon][CON_E]: dist 0 pos 1-3 */, e_frame /* [npair][9] */, e_geom /* records [ngc][GEO_E]: pos 0-2 mat 3-11 */;
+  int e_prof;
+  int env_floats;  // floats per environment slab
 };
 
-// LDS layout of one environment (float offsets), computed on the host.
-struct LdsPlan {
-  int qpos, qvel, ctrl, warm;
-  int xpos, xquat, com, xanchor, xaxis;
-  int cinert, crb, cdof, fcrb;
-  int cvel, cacc, cfrc;
-  int M, H, Lb;
-  int fsmooth, asmooth, qacc, Ma, grad, Mgrad, search, mv, fcon, tmp, fbias;
-  int actf;
-  int D, aref, Jaref, jv, J;
-  int cdist, cpos, cframe, gpos, gmat;
-  int prof;   // 24 floats, used by the diagnostic build only
-  int total;  // floats per environment
-};
-
-enum { AMX_MODE_ROLLOUT = 0, AMX_MODE_STEP = 1, AMX_MODE_FORWARD = 2 };
-
-struct LaunchArgs {
-  int mode, nenv, nsteps, x0_batched;
-  const float *x0;     // rollout: [nenv,nq+nv] or [nq+nv]
-  const float *us;     // rollout: [nenv,nsteps,nu]; step/forward: ctrl [nenv,nu]
-  float *xs;           // rollout: [nenv,nsteps+1,nq+nv] or NULL
-  float *xfinal;       // rollout: [nenv,nq+nv] or NULL
-  float *qpos, *qvel, *warm, *time;  // step/forward: in place state
-  const float *warm_in;              // forward: optional warm start
-  // forward outputs (any may be NULL)
-  float *o_qacc, *o_qacc_smooth, *o_qfrc_bias, *o_qfrc_constraint, *o_qM, *o_xpos, *o_xquat, *o_cdist;
-  int *o_nefc;
-  float *prof;  // diagnostic build only: per-env per-phase cycle sums [nenv,24]
-};

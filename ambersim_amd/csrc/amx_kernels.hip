@@ -4,12 +4,15 @@
 // Replaces mjx.forward / mjx.step under MjxEnv.pipeline_step (reference ambersim/rl/base.py:81-96)
 // and shoot (reference ambersim/trajopt/shooting.py:22-48).  Stage names follow SURVEY.md §8(a)
 // A9.1-A9.14.  Layout rules:
-//   * workgroup = 1 wavefront = 1 environment, so every branch on solver state is wave-uniform
-//     and __syncthreads() lowers to a wait on the LDS queue (no s_barrier);
-//   * per-body / per-dof / per-row arrays are struct-of-arrays in LDS (component-major), so lane b
-//     touching element b is bank-conflict free; dense matrices use an odd leading dimension;
-//   * tree scans run level by level (bodies sorted by depth); up-scans gather from a static child
-//     list instead of scattering;
+//   * one wavefront = one environment, so every branch on solver state is wave-uniform; a workgroup
+//     holds AMX_WAVES_PER_BLOCK independent waves that share ONE LDS copy of the model constants
+//     (staged once, one s_barrier) and never synchronise again — phases inside a wave are ordered by
+//     wavefront-scope fences only (LDS operations of one wave execute in order);
+//   * static lane roles: lane b owns body b, lane i owns dof i, lane r owns constraint row r, so
+//     per-row solver state (D, aref, Jaref, Jv) lives in registers and role constants are read from
+//     LDS records with odd strides (bank-conflict free), never through dependent HBM loads;
+//   * per-body / per-dof arrays are struct-of-arrays in LDS; dense matrices use an odd leading dimension;
+//   * tree scans run level by level; up-scans gather from a static child list instead of scattering;
 //   * the small dense factorisations (M, M+J'DJ, M+dt*damping) hold one matrix row per lane in
 //     registers and exchange pivots with v_readlane (no LDS traffic inside the factorisation);
 //   * wave reductions use DPP row operations + v_readlane, never LDS;
@@ -19,17 +22,23 @@
 
 #define DEV __device__ __forceinline__
 #define MINVAL 1e-15f
-#define MINIMP 0.0001f
-#define MAXIMP 0.9999f
 
 enum { JFREE = 0, JBALL = 1, JSLIDE = 2, JHINGE = 3 };
 enum { DIS_CONSTRAINT = 1, DIS_EQUALITY = 2, DIS_LIMIT = 8, DIS_CONTACT = 16, DIS_PASSIVE = 32,
        DIS_GRAVITY = 64, DIS_CLAMPCTRL = 128, DIS_WARMSTART = 256, DIS_ACTUATION = 1024,
        DIS_REFSAFE = 2048, DIS_EULERDAMP = 16384 };
 
-#define IP(name, i) (m.ip[m.name + (i)])
-#define FP(name, i) (m.fp[m.name + (i)])
-#define WSYNC() __syncthreads()
+extern __shared__ float lds[];
+#define CF(off) (lds[(off)])
+#define CI(off) (__float_as_int(lds[(off)]))
+// Orders this wave's LDS traffic between phases: compiler-level only, the hardware keeps one wave's
+// LDS operations in issue order.
+#define WSYNC()                                              \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+    __builtin_amdgcn_wave_barrier();                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+  } while (0)
 
 struct f3 { float x, y, z; };
 struct f4 { float w, x, y, z; };
@@ -67,7 +76,7 @@ DEV f3 mulTv(const m33 &M, f3 v) {
 DEV f3 qrot(f4 q, f3 v) { return mulv(q2m(q), v); }
 DEV f4 qnormalize(f4 q) {
   float n = sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
-  if (n > 0) { float s = 1.0f / n; q.w *= s; q.x *= s; q.y *= s; q.z *= s; }  // division by n, as a reciprocal multiply
+  if (n > 0) { float s = 1.0f / n; q.w *= s; q.x *= s; q.y *= s; q.z *= s; }
   return q;
 }
 DEV f3 normalize3(f3 v, float *len) {
@@ -123,7 +132,7 @@ DEV float readlane_f(float x, int lane) { return __int_as_float(__builtin_amdgcn
 template <int CTRL> DEV float dpp_f(float x) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
 }
-// Sum over the 64 lanes, result uniform.  quad_perm xor1, xor2, row_half_mirror, row_mirror inside each
+// Sum over the 64 lanes, result uniform: quad_perm xor1, xor2, row_half_mirror, row_mirror inside each
 // 16-lane row (DPP, no LDS), then the four row totals are combined through v_readlane.
 DEV float wave_sum(float x) {
   x += dpp_f<0xB1>(x);   // quad_perm [1,0,3,2]
@@ -132,89 +141,91 @@ DEV float wave_sum(float x) {
   x += dpp_f<0x140>(x);  // row_mirror
   return (readlane_f(x, 0) + readlane_f(x, 16)) + (readlane_f(x, 32) + readlane_f(x, 48));
 }
-DEV float wave_max(float x) {
-  x = fmaxf(x, dpp_f<0xB1>(x));
-  x = fmaxf(x, dpp_f<0x4E>(x));
-  x = fmaxf(x, dpp_f<0x141>(x));
-  x = fmaxf(x, dpp_f<0x140>(x));
-  return fmaxf(fmaxf(readlane_f(x, 0), readlane_f(x, 16)), fmaxf(readlane_f(x, 32), readlane_f(x, 48)));
-}
 
-// ---- register-row dense Cholesky: lane i holds row i of A (lower part).  Solves A x = rhs.
-// Lb receives L (row-major, leading dimension ld) and is also the staging buffer for the
-// transposed read of the back substitution.  When `factor` is false the factor already in Lb is reused.
+// ---- register-row dense Cholesky: lane i holds row i of the matrix at lds[A_off] (lower part).
+// Solves A x = rhs.  L is written row-major to lds[L_off] (may equal A_off: each lane overwrites only
+// its own row after reading it); the two substitutions re-read it masked (strict lower rows, then
+// strict lower columns), so every lane runs the same 3-instruction update per pivot.
+// `factor == false` reuses the factor already stored at L_off (CG preconditioner).
+// Pivot reciprocals use v_rsq_f32 + one Newton step (<= 1 ulp) instead of the IEEE sqrt/divide expansions.
 template <int N>
-__device__ __noinline__ void chol_solve_rows(const float *A, int ld, int n, float *Lb, const float *rhs, float *x,
-                                             bool factor, int lane) {
-  float a[N], invd[N];
+__device__ __noinline__ void chol_solve_rows(int A_off, int ld, int n, int L_off, int rhs_off, int x_off, int vstride, bool factor, int lane) {
+  float a[N];
+  const int li = lane < n ? lane : 0, row = li * ld;
   if (factor) {
 #pragma unroll
-    for (int k = 0; k < N; ++k) a[k] = (lane < n && k < n) ? A[lane * ld + k] : (k == lane ? 1.0f : 0.0f);
+    for (int k = 0; k < N; ++k) {
+      const float v = lds[A_off + row + (k < n ? k : 0)];
+      a[k] = (lane < n && k < n) ? v : (k == lane ? 1.0f : 0.0f);
+    }
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-      float ajj = readlane_f(a[j], j);
-      ajj = ajj > 0 ? ajj : MINVAL;
-      float inv = 1.0f / sqrtf(ajj);
-      invd[j] = inv;
-      float lij = a[j] * inv;
+      const float ajj = fmaxf(readlane_f(a[j], j), MINVAL);
+      float inv = __builtin_amdgcn_rsqf(ajj);
+      inv = inv * __builtin_fmaf(-0.5f * ajj * inv, inv, 1.5f);
+      const float lij = a[j] * inv;
       a[j] = lij;
 #pragma unroll
-      for (int k = j + 1; k < N; ++k) a[k] -= lij * readlane_f(lij, k);
+      for (int k = j + 1; k < N; ++k) a[k] = __builtin_fmaf(-lij, readlane_f(lij, k), a[k]);
     }
     if (lane < n) {
 #pragma unroll
       for (int k = 0; k < N; ++k)
-        if (k < n) Lb[lane * ld + k] = a[k];
+        if (k < n) lds[L_off + row + k] = a[k];
     }
-  } else {
-#pragma unroll
-    for (int k = 0; k < N; ++k) a[k] = (lane < n && k < n) ? Lb[lane * ld + k] : (k == lane ? 1.0f : 0.0f);
-#pragma unroll
-    for (int j = 0; j < N; ++j) invd[j] = 1.0f / readlane_f(a[j], j);
+    WSYNC();
   }
-  float b = lane < n ? rhs[lane] : 0.0f;
+  const float dinv = 1.0f / lds[L_off + row + li];
 #pragma unroll
-  for (int j = 0; j < N; ++j) {  // forward: L y = rhs
-    float yj = readlane_f(b, j) * invd[j];
-    b = lane == j ? yj : (lane > j ? b - a[j] * yj : b);
+  for (int k = 0; k < N; ++k) {  // strict lower part of row `lane`
+    const float v = lds[L_off + row + (k < n ? k : 0)];
+    a[k] = (lane < n && k < lane && k < n) ? v : 0.0f;
   }
-  WSYNC();
+  float b = lds[rhs_off + li * vstride];
+  b = lane < n ? b : 0.0f;
 #pragma unroll
-  for (int k = 0; k < N; ++k) a[k] = (lane < n && k < n && k >= lane) ? Lb[k * ld + lane] : 0.0f;  // column `lane` of L
+  for (int j = 0; j < N; ++j) {  // forward: L y = rhs; lane j's b is final when pivot j is reached
+    const float yj = readlane_f(b * dinv, j);
+    b = __builtin_fmaf(-a[j], yj, b);
+  }
+  b *= dinv;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {  // strict lower part of column `lane`
+    const float v = lds[L_off + (k < n ? k : 0) * ld + li];
+    a[k] = (lane < n && k > lane && k < n) ? v : 0.0f;
+  }
 #pragma unroll
   for (int j = N - 1; j >= 0; --j) {  // backward: L' x = y
-    float xj = readlane_f(b, j) * invd[j];
-    b = lane == j ? xj : (lane < j ? b - a[j] * xj : b);
+    const float xj = readlane_f(b * dinv, j);
+    b = __builtin_fmaf(-a[j], xj, b);
   }
-  if (lane < n) x[lane] = b;
+  if (lane < n) lds[x_off + lane * vstride] = b * dinv;
   WSYNC();
 }
 
-DEV void chol_solve(int nchol, const float *A, int ld, int n, float *Lb, const float *rhs, float *x, bool factor, int lane) {
-  if (nchol <= 8) chol_solve_rows<8>(A, ld, n, Lb, rhs, x, factor, lane);
-  else if (nchol <= 16) chol_solve_rows<16>(A, ld, n, Lb, rhs, x, factor, lane);
-  else if (nchol <= 24) chol_solve_rows<24>(A, ld, n, Lb, rhs, x, factor, lane);
-  else chol_solve_rows<32>(A, ld, n, Lb, rhs, x, factor, lane);
+// one out-of-line dispatcher so the call sites stay small
+__device__ __noinline__ void chol_solve(int nchol, int A_off, int ld, int n, int L_off, int rhs_off, int x_off, bool factor, int lane) {
+  const int vstride = DOF_E;
+  if (nchol <= 4) chol_solve_rows<4>(A_off, ld, n, L_off, rhs_off, x_off, vstride, factor, lane);
+  else if (nchol <= 8) chol_solve_rows<8>(A_off, ld, n, L_off, rhs_off, x_off, vstride, factor, lane);
+  else if (nchol <= 12) chol_solve_rows<12>(A_off, ld, n, L_off, rhs_off, x_off, vstride, factor, lane);
+  else if (nchol <= 16) chol_solve_rows<16>(A_off, ld, n, L_off, rhs_off, x_off, vstride, factor, lane);
+  else if (nchol <= 20) chol_solve_rows<20>(A_off, ld, n, L_off, rhs_off, x_off, vstride, factor, lane);
+  else if (nchol <= 24) chol_solve_rows<24>(A_off, ld, n, L_off, rhs_off, x_off, vstride, factor, lane);
+  else if (nchol <= 28) chol_solve_rows<28>(A_off, ld, n, L_off, rhs_off, x_off, vstride, factor, lane);
+  else chol_solve_rows<32>(A_off, ld, n, L_off, rhs_off, x_off, vstride, factor, lane);
 }
 
-// impedance / reference acceleration parameters of one constraint row [A9.6]
-DEV void kbi(const DevModel &m, float sr0, float sr1, const float *si, float pos, float *k, float *b, float *imp) {
-  float timeconst = sr0, dampratio = sr1;
-  if (!(m.disableflags & DIS_REFSAFE)) timeconst = fmaxf(timeconst, 2 * m.dt);
-  float dmin = fminf(fmaxf(si[0], MINIMP), MAXIMP), dmax = fminf(fmaxf(si[1], MINIMP), MAXIMP);
-  float width = fmaxf(MINVAL, si[2]), mid = fminf(fmaxf(si[3], MINIMP), MAXIMP), power = fmaxf(1.0f, si[4]);
-  float kk = 1.0f / (dmax * dmax * timeconst * timeconst * dampratio * dampratio);
-  float bb = 2.0f / (dmax * timeconst);
-  if (sr0 <= 0) kk = -sr0 / (dmax * dmax);
-  if (sr1 <= 0) bb = -sr1 / dmax;
-  float x = fabsf(pos) / width;
-  float ia = (1.0f / powf(mid, power - 1)) * powf(x, power);
-  float ib = 1.0f - (1.0f / powf(1 - mid, power - 1)) * powf(1 - x, power);
-  float y = x < mid ? ia : ib;
-  float v = dmin + y * (dmax - dmin);
+// impedance of one constraint row [A9.6]; k and b are folded on the host, rec points at {k,b,dmin,dmax,width,mid,power,ca,cb}
+DEV float row_impedance(int rec, float pos) {
+  const float dmin = CF(rec + 2), dmax = CF(rec + 3), width = CF(rec + 4), mid = CF(rec + 5), power = CF(rec + 6);
+  const float x = fabsf(pos) / width;
+  float ia, ib;
+  if (power == 2.0f) { ia = CF(rec + 7) * (x * x); ib = 1.0f - CF(rec + 8) * ((1 - x) * (1 - x)); }
+  else { ia = CF(rec + 7) * powf(x, power); ib = 1.0f - CF(rec + 8) * powf(1 - x, power); }
+  float v = dmin + (x < mid ? ia : ib) * (dmax - dmin);
   v = fminf(fmaxf(v, dmin), dmax);
-  if (x > 1.0f) v = dmax;
-  *k = kk; *b = bb; *imp = v;
+  return x > 1.0f ? dmax : v;
 }
 
 struct LSPoint { float alpha, cost, d0, d1; };
@@ -223,135 +234,151 @@ struct LSPoint { float alpha, cost, d0, d1; };
 #ifdef AMX_PROFILE
 #define PROF_N 24
 #define PROF_DECL unsigned prof_t;
-#define PROF_INIT()
-#define PROF(id) do { unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); if (lane == 0) s[p.prof + (id)] += (float)(t_ - prof_t); prof_t = t_; } while (0)
+#define PROF(id) do { unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); if (lane == 0) lds[eb + m.e_prof + (id)] += (float)(t_ - prof_t); prof_t = t_; } while (0)
 #else
 #define PROF_DECL
-#define PROF_INIT()
 #define PROF(id)
 #endif
 
 // =====================================================================================================
-// One environment's physics.  All members index LDS through `s` (this wave's slab).
+// One environment's physics.  `eb` is this wave's slab in LDS; constants live at the front of LDS.
 // =====================================================================================================
 struct Env {
   const DevModel &m;
-  const LdsPlan &p;
-  float *s;
-  int lane;
+  const int eb, lane;
+  // static role constants of this lane
+  int b_parent, b_level, b_root, b_jntadr, b_jntnum, b_childadr, b_childnum;  // body `lane`
+  int d_body, d_jnt, d_kind, d_axis, d_root;                                  // dof `lane`
+  // per-row solver state of row `lane`
+  float rD, rAref, rJaref, rJv;
   PROF_DECL
 
-  DEV Env(const DevModel &m_, const LdsPlan &p_, float *s_, int lane_) : m(m_), p(p_), s(s_), lane(lane_) {}
+  DEV Env(const DevModel &m_, int eb_, int lane_) : m(m_), eb(eb_), lane(lane_) {
+    const int br = m.c_body + (lane < m.nb ? lane : 0) * BODY_S;
+    b_parent = CI(br); b_level = lane < m.nb ? CI(br + 1) : -1; b_root = CI(br + 2); b_jntadr = CI(br + 3); b_jntnum = CI(br + 4);
+    b_childadr = CI(br + 5); b_childnum = CI(br + 6);
+    const int dr = m.c_dof + (lane < m.nv ? lane : 0) * DOF_S;
+    d_body = CI(dr); d_jnt = CI(dr + 1); d_kind = CI(dr + 2); d_axis = CI(dr + 3); d_root = CI(dr + 8);
+    rD = rAref = rJaref = rJv = 0.0f;
+  }
+
+  // SoA accessors of the environment slab
+  // Records with odd compile-time strides: lane-per-record access is bank-conflict free and every field
+  // is an immediate offset from one base address (no per-field address registers).
+  DEV float &body(int f, int b) const { return lds[eb + m.e_body + b * BODY_E + f]; }
+  DEV float &jnt(int f, int j) const { return lds[eb + m.e_jnt + j * JNT_E + f]; }
+  DEV float &dof(int f, int i) const { return lds[eb + m.e_dof + i * DOF_E + f]; }
+  DEV float &row(int f, int r) const { return lds[eb + m.e_row + r * ROW_E + f]; }
+  DEV float &con(int f, int c) const { return lds[eb + m.e_con + c * CON_E + f]; }
+  DEV float &geo(int f, int g) const { return lds[eb + m.e_geom + g * GEO_E + f]; }
+  DEV f3 ld_xpos(int b) const { return mk3(body(0, b), body(1, b), body(2, b)); }
+  DEV f4 ld_xquat(int b) const { f4 q = {body(3, b), body(4, b), body(5, b), body(6, b)}; return q; }
+  DEV f3 ld_com(int r) const { const int o = eb + m.e_com + 3 * r; return mk3(lds[o], lds[o + 1], lds[o + 2]); }
+  DEV sv ld_bsv(int f0, int b) const { sv r = {{body(f0, b), body(f0 + 1, b), body(f0 + 2, b), body(f0 + 3, b), body(f0 + 4, b), body(f0 + 5, b)}}; return r; }
+  DEV void st_bsv(int f0, int b, const sv &v) const {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) body(f0 + k, b) = v.v[k];
+  }
+  DEV sv ld_dsv(int f0, int i) const { sv r = {{dof(f0, i), dof(f0 + 1, i), dof(f0 + 2, i), dof(f0 + 3, i), dof(f0 + 4, i), dof(f0 + 5, i)}}; return r; }
+  DEV void st_dsv(int f0, int i, const sv &v) const {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dof(f0 + k, i) = v.v[k];
+  }
+  enum { F_XPOS = 0, F_XQUAT = 3, F_CINERT = 7, F_CRB = 17, F_CVEL = 27, F_CACC = 33, F_CFRC = 39 };
+  enum { D_CDOF = 0, D_FCRB = 6, D_FSMOOTH = 12, D_ASMOOTH = 13, D_QACC = 14, D_MA = 15, D_GRAD = 16, D_MGRAD = 17,
+         D_SEARCH = 18, D_MV = 19, D_FCON = 20, D_TMP = 21, D_FBIAS = 22 };
+  DEV int dofoff(int f) const { return eb + m.e_dof + f; }  // element i of dof field f lives at dofoff(f) + i*DOF_E
 
   // ------------------------------------------------------------------ A9.1 kinematics
   DEV void kinematics() {
-    const int nb = m.nb, nj = m.njnt;
-    float *xpos = s + p.xpos, *xquat = s + p.xquat, *qpos = s + p.qpos;
+    const int b = lane;
     if (lane == 0) {
-      xpos[0] = 0; xpos[nb] = 0; xpos[2 * nb] = 0;
-      xquat[0] = 1; xquat[nb] = 0; xquat[2 * nb] = 0; xquat[3 * nb] = 0;
+      body(0, 0) = 0; body(1, 0) = 0; body(2, 0) = 0;
+      body(3, 0) = 1; body(4, 0) = 0; body(5, 0) = 0; body(6, 0) = 0;
     }
     WSYNC();
+    const int br = m.c_body + (b < m.nb ? b : 0) * BODY_S;
+    const f3 bpos = mk3(CF(br + 7), CF(br + 8), CF(br + 9));
+    const f4 bquat = {CF(br + 10), CF(br + 11), CF(br + 12), CF(br + 13)};
     for (int L = 1; L < m.nlevel; ++L) {
-      const int beg = IP(level_adr, L), end = IP(level_adr, L + 1);
-      for (int t = beg + lane; t < end; t += AMX_WAVE) {
-        const int b = IP(level_body, t), par = IP(body_parent, b);
-        f3 ppos = mk3(xpos[par], xpos[nb + par], xpos[2 * nb + par]);
-        f4 pq = {xquat[par], xquat[nb + par], xquat[2 * nb + par], xquat[3 * nb + par]};
-        f3 pos = ppos + qrot(pq, mk3(FP(body_pos, 3 * b), FP(body_pos, 3 * b + 1), FP(body_pos, 3 * b + 2)));
-        f4 bq = {FP(body_quat, 4 * b), FP(body_quat, 4 * b + 1), FP(body_quat, 4 * b + 2), FP(body_quat, 4 * b + 3)};
-        f4 quat = qmul(pq, bq);
-        const int ja = IP(body_jntadr, b), jn = IP(body_jntnum, b);
-        for (int k = 0; k < jn; ++k) {
-          const int j = ja + k, t_ = IP(jnt_type, j), qa = IP(jnt_qadr, j);
-          f3 jpos = mk3(FP(jnt_pos, 3 * j), FP(jnt_pos, 3 * j + 1), FP(jnt_pos, 3 * j + 2));
-          f3 jax = mk3(FP(jnt_axis, 3 * j), FP(jnt_axis, 3 * j + 1), FP(jnt_axis, 3 * j + 2));
+      if (b_level == L) {
+        const int par = b_parent;
+        const f4 pq = ld_xquat(par);
+        f3 pos = ld_xpos(par) + qrot(pq, bpos);
+        f4 quat = qmul(pq, bquat);
+        for (int k = 0; k < b_jntnum; ++k) {
+          const int j = b_jntadr + k, jr = m.c_jnt + j * JNT_S;
+          const int t_ = CI(jr), qa = eb + m.e_qpos + CI(jr + 1);
+          const f3 jpos = mk3(CF(jr + 4), CF(jr + 5), CF(jr + 6)), jax = mk3(CF(jr + 7), CF(jr + 8), CF(jr + 9));
           f3 anchor, axis;
           if (t_ == JFREE) {
-            anchor = mk3(qpos[qa], qpos[qa + 1], qpos[qa + 2]);
+            anchor = mk3(lds[qa], lds[qa + 1], lds[qa + 2]);
             axis = mk3(0, 0, 1);
             pos = anchor;
-            f4 q = {qpos[qa + 3], qpos[qa + 4], qpos[qa + 5], qpos[qa + 6]};
+            f4 q = {lds[qa + 3], lds[qa + 4], lds[qa + 5], lds[qa + 6]};
             q = qnormalize(q);
-            qpos[qa + 3] = q.w; qpos[qa + 4] = q.x; qpos[qa + 5] = q.y; qpos[qa + 6] = q.z;
+            lds[qa + 3] = q.w; lds[qa + 4] = q.x; lds[qa + 5] = q.y; lds[qa + 6] = q.z;
             quat = q;
           } else {
             anchor = qrot(quat, jpos) + pos;
             axis = qrot(quat, jax);
             if (t_ == JBALL) {
-              f4 q = {qpos[qa], qpos[qa + 1], qpos[qa + 2], qpos[qa + 3]};
+              f4 q = {lds[qa], lds[qa + 1], lds[qa + 2], lds[qa + 3]};
               q = qnormalize(q);
-              qpos[qa] = q.w; qpos[qa + 1] = q.x; qpos[qa + 2] = q.y; qpos[qa + 3] = q.z;
+              lds[qa] = q.w; lds[qa + 1] = q.x; lds[qa + 2] = q.y; lds[qa + 3] = q.z;
               quat = qmul(quat, q);
               pos = anchor - qrot(quat, jpos);
             } else if (t_ == JHINGE) {
-              quat = qmul(quat, axisangle(jax, qpos[qa] - FP(qpos0, qa)));
+              quat = qmul(quat, axisangle(jax, lds[qa] - CF(jr + 10)));
               pos = anchor - qrot(quat, jpos);
             } else {
-              pos = pos + axis * (qpos[qa] - FP(qpos0, qa));
+              pos = pos + axis * (lds[qa] - CF(jr + 10));
             }
           }
-          float *xa = s + p.xanchor, *xx = s + p.xaxis;
-          xa[j] = anchor.x; xa[nj + j] = anchor.y; xa[2 * nj + j] = anchor.z;
-          xx[j] = axis.x; xx[nj + j] = axis.y; xx[2 * nj + j] = axis.z;
+          jnt(0, j) = anchor.x; jnt(1, j) = anchor.y; jnt(2, j) = anchor.z;
+          jnt(3, j) = axis.x; jnt(4, j) = axis.y; jnt(5, j) = axis.z;
         }
-        xpos[b] = pos.x; xpos[nb + b] = pos.y; xpos[2 * nb + b] = pos.z;
-        xquat[b] = quat.w; xquat[nb + b] = quat.x; xquat[2 * nb + b] = quat.y; xquat[3 * nb + b] = quat.z;
+        body(0, b) = pos.x; body(1, b) = pos.y; body(2, b) = pos.z;
+        body(3, b) = quat.w; body(4, b) = quat.x; body(5, b) = quat.y; body(6, b) = quat.z;
       }
       WSYNC();
     }
   }
 
-  DEV f3 ld_xpos(int b) const { const float *x = s + p.xpos; return mk3(x[b], x[m.nb + b], x[2 * m.nb + b]); }
-  DEV f4 ld_xquat(int b) const {
-    const float *x = s + p.xquat;
-    f4 q = {x[b], x[m.nb + b], x[2 * m.nb + b], x[3 * m.nb + b]};
-    return q;
-  }
-  DEV f3 ld_com(int r) const { const float *c = s + p.com; return mk3(c[3 * r], c[3 * r + 1], c[3 * r + 2]); }
-
-  // ------------------------------------------------------------------ A9.2 com_pos: tree COM, cinert, cdof
+  // ------------------------------------------------------------------ A9.2 com_pos: tree COM, cinert, cdof (+ collision geom poses)
   DEV void com_pos() {
-    const int nb = m.nb, nv = m.nv, nj = m.njnt;
+    const int b = lane, nb = m.nb;
+    const bool isb = b > 0 && b < nb;
+    const int br = m.c_body + (isb ? b : 0) * BODY_S;
+    f3 xi = mk3(0, 0, 0);
+    f4 xq = {1, 0, 0, 0};
+    const float ms = isb ? CF(br + 21) : 0.0f;
+    if (isb) {
+      xq = ld_xquat(b);
+      xi = ld_xpos(b) + qrot(xq, mk3(CF(br + 14), CF(br + 15), CF(br + 16)));
+    }
     for (int r = 0; r < m.nroot; ++r) {
-      float sx = 0, sy = 0, sz = 0, sm = 0;
-      for (int b = 1 + lane; b < nb; b += AMX_WAVE) {
-        if (IP(body_root, b) == r) {
-          f3 ip = mk3(FP(body_ipos, 3 * b), FP(body_ipos, 3 * b + 1), FP(body_ipos, 3 * b + 2));
-          f3 xi = ld_xpos(b) + qrot(ld_xquat(b), ip);
-          float ms = FP(body_mass, b);
-          sx += xi.x * ms; sy += xi.y * ms; sz += xi.z * ms; sm += ms;
-        }
-      }
-      sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz); sm = wave_sum(sm);
-      if (lane == 0) {
-        float *c = s + p.com + 3 * r;
-        if (sm < MINVAL) {
-          const int rb = IP(root_body, r);
-          f3 ip = mk3(FP(body_ipos, 3 * rb), FP(body_ipos, 3 * rb + 1), FP(body_ipos, 3 * rb + 2));
-          f3 xi = ld_xpos(rb) + qrot(ld_xquat(rb), ip);
-          c[0] = xi.x; c[1] = xi.y; c[2] = xi.z;
-        } else {
-          c[0] = sx / sm; c[1] = sy / sm; c[2] = sz / sm;
-        }
+      const bool mine = isb && b_root == r;
+      float sx = wave_sum(mine ? xi.x * ms : 0.0f), sy = wave_sum(mine ? xi.y * ms : 0.0f), sz = wave_sum(mine ? xi.z * ms : 0.0f),
+            sm = wave_sum(mine ? ms : 0.0f);
+      const int rb = CI(m.c_rootbody + r);
+      if (b == rb) {  // the root body itself writes the tree's COM
+        const int o = eb + m.e_com + 3 * r;
+        if (sm < MINVAL) { lds[o] = xi.x; lds[o + 1] = xi.y; lds[o + 2] = xi.z; }
+        else { lds[o] = sx / sm; lds[o + 1] = sy / sm; lds[o + 2] = sz / sm; }
       }
     }
     WSYNC();
-    float *ci = s + p.cinert;
-    for (int b = lane; b < nb; b += AMX_WAVE) {
+    if (b < nb) {
       float r[10];
       if (b == 0) {
 #pragma unroll
         for (int k = 0; k < 10; ++k) r[k] = 0;
       } else {
-        f4 xq = ld_xquat(b);
-        f3 ip = mk3(FP(body_ipos, 3 * b), FP(body_ipos, 3 * b + 1), FP(body_ipos, 3 * b + 2));
-        f3 xi = ld_xpos(b) + qrot(xq, ip);
-        f4 iq = {FP(body_iquat, 4 * b), FP(body_iquat, 4 * b + 1), FP(body_iquat, 4 * b + 2), FP(body_iquat, 4 * b + 3)};
-        m33 R = q2m(qmul(xq, iq));
-        f3 h = xi - ld_com(IP(body_root, b));
-        const float i0 = FP(body_inertia, 3 * b), i1 = FP(body_inertia, 3 * b + 1), i2 = FP(body_inertia, 3 * b + 2);
-        const float ms = FP(body_mass, b);
+        const f4 iq = {CF(br + 17), CF(br + 18), CF(br + 19), CF(br + 20)};
+        const m33 R = q2m(qmul(xq, iq));
+        const f3 h = xi - ld_com(b_root);
+        const float i0 = CF(br + 22), i1 = CF(br + 23), i2 = CF(br + 24);
 #define RIR(i, j) (R.a[3 * i] * i0 * R.a[3 * j] + R.a[3 * i + 1] * i1 * R.a[3 * j + 1] + R.a[3 * i + 2] * i2 * R.a[3 * j + 2])
         r[0] = RIR(0, 0) + ms * (h.y * h.y + h.z * h.z);
         r[1] = RIR(1, 1) + ms * (h.x * h.x + h.z * h.z);
@@ -363,135 +390,118 @@ struct Env {
         r[6] = ms * h.x; r[7] = ms * h.y; r[8] = ms * h.z; r[9] = ms;
       }
 #pragma unroll
-      for (int k = 0; k < 10; ++k) ci[k * nb + b] = r[k];
+      for (int k = 0; k < 10; ++k) body(F_CINERT + k, b) = r[k];
     }
-    float *cd = s + p.cdof;
-    const float *xa = s + p.xanchor, *xx = s + p.xaxis;
-    for (int i = lane; i < nv; i += AMX_WAVE) {
-      const int j = IP(dof_jnt, i), b = IP(dof_body, i), kind = IP(dof_kind, i), ax = IP(dof_axis, i);
-      f3 off = ld_com(IP(body_root, b)) - mk3(xa[j], xa[nj + j], xa[2 * nj + j]);
+    if (lane < m.nv) {
+      const int i = lane, j = d_jnt;
+      const f3 off = ld_com(d_root) - mk3(jnt(0, j), jnt(1, j), jnt(2, j));
       f3 w = mk3(0, 0, 0), l = mk3(0, 0, 0);
-      if (kind == 0) {
-        l = mk3(ax == 0 ? 1.0f : 0.0f, ax == 1 ? 1.0f : 0.0f, ax == 2 ? 1.0f : 0.0f);
-      } else if (kind == 1) {
-        m33 R = q2m(ld_xquat(b));
-        w = mk3(R.a[ax], R.a[3 + ax], R.a[6 + ax]);
+      if (d_kind == 0) {
+        l = mk3(d_axis == 0 ? 1.0f : 0.0f, d_axis == 1 ? 1.0f : 0.0f, d_axis == 2 ? 1.0f : 0.0f);
+      } else if (d_kind == 1) {
+        const m33 R = q2m(ld_xquat(d_body));
+        w = mk3(R.a[d_axis], R.a[3 + d_axis], R.a[6 + d_axis]);
         l = cross(w, off);
-      } else if (kind == 2) {
-        w = mk3(xx[j], xx[nj + j], xx[2 * nj + j]);
+      } else if (d_kind == 2) {
+        w = mk3(jnt(3, j), jnt(4, j), jnt(5, j));
         l = cross(w, off);
       } else {
-        l = mk3(xx[j], xx[nj + j], xx[2 * nj + j]);
+        l = mk3(jnt(3, j), jnt(4, j), jnt(5, j));
       }
-      cd[i] = w.x; cd[nv + i] = w.y; cd[2 * nv + i] = w.z; cd[3 * nv + i] = l.x; cd[4 * nv + i] = l.y; cd[5 * nv + i] = l.z;
+      dof(0, i) = w.x; dof(1, i) = w.y; dof(2, i) = w.z; dof(3, i) = l.x; dof(4, i) = l.y; dof(5, i) = l.z;
+    }
+    if (lane < m.ngc) {
+      const int g = lane, gr = m.c_geom + g * GEOM_S, gb = CI(gr);
+      const f4 q = ld_xquat(gb);
+      const f3 pos = ld_xpos(gb) + qrot(q, mk3(CF(gr + 2), CF(gr + 3), CF(gr + 4)));
+      const f4 gq = {CF(gr + 5), CF(gr + 6), CF(gr + 7), CF(gr + 8)};
+      const m33 R = q2m(qmul(q, gq));
+      geo(0, g) = pos.x; geo(1, g) = pos.y; geo(2, g) = pos.z;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) geo(3 + k, g) = R.a[k];
     }
     WSYNC();
-  }
-
-  DEV sv ld_sv(int base, int n, int i) const {
-    const float *a = s + base;
-    sv r = {{a[i], a[n + i], a[2 * n + i], a[3 * n + i], a[4 * n + i], a[5 * n + i]}};
-    return r;
-  }
-  DEV void st_sv(int base, int n, int i, const sv &v) {
-    float *a = s + base;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) a[k * n + i] = v.v[k];
   }
 
   // ------------------------------------------------------------------ A9.3 crb + mass matrix
   DEV void crb_and_M() {
-    const int nb = m.nb, nv = m.nv, ldm = m.ldm;
-    float *crb = s + p.crb;
-    const float *ci = s + p.cinert;
+    const int b = lane, nv = m.nv, ldm = m.ldm;
     for (int L = m.nlevel - 1; L >= 1; --L) {
-      const int beg = IP(level_adr, L), end = IP(level_adr, L + 1);
-      for (int t = beg + lane; t < end; t += AMX_WAVE) {
-        const int b = IP(level_body, t);
+      if (b_level == L) {
         float r[10];
 #pragma unroll
-        for (int k = 0; k < 10; ++k) r[k] = ci[k * nb + b];
-        for (int c = IP(child_adr, b); c < IP(child_adr, b + 1); ++c) {
-          const int cb = IP(child_list, c);
+        for (int k = 0; k < 10; ++k) r[k] = body(F_CINERT + k, b);
+        for (int c = 0; c < b_childnum; ++c) {
+          const int cb = CI(m.c_child + b_childadr + c);
 #pragma unroll
-          for (int k = 0; k < 10; ++k) r[k] += crb[k * nb + cb];
+          for (int k = 0; k < 10; ++k) r[k] += body(F_CRB + k, cb);
         }
 #pragma unroll
-        for (int k = 0; k < 10; ++k) crb[k * nb + b] = r[k];
+        for (int k = 0; k < 10; ++k) body(F_CRB + k, b) = r[k];
       }
       WSYNC();
     }
-    for (int i = lane; i < nv; i += AMX_WAVE) {
-      const int b = IP(dof_body, i);
+    if (lane < nv) {
       float I[10];
 #pragma unroll
-      for (int k = 0; k < 10; ++k) I[k] = crb[k * nb + b];
-      st_sv(p.fcrb, nv, i, inert_mul(I, ld_sv(p.cdof, nv, i)));
+      for (int k = 0; k < 10; ++k) I[k] = body(F_CRB + k, d_body);
+      st_dsv(D_FCRB, lane, inert_mul(I, ld_dsv(D_CDOF, lane)));
     }
     WSYNC();
-    float *M = s + p.M;
+    const int Mo = eb + m.e_M;
     for (int e = lane; e < m.nM; e += AMX_WAVE) {
-      const int i = IP(M_i, e), j = IP(M_j, e);
-      sv f = ld_sv(p.fcrb, nv, i), c = ld_sv(p.cdof, nv, j);
+      const int pk = CI(m.c_M + e), i = pk & 255, j = pk >> 8;
+      const sv f = ld_dsv(D_FCRB, i), c = ld_dsv(D_CDOF, j);
       float v = 0;
 #pragma unroll
       for (int k = 0; k < 6; ++k) v += c.v[k] * f.v[k];
-      if (i == j) v += FP(dof_armature, i);
-      M[i * ldm + j] = v;
-      M[j * ldm + i] = v;
+      if (i == j) v += CF(m.c_dof + i * DOF_S + 4);
+      lds[Mo + i * ldm + j] = v;
+      lds[Mo + j * ldm + i] = v;
     }
     WSYNC();
   }
 
   // ------------------------------------------------------------------ A9.8 com_vel + A9.10 rne (one down-scan, one up-scan)
   DEV void velocity_and_bias() {
-    const int nb = m.nb, nv = m.nv;
-    const float *qvel = s + p.qvel, *ci = s + p.cinert;
+    const int b = lane;
+    const int qv = eb + m.e_qvel;
     if (lane == 0) {
       sv z = {{0, 0, 0, 0, 0, 0}};
-      st_sv(p.cvel, nb, 0, z);
+      st_bsv(F_CVEL, 0, z);
+      st_bsv(F_CFRC, 0, z);
       if (!(m.disableflags & DIS_GRAVITY)) { z.v[3] = -m.gx; z.v[4] = -m.gy; z.v[5] = -m.gz; }
-      st_sv(p.cacc, nb, 0, z);
-      sv zz = {{0, 0, 0, 0, 0, 0}};
-      st_sv(p.cfrc, nb, 0, zz);
+      st_bsv(F_CACC, 0, z);
     }
     WSYNC();
     for (int L = 1; L < m.nlevel; ++L) {
-      const int beg = IP(level_adr, L), end = IP(level_adr, L + 1);
-      for (int t = beg + lane; t < end; t += AMX_WAVE) {
-        const int b = IP(level_body, t), par = IP(body_parent, b);
-        sv cv = ld_sv(p.cvel, nb, par), ca = ld_sv(p.cacc, nb, par);
-        const int ja = IP(body_jntadr, b), jn = IP(body_jntnum, b);
-        for (int k = 0; k < jn; ++k) {
-          const int j = ja + k, t_ = IP(jnt_type, j), da = IP(jnt_dadr, j);
+      if (b_level == L) {
+        sv cv = ld_bsv(F_CVEL, b_parent), ca = ld_bsv(F_CACC, b_parent);
+        for (int k = 0; k < b_jntnum; ++k) {
+          const int jr = m.c_jnt + (b_jntadr + k) * JNT_S, t_ = CI(jr), da = CI(jr + 2);
           if (t_ == JFREE) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-              sv c = ld_sv(p.cdof, nv, da + i);
-              const float q = qvel[da + i];
+              const sv c = ld_dsv(D_CDOF, da + i);
+              const float q = lds[qv + da + i];
 #pragma unroll
               for (int e = 0; e < 6; ++e) cv.v[e] += c.v[e] * q;
             }
-            sv cd3 = motion_cross(cv, ld_sv(p.cdof, nv, da + 3)), cd4 = motion_cross(cv, ld_sv(p.cdof, nv, da + 4)),
-               cd5 = motion_cross(cv, ld_sv(p.cdof, nv, da + 5));
+            const sv c3 = ld_dsv(D_CDOF, da + 3), c4 = ld_dsv(D_CDOF, da + 4), c5 = ld_dsv(D_CDOF, da + 5);
+            const sv cd3 = motion_cross(cv, c3), cd4 = motion_cross(cv, c4), cd5 = motion_cross(cv, c5);
+            const float q3 = lds[qv + da + 3], q4 = lds[qv + da + 4], q5 = lds[qv + da + 5];
 #pragma unroll
             for (int e = 0; e < 6; ++e) {
-              ca.v[e] += cd3.v[e] * qvel[da + 3] + cd4.v[e] * qvel[da + 4] + cd5.v[e] * qvel[da + 5];
-            }
-#pragma unroll
-            for (int i = 3; i < 6; ++i) {
-              sv c = ld_sv(p.cdof, nv, da + i);
-              const float q = qvel[da + i];
-#pragma unroll
-              for (int e = 0; e < 6; ++e) cv.v[e] += c.v[e] * q;
+              ca.v[e] += cd3.v[e] * q3 + cd4.v[e] * q4 + cd5.v[e] * q5;
+              cv.v[e] += c3.v[e] * q3 + c4.v[e] * q4 + c5.v[e] * q5;
             }
           } else {
             const int n = t_ == JBALL ? 3 : 1;
             sv add = {{0, 0, 0, 0, 0, 0}};
             for (int i = 0; i < n; ++i) {
-              sv c = ld_sv(p.cdof, nv, da + i);
-              sv cd = motion_cross(cv, c);
-              const float q = qvel[da + i];
+              const sv c = ld_dsv(D_CDOF, da + i);
+              const sv cd = motion_cross(cv, c);
+              const float q = lds[qv + da + i];
 #pragma unroll
               for (int e = 0; e < 6; ++e) { ca.v[e] += cd.v[e] * q; add.v[e] += c.v[e] * q; }
             }
@@ -499,32 +509,28 @@ struct Env {
             for (int e = 0; e < 6; ++e) cv.v[e] += add.v[e];
           }
         }
-        st_sv(p.cvel, nb, b, cv);
-        st_sv(p.cacc, nb, b, ca);
+        st_bsv(F_CVEL, b, cv);
+        st_bsv(F_CACC, b, ca);
         float I[10];
 #pragma unroll
-        for (int k = 0; k < 10; ++k) I[k] = ci[k * nb + b];
-        sv f = inert_mul(I, ca), g = motion_cross_force(cv, inert_mul(I, cv));
+        for (int k = 0; k < 10; ++k) I[k] = body(F_CINERT + k, b);
+        sv f = inert_mul(I, ca);
+        const sv g = motion_cross_force(cv, inert_mul(I, cv));
 #pragma unroll
         for (int e = 0; e < 6; ++e) f.v[e] += g.v[e];
-        st_sv(p.cfrc, nb, b, f);
+        st_bsv(F_CFRC, b, f);
       }
       WSYNC();
     }
     for (int L = m.nlevel - 2; L >= 1; --L) {  // up-scan: gather children
-      const int beg = IP(level_adr, L), end = IP(level_adr, L + 1);
-      for (int t = beg + lane; t < end; t += AMX_WAVE) {
-        const int b = IP(level_body, t);
-        const int c0 = IP(child_adr, b), c1 = IP(child_adr, b + 1);
-        if (c1 > c0) {
-          sv f = ld_sv(p.cfrc, nb, b);
-          for (int c = c0; c < c1; ++c) {
-            sv g = ld_sv(p.cfrc, nb, IP(child_list, c));
+      if (b_level == L && b_childnum > 0) {
+        sv f = ld_bsv(F_CFRC, b);
+        for (int c = 0; c < b_childnum; ++c) {
+          const sv g = ld_bsv(F_CFRC, CI(m.c_child + b_childadr + c));
 #pragma unroll
-            for (int e = 0; e < 6; ++e) f.v[e] += g.v[e];
-          }
-          st_sv(p.cfrc, nb, b, f);
+          for (int e = 0; e < 6; ++e) f.v[e] += g.v[e];
         }
+        st_bsv(F_CFRC, b, f);
       }
       WSYNC();
     }
@@ -532,161 +538,143 @@ struct Env {
 
   // ------------------------------------------------------------------ A9.9 passive, A9.7/A9.11 actuation, A9.12 qfrc_smooth
   DEV void smooth_forces() {
-    const int nv = m.nv, nu = m.nu;
-    const float *qpos = s + p.qpos, *qvel = s + p.qvel, *ctrl = s + p.ctrl;
-    float *actf = s + p.actf;
-    const bool act_on = nu > 0 && !(m.disableflags & DIS_ACTUATION);
-    if (act_on) {
-      for (int u = lane; u < nu; u += AMX_WAVE) {
-        const int qa = IP(act_qadr, u), da = IP(act_dadr, u), fl = IP(act_flags, u);
-        const float gear = FP(act_gear, u);
-        float c = ctrl[u];
-        if (!(m.disableflags & DIS_CLAMPCTRL) && (fl & 1)) c = fminf(fmaxf(c, FP(act_ctrlrange, 2 * u)), FP(act_ctrlrange, 2 * u + 1));
-        float force = FP(act_gain, u) * c;
-        if (fl & 4) force += FP(act_bias, 3 * u) + FP(act_bias, 3 * u + 1) * (qpos[qa] * gear) + FP(act_bias, 3 * u + 2) * (qvel[da] * gear);
-        if (fl & 2) force = fminf(fmaxf(force, FP(act_forcerange, 2 * u)), FP(act_forcerange, 2 * u + 1));
-        actf[u] = gear * force;
-      }
+    const int qp = eb + m.e_qpos, qv = eb + m.e_qvel;
+    const bool act_on = m.nu > 0 && !(m.disableflags & DIS_ACTUATION);
+    if (act_on && lane < m.nu) {
+      const int ar = m.c_act + lane * ACT_S, fl = CI(ar + 2);
+      const float gear = CF(ar + 3);
+      float c = lds[eb + m.e_ctrl + lane];
+      if (!(m.disableflags & DIS_CLAMPCTRL) && (fl & 1)) c = fminf(fmaxf(c, CF(ar + 8)), CF(ar + 9));
+      float force = CF(ar + 4) * c;
+      if (fl & 4) force += CF(ar + 5) + CF(ar + 6) * (lds[qp + CI(ar)] * gear) + CF(ar + 7) * (lds[qv + CI(ar + 1)] * gear);
+      if (fl & 2) force = fminf(fmaxf(force, CF(ar + 10)), CF(ar + 11));
+      lds[eb + m.e_actf + lane] = gear * force;
     }
     WSYNC();
-    float *fs = s + p.fsmooth;
-    for (int i = lane; i < nv; i += AMX_WAVE) {
-      const int b = IP(dof_body, i), j = IP(dof_jnt, i);
-      sv c = ld_sv(p.cdof, nv, i), f = ld_sv(p.cfrc, m.nb, b);
+    if (lane < m.nv) {
+      const int i = lane, dr = m.c_dof + i * DOF_S;
+      const sv c = ld_dsv(D_CDOF, i), f = ld_bsv(F_CFRC, d_body);
       float bias = 0;
 #pragma unroll
       for (int e = 0; e < 6; ++e) bias += c.v[e] * f.v[e];
       float pas = 0;
       if (!(m.disableflags & DIS_PASSIVE)) {
-        const float k = FP(jnt_stiff, j);
-        const int kind = IP(dof_kind, i);
-        if (k != 0.0f && kind >= 2) { const int qa = IP(jnt_qadr, j); pas -= k * (qpos[qa] - FP(qpos_spring, qa)); }
-        pas -= FP(dof_damping, i) * qvel[i];
+        const int jr = m.c_jnt + d_jnt * JNT_S;
+        const float k = CF(jr + 11);
+        if (k != 0.0f && d_kind >= 2) pas -= k * (lds[qp + CI(jr + 1)] - CF(jr + 12));
+        pas -= CF(dr + 5) * lds[qv + i];
       }
       float act = 0;
-      if (act_on) for (int a = IP(dof_actadr, i); a < IP(dof_actadr, i + 1); ++a) act += actf[IP(dof_actlist, a)];
-      s[p.fbias + i] = bias;  // qfrc_bias, kept for amx_forward outputs
-      fs[i] = pas - bias + act;
+      if (act_on) {
+        const int a0 = CI(dr + 6), an = CI(dr + 7);
+        for (int a = 0; a < an; ++a) act += lds[eb + m.e_actf + CI(m.c_dofact + a0 + a)];
+      }
+      dof(D_FBIAS, i) = bias;
+      dof(D_FSMOOTH, i) = pas - bias + act;
     }
     WSYNC();
   }
 
-  // ------------------------------------------------------------------ A9.5 collision
+  // ------------------------------------------------------------------ A9.5 collision (one lane per static geom pair)
   DEV void plane_sphere(f3 n, f3 ppos, f3 spos, float r, float *dist, f3 *pos) const {
-    float d = dot(spos - ppos, n) - r;
+    const float d = dot(spos - ppos, n) - r;
     *dist = d;
     *pos = spos - n * (r + 0.5f * d);
   }
+  DEV void st_contact(int c, float d, f3 cp) const { con(0, c) = d; con(1, c) = cp.x; con(2, c) = cp.y; con(3, c) = cp.z; }
   DEV void collision() {
-    const int ngc = m.ngc;
-    float *gpos = s + p.gpos, *gmat = s + p.gmat;
-    for (int g = lane; g < ngc; g += AMX_WAVE) {
-      const int b = IP(gc_body, g);
-      f4 xq = ld_xquat(b);
-      f3 pos = ld_xpos(b) + qrot(xq, mk3(FP(gc_pos, 3 * g), FP(gc_pos, 3 * g + 1), FP(gc_pos, 3 * g + 2)));
-      f4 gq = {FP(gc_quat, 4 * g), FP(gc_quat, 4 * g + 1), FP(gc_quat, 4 * g + 2), FP(gc_quat, 4 * g + 3)};
-      m33 R = q2m(qmul(xq, gq));
-      gpos[g] = pos.x; gpos[ngc + g] = pos.y; gpos[2 * ngc + g] = pos.z;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) gmat[k * ngc + g] = R.a[k];
-    }
-    WSYNC();
-    float *cdist = s + p.cdist, *cpos = s + p.cpos, *cframe = s + p.cframe;
-    const int nc = m.ncon, np = m.npair;
-    for (int pr = lane; pr < np; pr += AMX_WAVE) {
-      const int g1 = IP(pair_g1, pr), g2 = IP(pair_g2, pr), fn = IP(pair_fn, pr), c0 = IP(pair_conadr, pr);
-      f3 pos1 = mk3(gpos[g1], gpos[ngc + g1], gpos[2 * ngc + g1]), pos2 = mk3(gpos[g2], gpos[ngc + g2], gpos[2 * ngc + g2]);
+    const int np = m.npair;
+    if (lane < np) {
+      const int pr = lane, rec = m.c_pair + pr * PAIR_S;
+      const int g1 = CI(rec), g2 = CI(rec + 1), fn = CI(rec + 2), c0 = CI(rec + 3);
+      const f3 pos1 = mk3(geo(0, g1), geo(1, g1), geo(2, g1)), pos2 = mk3(geo(0, g2), geo(1, g2), geo(2, g2));
       m33 R1, R2;
 #pragma unroll
-      for (int k = 0; k < 9; ++k) { R1.a[k] = gmat[k * ngc + g1]; R2.a[k] = gmat[k * ngc + g2]; }
-      f3 size1 = mk3(FP(gc_size, 3 * g1), FP(gc_size, 3 * g1 + 1), FP(gc_size, 3 * g1 + 2));
-      f3 size2 = mk3(FP(gc_size, 3 * g2), FP(gc_size, 3 * g2 + 1), FP(gc_size, 3 * g2 + 2));
+      for (int k = 0; k < 9; ++k) { R1.a[k] = geo(3 + k, g1); R2.a[k] = geo(3 + k, g2); }
+      const int s1 = m.c_geom + g1 * GEOM_S + 9, s2 = m.c_geom + g2 * GEOM_S + 9;
       float fr[9];
       if (fn == 0) {
-        f3 n = mk3(R1.a[2], R1.a[5], R1.a[8]), cp;
+        const f3 n = mk3(R1.a[2], R1.a[5], R1.a[8]);
+        f3 cp;
         float d;
-        plane_sphere(n, pos1, pos2, size2.x, &d, &cp);
-        cdist[c0] = d; cpos[c0] = cp.x; cpos[nc + c0] = cp.y; cpos[2 * nc + c0] = cp.z;
+        plane_sphere(n, pos1, pos2, CF(s2), &d, &cp);
+        st_contact(c0, d, cp);
         make_frame(n, fr);
       } else if (fn == 1) {
-        f3 n = mk3(R1.a[2], R1.a[5], R1.a[8]), axis = mk3(R2.a[2], R2.a[5], R2.a[8]);
+        const f3 n = mk3(R1.a[2], R1.a[5], R1.a[8]), axis = mk3(R2.a[2], R2.a[5], R2.a[8]);
         float bn;
         f3 b = normalize3(axis - n * dot(n, axis), &bn);
         if (bn < 0.5f) b = (n.y > -0.5f && n.y < 0.5f) ? mk3(0, 1, 0) : mk3(0, 0, 1);
-        f3 c = cross(n, b);
+        const f3 c = cross(n, b);
         fr[0] = n.x; fr[1] = n.y; fr[2] = n.z; fr[3] = b.x; fr[4] = b.y; fr[5] = b.z; fr[6] = c.x; fr[7] = c.y; fr[8] = c.z;
+        const float rad = CF(s2), half = CF(s2 + 1);
         for (int k = 0; k < 2; ++k) {
           f3 cp;
           float d;
-          plane_sphere(n, pos1, pos2 + axis * (k == 0 ? size2.y : -size2.y), size2.x, &d, &cp);
-          cdist[c0 + k] = d; cpos[c0 + k] = cp.x; cpos[nc + c0 + k] = cp.y; cpos[2 * nc + c0 + k] = cp.z;
+          plane_sphere(n, pos1, pos2 + axis * (k == 0 ? half : -half), rad, &d, &cp);
+          st_contact(c0 + k, d, cp);
         }
       } else if (fn == 2) {
-        const int nvt = IP(pair_vertnum, pr), va = IP(pair_vertadr, pr);
-        f3 nw = mk3(R1.a[2], R1.a[5], R1.a[8]);
-        f3 pl = mulTv(R2, pos1 - pos2), n = mulTv(R2, nw);
+        const int nvt = CI(rec + 6), va = m.c_vert + 3 * CI(rec + 5);
+        const f3 nw = mk3(R1.a[2], R1.a[5], R1.a[8]);
+        const f3 pl = mulTv(R2, pos1 - pos2), n = mulTv(R2, nw);
         float smax = -1e30f;
-        for (int v = 0; v < nvt; ++v) {
-          f3 vt = mk3(FP(convex_vert, 3 * (va + v)), FP(convex_vert, 3 * (va + v) + 1), FP(convex_vert, 3 * (va + v) + 2));
-          smax = fmaxf(smax, dot(pl - vt, n));
-        }
+#define VERT(v) mk3(CF(va + 3 * (v)), CF(va + 3 * (v) + 1), CF(va + 3 * (v) + 2))
+        for (int v = 0; v < nvt; ++v) smax = fmaxf(smax, dot(pl - VERT(v), n));
         const float thr = fmaxf(0.0f, smax - 1e-3f);
         int idx[4];
         float best;
-#define VERT(v) mk3(FP(convex_vert, 3 * (va + (v))), FP(convex_vert, 3 * (va + (v)) + 1), FP(convex_vert, 3 * (va + (v)) + 2))
 #define MASKV(vt) (dot(pl - (vt), n) > thr ? 0.0f : -1e6f)
         idx[0] = 0; best = -1e30f;
-        for (int v = 0; v < nvt; ++v) { float sc = MASKV(VERT(v)); if (sc > best) { best = sc; idx[0] = v; } }
-        f3 a = VERT(idx[0]);
+        for (int v = 0; v < nvt; ++v) { const float sc = MASKV(VERT(v)); if (sc > best) { best = sc; idx[0] = v; } }
+        const f3 a = VERT(idx[0]);
         idx[1] = 0; best = -1e30f;
-        for (int v = 0; v < nvt; ++v) { f3 vt = VERT(v); f3 d = a - vt; float sc = dot(d, d) + MASKV(vt); if (sc > best) { best = sc; idx[1] = v; } }
-        f3 bb = VERT(idx[1]);
-        f3 ab = cross(n, a - bb);
+        for (int v = 0; v < nvt; ++v) { const f3 vt = VERT(v); const f3 d = a - vt; const float sc = dot(d, d) + MASKV(vt); if (sc > best) { best = sc; idx[1] = v; } }
+        const f3 bb = VERT(idx[1]);
+        const f3 ab = cross(n, a - bb);
         idx[2] = 0; best = -1e30f;
-        for (int v = 0; v < nvt; ++v) { f3 vt = VERT(v); float sc = fabsf(dot(a - vt, ab)) + MASKV(vt); if (sc > best) { best = sc; idx[2] = v; } }
-        f3 cc = VERT(idx[2]);
-        f3 ac = cross(n, a - cc), bc = cross(n, bb - cc);
+        for (int v = 0; v < nvt; ++v) { const f3 vt = VERT(v); const float sc = fabsf(dot(a - vt, ab)) + MASKV(vt); if (sc > best) { best = sc; idx[2] = v; } }
+        const f3 cc = VERT(idx[2]);
+        const f3 ac = cross(n, a - cc), bc = cross(n, bb - cc);
         idx[3] = 0; best = -1e30f;
-        for (int v = 0; v < nvt; ++v) { f3 vt = VERT(v); float sc = fabsf(dot(bb - vt, bc)) + MASKV(vt); if (sc > best) { best = sc; idx[3] = v; } }
-        for (int v = 0; v < nvt; ++v) { f3 vt = VERT(v); float sc = fabsf(dot(a - vt, ac)) + MASKV(vt); if (sc > best) { best = sc; idx[3] = v; } }
+        for (int v = 0; v < nvt; ++v) { const f3 vt = VERT(v); const float sc = fabsf(dot(bb - vt, bc)) + MASKV(vt); if (sc > best) { best = sc; idx[3] = v; } }
+        for (int v = 0; v < nvt; ++v) { const f3 vt = VERT(v); const float sc = fabsf(dot(a - vt, ac)) + MASKV(vt); if (sc > best) { best = sc; idx[3] = v; } }
         make_frame(nw, fr);
         for (int k = 0; k < 4; ++k) {
           bool unique = true;
           for (int j = 0; j < k; ++j) unique = unique && (idx[j] != idx[k]);
-          f3 vt = VERT(idx[k]);
-          float d = unique ? -dot(pl - vt, n) : 1.0f;
-          f3 cp = pos2 + mulv(R2, vt) - nw * (0.5f * d);
-          cdist[c0 + k] = d; cpos[c0 + k] = cp.x; cpos[nc + c0 + k] = cp.y; cpos[2 * nc + c0 + k] = cp.z;
+          const f3 vt = VERT(idx[k]);
+          const float d = unique ? -dot(pl - vt, n) : 1.0f;
+          st_contact(c0 + k, d, pos2 + mulv(R2, vt) - nw * (0.5f * d));
         }
 #undef VERT
 #undef MASKV
       } else {
         f3 p1 = pos1, p2 = pos2;
-        const float r1 = size1.x, r2 = size2.x;
+        const float r1 = CF(s1), r2 = CF(s2);
         if (fn == 4) {
-          f3 ax = mk3(R2.a[2], R2.a[5], R2.a[8]);
-          float t = fminf(fmaxf(dot(pos1 - pos2, ax), -size2.y), size2.y);
-          p2 = pos2 + ax * t;
+          const f3 ax = mk3(R2.a[2], R2.a[5], R2.a[8]);
+          const float h2 = CF(s2 + 1);
+          p2 = pos2 + ax * fminf(fmaxf(dot(pos1 - pos2, ax), -h2), h2);
         } else if (fn == 5) {
-          f3 a1 = mk3(R1.a[2], R1.a[5], R1.a[8]), a2 = mk3(R2.a[2], R2.a[5], R2.a[8]);
-          const float h1 = size1.y, h2 = size2.y;
-          f3 dv = pos1 - pos2;
-          float a12 = dot(a1, a2), d1 = dot(dv, a1), d2 = dot(dv, a2), det = 1 - a12 * a12, t1, t2;
-          t1 = fabsf(det) < 1e-6f ? 0.0f : fminf(fmaxf((a12 * d2 - d1) / det, -h1), h1);
-          t2 = fminf(fmaxf(d2 + t1 * a12, -h2), h2);
+          const f3 a1 = mk3(R1.a[2], R1.a[5], R1.a[8]), a2 = mk3(R2.a[2], R2.a[5], R2.a[8]);
+          const float h1 = CF(s1 + 1), h2 = CF(s2 + 1);
+          const f3 dv = pos1 - pos2;
+          const float a12 = dot(a1, a2), d1 = dot(dv, a1), d2 = dot(dv, a2), det = 1 - a12 * a12;
+          float t1 = fabsf(det) < 1e-6f ? 0.0f : fminf(fmaxf((a12 * d2 - d1) / det, -h1), h1);
+          const float t2 = fminf(fmaxf(d2 + t1 * a12, -h2), h2);
           t1 = fminf(fmaxf(t2 * a12 - d1, -h1), h1);
           p1 = pos1 + a1 * t1; p2 = pos2 + a2 * t2;
         }
         float len;
         f3 n = normalize3(p2 - p1, &len);
         if (len == 0) n = mk3(1, 0, 0);
-        float d = len - (r1 + r2);
-        f3 cp = p1 + n * (r1 + 0.5f * d);
-        cdist[c0] = d; cpos[c0] = cp.x; cpos[nc + c0] = cp.y; cpos[2 * nc + c0] = cp.z;
+        const float d = len - (r1 + r2);
+        st_contact(c0, d, p1 + n * (r1 + 0.5f * d));
         make_frame(n, fr);
       }
 #pragma unroll
-      for (int k = 0; k < 9; ++k) cframe[k * np + pr] = fr[k];
+      for (int k = 0; k < 9; ++k) lds[eb + m.e_frame + pr * 9 + k] = fr[k];
     }
     WSYNC();
   }
@@ -695,264 +683,214 @@ struct Env {
   // Row table (static): [0,neq) joint equalities, [neq,neq+nlim) joint limits, then 4 pyramid rows per
   // contact slot.  A row that is inactive this step gets D = 0 (the reference zeroes it instead).
   DEV void make_constraint() {
-    const int nv = m.nv, ldj = m.ldj, nc = m.ncon, np = m.npair;
-    const float *qpos = s + p.qpos, *qvel = s + p.qvel;
-    float *J = s + p.J, *D = s + p.D, *aref = s + p.aref;
+    const int ldj = m.ldj, np = m.npair, Jo = eb + m.e_J;
+    const int qp = eb + m.e_qpos, qv = eb + m.e_qvel;
     const bool con_on = !(m.disableflags & DIS_CONSTRAINT);
-    // contact Jacobian entries: one lane per (contact, pair-dof)
+    const int row0 = m.neq + m.nlim;
     if (con_on && !(m.disableflags & DIS_CONTACT)) {
-      const float *cd = s + p.cdof, *cpos = s + p.cpos, *cframe = s + p.cframe;
-      const int row0 = m.neq + m.nlim;
-      const int total = IP(pair_dofadr, np) > 0 ? nc : 0;
-      // flatten (contact c, slot t) with a per-contact loop over its pair's dof list
-      for (int c = 0; c < total; ++c) {
-        const int pr = IP(con_pair, c);
-        const int d0 = IP(pair_dofadr, pr), d1 = IP(pair_dofadr, pr + 1);
-        const float mu = FP(pair_mu, pr);
-        f3 pt = mk3(cpos[c], cpos[nc + c], cpos[2 * nc + c]);
-        f3 off2 = pt - ld_com(IP(pair_root2, pr)), off1 = pt - ld_com(IP(pair_root1, pr));
-        f3 fn_ = mk3(cframe[pr], cframe[np + pr], cframe[2 * np + pr]);
-        f3 ft1 = mk3(cframe[3 * np + pr], cframe[4 * np + pr], cframe[5 * np + pr]);
-        f3 ft2 = mk3(cframe[6 * np + pr], cframe[7 * np + pr], cframe[8 * np + pr]);
-        for (int t = d0 + lane; t < d1; t += AMX_WAVE) {
-          const int i = IP(pair_doflist, t), sg = IP(pair_dofsign, t);
-          f3 w = mk3(cd[i], cd[nv + i], cd[2 * nv + i]), l = mk3(cd[3 * nv + i], cd[4 * nv + i], cd[5 * nv + i]);
-          f3 jp = mk3(0, 0, 0);
-          if (sg & 1) jp = jp + (l + cross(w, off2));
-          if (sg & 2) jp = jp - (l + cross(w, off1));
-          const float jn = dot(fn_, jp), j1 = dot(ft1, jp), j2 = dot(ft2, jp);
-          const int r = row0 + 4 * c;
-          J[(r + 0) * ldj + i] = jn + mu * j1;
-          J[(r + 1) * ldj + i] = jn - mu * j1;
-          J[(r + 2) * ldj + i] = jn + mu * j2;
-          J[(r + 3) * ldj + i] = jn - mu * j2;
-        }
+      // contact Jacobian entries: one lane per (contact, dof of the pair's ancestor chains)
+      for (int t = lane; t < m.njac; t += AMX_WAVE) {
+        const int pk = CI(m.c_jac + t), c = pk & 255, pd = CI(m.c_pairdof + (pk >> 8)), i = pd & 255, sg = pd >> 8;
+        const int pr = CI(m.c_conpair + c), rec = m.c_pair + pr * PAIR_S;
+        const float mu = CF(rec + 11);
+        const f3 pt = mk3(con(1, c), con(2, c), con(3, c));
+        const int fo = eb + m.e_frame + pr * 9;
+        const f3 fn_ = mk3(lds[fo], lds[fo + 1], lds[fo + 2]), ft1 = mk3(lds[fo + 3], lds[fo + 4], lds[fo + 5]),
+                 ft2 = mk3(lds[fo + 6], lds[fo + 7], lds[fo + 8]);
+        const f3 w = mk3(dof(0, i), dof(1, i), dof(2, i)), l = mk3(dof(3, i), dof(4, i), dof(5, i));
+        f3 jp = mk3(0, 0, 0);
+        if (sg & 1) jp = jp + (l + cross(w, pt - ld_com(CI(rec + 8))));
+        if (sg & 2) jp = jp - (l + cross(w, pt - ld_com(CI(rec + 7))));
+        const float jn = dot(fn_, jp), j1 = dot(ft1, jp), j2 = dot(ft2, jp);
+        const int r = Jo + (row0 + 4 * c) * ldj + i;
+        lds[r] = jn + mu * j1;
+        lds[r + ldj] = jn - mu * j1;
+        lds[r + 2 * ldj] = jn + mu * j2;
+        lds[r + 3 * ldj] = jn - mu * j2;
       }
     }
     WSYNC();
-    for (int r = lane; r < m.nefc; r += AMX_WAVE) {
-      float pos = 0, invw = 0, sr0 = 0.02f, sr1 = 1.0f, si[5] = {0.9f, 0.95f, 0.001f, 0.5f, 2.0f}, jv = 0;
+    float dd = 0, ar = 0;
+    if (con_on && lane < m.nefc) {
+      const int r = lane;
+      float pos = 0, invw = 0, jv = 0;
       bool active = false;
-      if (!con_on) {
-      } else if (r < m.neq) {
-        const int e = r;
+      int rec = 0;  // points at the {k,b,dmin,...} block of the row's record
+      if (r < m.neq) {
         if (!(m.disableflags & DIS_EQUALITY)) {
           active = true;
-          const int q1 = IP(eq_q1, e), d1 = IP(eq_d1, e), q2 = IP(eq_q2, e), d2 = IP(eq_d2, e);
-          const float *c = m.fp + m.eq_data + 5 * e;
-          float pos1 = qpos[q1] - FP(qpos0, q1);
-          invw = FP(eq_invw1, e);
-          J[r * ldj + d1] = 1.0f;
-          jv = qvel[d1];
+          const int er = m.c_eq + r * EQ_S, q1 = CI(er), d1 = CI(er + 1), q2 = CI(er + 2), d2 = CI(er + 3);
+          const float pos1 = lds[qp + q1] - CF(er + 19);
+          invw = CF(er + 18);
+          lds[Jo + r * ldj + d1] = 1.0f;
+          jv = lds[qv + d1];
           if (q2 >= 0) {
-            const float dif = qpos[q2] - FP(qpos0, q2);
+            const float dif = lds[qp + q2] - CF(er + 20);
+            const float c0 = CF(er + 4), c1 = CF(er + 5), c2 = CF(er + 6), c3 = CF(er + 7), c4 = CF(er + 8);
             const float dp2 = dif * dif, dp3 = dp2 * dif, dp4 = dp3 * dif;
-            const float deriv = c[1] + c[2] * dif * 2 + c[3] * dp2 * 3 + c[4] * dp3 * 4;
-            pos = pos1 - (c[0] + c[1] * dif + c[2] * dp2 + c[3] * dp3 + c[4] * dp4);
-            J[r * ldj + d2] = -deriv;
-            jv += -deriv * qvel[d2];
-            invw += FP(eq_invw2, e);
+            const float deriv = c1 + c2 * dif * 2 + c3 * dp2 * 3 + c4 * dp3 * 4;
+            pos = pos1 - (c0 + c1 * dif + c2 * dp2 + c3 * dp3 + c4 * dp4);
+            lds[Jo + r * ldj + d2] = -deriv;
+            jv += -deriv * lds[qv + d2];
           } else {
-            pos = pos1 - c[0];
+            pos = pos1 - CF(er + 4);
           }
-          sr0 = FP(eq_solref, 2 * e); sr1 = FP(eq_solref, 2 * e + 1);
-#pragma unroll
-          for (int k = 0; k < 5; ++k) si[k] = FP(eq_solimp, 5 * e + k);
+          rec = er + 9;
         }
-      } else if (r < m.neq + m.nlim) {
-        const int l = r - m.neq;
+      } else if (r < row0) {
         if (!(m.disableflags & DIS_LIMIT)) {
-          const int qa = IP(lim_qadr, l), da = IP(lim_dadr, l);
-          const float q = qpos[qa];
-          const float dmin = q - FP(lim_range, 2 * l), dmax = FP(lim_range, 2 * l + 1) - q;
-          pos = fminf(dmin, dmax) - FP(lim_margin, l);
+          const int lr = m.c_lim + (r - m.neq) * LIM_S, da = CI(lr + 1);
+          const float q = lds[qp + CI(lr)];
+          const float dmin = q - CF(lr + 2), dmax = CF(lr + 3) - q;
+          pos = fminf(dmin, dmax) - CF(lr + 4);
           active = pos < 0;
           const float sgn = dmin < dmax ? 1.0f : -1.0f;
-          J[r * ldj + da] = sgn;
-          jv = sgn * qvel[da];
-          invw = FP(lim_invw, l);
-          sr0 = FP(lim_solref, 2 * l); sr1 = FP(lim_solref, 2 * l + 1);
-#pragma unroll
-          for (int k = 0; k < 5; ++k) si[k] = FP(lim_solimp, 5 * l + k);
+          lds[Jo + r * ldj + da] = sgn;
+          jv = sgn * lds[qv + da];
+          invw = CF(lr + 14);
+          rec = lr + 5;
         }
-      } else {
-        const int cr = r - m.neq - m.nlim, c = cr >> 2, k = cr & 3;
-        if (!(m.disableflags & DIS_CONTACT)) {
-          const int pr = IP(con_pair, c);
-          const float margin = FP(pair_margin, pr), dist = s[p.cdist + c];
-          active = dist < margin;
-          pos = dist - margin;
-          const float mu = FP(pair_mu, pr), tw = FP(pair_invw, pr);
-          const float f = (k & 1) ? -mu : mu;
-          invw = (tw + f * f * tw) * 2 * f * f / m.impratio;
-          for (int t = IP(pair_dofadr, pr); t < IP(pair_dofadr, pr + 1); ++t) {
-            const int i = IP(pair_doflist, t);
-            jv += J[r * ldj + i] * qvel[i];
-          }
-          sr0 = FP(pair_solref, 2 * pr); sr1 = FP(pair_solref, 2 * pr + 1);
-#pragma unroll
-          for (int kk = 0; kk < 5; ++kk) si[kk] = FP(pair_solimp, 5 * pr + kk);
+      } else if (!(m.disableflags & DIS_CONTACT)) {
+        const int cr = r - row0, c = cr >> 2, k = cr & 3;
+        const int pr = CI(m.c_conpair + c), prec = m.c_pair + pr * PAIR_S;
+        const float margin = CF(prec + 21), dist = con(0, c);
+        active = dist < margin;
+        pos = dist - margin;
+        const float mu = CF(prec + 11), tw = CF(prec + 22);
+        const float f = (k & 1) ? -mu : mu;
+        invw = (tw + f * f * tw) * 2 * f * f / m.impratio;
+        const int d0 = CI(prec + 9), dn = CI(prec + 10);
+        for (int t = 0; t < dn; ++t) {
+          const int i = CI(m.c_pairdof + d0 + t) & 255;
+          jv += lds[Jo + r * ldj + i] * lds[qv + i];
         }
+        rec = prec + 12;
       }
-      float dd = 0, ar = 0;
       if (active) {
-        float k_, b_, imp;
-        kbi(m, sr0, sr1, si, pos, &k_, &b_, &imp);
+        const float imp = row_impedance(rec, pos);
         const float rr = fmaxf(invw * (1 - imp) / imp, MINVAL);
         dd = 1.0f / rr;
-        ar = -b_ * jv - k_ * imp * pos;
+        ar = -CF(rec + 1) * jv - CF(rec) * imp * pos;
       }
-      D[r] = dd;
-      aref[r] = ar;
     }
-    WSYNC();
+    rD = dd;
+    rAref = ar;
   }
 
   // ------------------------------------------------------------------ A9.13 solver
-  DEV void mul_M(const float *v, float *out) {  // out = M v (dense row per lane)
-    const int nv = m.nv, ldm = m.ldm;
-    const float *M = s + p.M;
-    for (int i = lane; i < nv; i += AMX_WAVE) {
-      float acc = 0;
-      for (int j = 0; j < nv; ++j) acc += M[i * ldm + j] * v[j];
-      out[i] = acc;
-    }
+  DEV float mul_M_row(int vf) const {  // (M v)[lane], v = dof field vf
+    const int nv = m.nv, Mo = eb + m.e_M + (lane < nv ? lane : 0) * m.ldm, vo = dofoff(vf);
+    float acc = 0;
+    for (int j = 0; j < nv; ++j) acc += lds[Mo + j] * lds[vo + j * DOF_E];
+    return acc;
   }
-  DEV float row_dot(int r, const float *v) const {  // J[r,:] . v over the row's static support
-    const float *J = s + p.J;
-    const int ldj = m.ldj;
+  DEV float row_dot(int vf) const {  // J[lane,:] . v over the row's static support
+    const int r = lane, ldj = m.ldj, Jo = eb + m.e_J + r * ldj, vo = dofoff(vf);
+    if (r >= m.nefc) return 0.0f;
     if (r < m.neq) {
-      const int d1 = IP(eq_d1, r), d2 = IP(eq_d2, r);
-      float a = J[r * ldj + d1] * v[d1];
-      if (d2 >= 0) a += J[r * ldj + d2] * v[d2];
+      const int er = m.c_eq + r * EQ_S, d1 = CI(er + 1), d2 = CI(er + 3);
+      float a = lds[Jo + d1] * lds[vo + d1 * DOF_E];
+      if (d2 >= 0) a += lds[Jo + d2] * lds[vo + d2 * DOF_E];
       return a;
     } else if (r < m.neq + m.nlim) {
-      const int da = IP(lim_dadr, r - m.neq);
-      return J[r * ldj + da] * v[da];
+      const int da = CI(m.c_lim + (r - m.neq) * LIM_S + 1);
+      return lds[Jo + da] * lds[vo + da * DOF_E];
     }
-    const int pr = IP(con_pair, (r - m.neq - m.nlim) >> 2);
+    const int prec = m.c_pair + CI(m.c_conpair + ((r - m.neq - m.nlim) >> 2)) * PAIR_S;
+    const int d0 = CI(prec + 9), dn = CI(prec + 10);
     float a = 0;
-    for (int t = IP(pair_dofadr, pr); t < IP(pair_dofadr, pr + 1); ++t) {
-      const int i = IP(pair_doflist, t);
-      a += J[r * ldj + i] * v[i];
+    for (int t = 0; t < dn; ++t) {
+      const int i = CI(m.c_pairdof + d0 + t) & 255;
+      a += lds[Jo + i] * lds[vo + i * DOF_E];
     }
     return a;
   }
-  // Jaref = J qacc - aref, Ma = M qacc, then cost / forces (update_constraint).  Returns cost; gauss via pointer.
-  DEV void init_context(const float *qacc) {
-    mul_M(qacc, s + p.Ma);
-    const float *aref = s + p.aref;
-    float *Jaref = s + p.Jaref;
-    for (int r = lane; r < m.nefc; r += AMX_WAVE) Jaref[r] = row_dot(r, qacc) - aref[r];
+  // Ma = M v, Jaref = J v - aref  (v = dof field vf)
+  DEV void init_context(int vf) {
+    const float ma = mul_M_row(vf);
+    if (lane < m.nv) dof(D_MA, lane) = ma;
+    rJaref = row_dot(vf) - rAref;
     WSYNC();
   }
-  DEV float constraint_cost(const float *qacc, float *gauss_out) {
-    const float *D = s + p.D, *Jaref = s + p.Jaref, *Ma = s + p.Ma, *fs = s + p.fsmooth, *as = s + p.asmooth;
-    float c = 0, g = 0;
-    for (int r = lane; r < m.nefc; r += AMX_WAVE) {
-      const float ja = Jaref[r];
-      const bool act = ja < 0 || r < m.neq;
-      if (act) c += 0.5f * D[r] * ja * ja;
-    }
-    for (int i = lane; i < m.nv; i += AMX_WAVE) g += (Ma[i] - fs[i]) * (qacc[i] - as[i]);
+  DEV float constraint_cost(int vf, float *gauss_out) const {
+    const bool act = lane < m.nefc && (rJaref < 0 || lane < m.neq);
+    float c = act ? 0.5f * rD * rJaref * rJaref : 0.0f;
+    float g = lane < m.nv ? (dof(D_MA, lane) - dof(D_FSMOOTH, lane)) * (dof(vf, lane) - dof(D_ASMOOTH, lane)) : 0.0f;
     c = wave_sum(c);
     g = 0.5f * wave_sum(g);
     *gauss_out = g;
     return c + g;
   }
-  // qfrc_constraint = J' f with f = -D*Jaref on active rows, then grad = Ma - qfrc_smooth - qfrc_constraint
+  // qfrc_constraint = J' f with f = -D*Jaref on active rows, grad = Ma - qfrc_smooth - qfrc_constraint;
+  // also publishes D*active per row for the Hessian assembly.
   DEV void constraint_force_and_grad() {
-    const int nv = m.nv, ldj = m.ldj;
-    const float *D = s + p.D, *Jaref = s + p.Jaref, *J = s + p.J;
-    float *fcon = s + p.fcon, *grad = s + p.grad, *frow = s + p.jv;  // jv doubles as efc_force scratch here
-    for (int r = lane; r < m.nefc; r += AMX_WAVE) {
-      const float ja = Jaref[r];
-      frow[r] = (ja < 0 || r < m.neq) ? -D[r] * ja : 0.0f;
-    }
+    const int ldj = m.ldj, Jo = eb + m.e_J;
+    const bool act = lane < m.nefc && (rJaref < 0 || lane < m.neq) && rD > 0;
+    const float f = act ? -rD * rJaref : 0.0f;
+    if (lane < m.nefc) { row(0, lane) = act ? rD : 0.0f; row(1, lane) = f; }
+    unsigned long long mask = __ballot(act);
     WSYNC();
-    for (int i = lane; i < nv; i += AMX_WAVE) {
-      float acc = 0;
-      for (int r = 0; r < m.nefc; ++r) acc += J[r * ldj + i] * frow[r];
-      fcon[i] = acc;
-      grad[i] = s[p.Ma + i] - s[p.fsmooth + i] - acc;
+    float acc = 0;
+    const int col = Jo + (lane < m.nv ? lane : 0);
+    while (mask) {
+      const int r = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      acc += lds[col + r * ldj] * row(1, r);
+    }
+    if (lane < m.nv) {
+      dof(D_FCON, lane) = acc;
+      dof(D_GRAD, lane) = dof(D_MA, lane) - dof(D_FSMOOTH, lane) - acc;
     }
     WSYNC();
   }
   DEV void newton_direction() {  // Mgrad = (M + J' D_active J)^-1 grad
-    const int nv = m.nv, ldm = m.ldm, ldj = m.ldj, np = m.npair;
-    const float *M = s + p.M, *D = s + p.D, *Jaref = s + p.Jaref, *J = s + p.J;
-    float *H = s + p.H;
-    for (int e = lane; e < nv * ldm; e += AMX_WAVE) H[e] = M[e];
+    const int nv = m.nv, ldm = m.ldm, ldj = m.ldj, Mo = eb + m.e_M, Ho = eb + m.e_H, Jo = eb + m.e_J;
+    for (int e = lane; e < nv * ldm; e += AMX_WAVE) lds[Ho + e] = lds[Mo + e];
     WSYNC();
-    // equality + limit rows: a handful of entries each
-    for (int r = lane; r < m.neq + m.nlim; r += AMX_WAVE) {
-      const float ja = Jaref[r];
-      const float d = (ja < 0 || r < m.neq) ? D[r] : 0.0f;
+    const int row0 = m.neq + m.nlim;
+    if (lane < row0) {  // equality + limit rows: a handful of entries each
+      const int r = lane;
+      const float d = row(0, r);
       if (d != 0.0f) {
         if (r < m.neq) {
-          const int d1 = IP(eq_d1, r), d2 = IP(eq_d2, r);
-          const float j1 = J[r * ldj + d1];
-          atomicAdd(&H[d1 * ldm + d1], d * j1 * j1);
+          const int er = m.c_eq + r * EQ_S, d1 = CI(er + 1), d2 = CI(er + 3);
+          const float j1 = lds[Jo + r * ldj + d1];
+          atomicAdd(&lds[Ho + d1 * ldm + d1], d * j1 * j1);
           if (d2 >= 0) {
-            const float j2 = J[r * ldj + d2];
-            atomicAdd(&H[d2 * ldm + d2], d * j2 * j2);
-            atomicAdd(&H[d1 * ldm + d2], d * j1 * j2);
-            atomicAdd(&H[d2 * ldm + d1], d * j1 * j2);
+            const float j2 = lds[Jo + r * ldj + d2];
+            atomicAdd(&lds[Ho + d2 * ldm + d2], d * j2 * j2);
+            atomicAdd(&lds[Ho + d1 * ldm + d2], d * j1 * j2);
+            atomicAdd(&lds[Ho + d2 * ldm + d1], d * j1 * j2);
           }
         } else {
-          const int da = IP(lim_dadr, r - m.neq);
-          atomicAdd(&H[da * ldm + da], d);  // J = +-1
+          const int da = CI(m.c_lim + (r - m.neq) * LIM_S + 1);
+          atomicAdd(&lds[Ho + da * ldm + da], d);  // J = +-1
         }
       }
     }
-    // contact rows: per pair, outer products over the pair's dof list
-    const int row0 = m.neq + m.nlim;
-    for (int pr = 0; pr < np; ++pr) {
-      const int d0 = IP(pair_dofadr, pr), nd = IP(pair_dofadr, pr + 1) - d0;
-      const int c0 = IP(pair_conadr, pr), c1 = pr + 1 < np ? IP(pair_conadr, pr + 1) : m.ncon;
-      const int r0 = row0 + 4 * c0, r1 = row0 + 4 * c1;
-      // skip pairs with no active row (uniform)
-      float any = 0;
-      for (int r = r0 + lane; r < r1; r += AMX_WAVE) any += (Jaref[r] < 0 && D[r] > 0) ? 1.0f : 0.0f;
-      if (wave_sum(any) == 0.0f) continue;
-      for (int e = lane; e < nd * nd; e += AMX_WAVE) {
-        const int a = e / nd, b = e - a * nd;
-        if (b > a) continue;
-        const int i = IP(pair_doflist, d0 + a), j = IP(pair_doflist, d0 + b);
-        float acc = 0;
-        for (int r = r0; r < r1; ++r) {
-          const float ja = Jaref[r];
-          if (ja < 0) acc += D[r] * J[r * ldj + i] * J[r * ldj + j];
-        }
-        atomicAdd(&H[i * ldm + j], acc);
-        if (i != j) atomicAdd(&H[j * ldm + i], acc);
+    // contact rows: one lane per (pair, lower-triangle entry of the pair's dof block)
+    for (int t = lane; t < m.nhent; t += AMX_WAVE) {
+      const int pk = CI(m.c_hent + t), i = pk & 255, j = (pk >> 8) & 255, pr = pk >> 16;
+      const int prec = m.c_pair + pr * PAIR_S, r0 = row0 + 4 * CI(prec + 3), nr = 4 * CI(prec + 4);
+      float acc = 0;
+      for (int k = 0; k < nr; ++k) {
+        const float d = row(0, r0 + k);
+        if (d != 0.0f) acc += d * lds[Jo + (r0 + k) * ldj + i] * lds[Jo + (r0 + k) * ldj + j];
+      }
+      if (acc != 0.0f) {
+        atomicAdd(&lds[Ho + i * ldm + j], acc);
+        if (i != j) atomicAdd(&lds[Ho + j * ldm + i], acc);
       }
     }
     WSYNC();
     PROF(14);
-    chol_solve(m.nchol, H, ldm, nv, s + p.Lb, s + p.grad, s + p.Mgrad, true, lane);
+    chol_solve(m.nchol, Ho, ldm, nv, Ho, dofoff(D_GRAD), dofoff(D_MGRAD), true, lane);
   }
 
-  DEV LSPoint ls_point(float alpha, float ja, float jv, float d, bool iseq, bool valid, float g0, float g1, float g2) const {
-    const float x = ja + alpha * jv;
+  DEV LSPoint ls_point(float alpha, bool valid, bool iseq, float g0, float g1, float g2) const {
+    const float x = rJaref + alpha * rJv;
     const bool act = valid && (x < 0 || iseq);
-    float q0 = act ? 0.5f * ja * ja * d : 0.0f, q1 = act ? jv * ja * d : 0.0f, q2 = act ? 0.5f * jv * jv * d : 0.0f;
-    q0 = wave_sum(q0) + g0; q1 = wave_sum(q1) + g1; q2 = wave_sum(q2) + g2;
-    LSPoint r;
-    r.alpha = alpha;
-    r.cost = alpha * alpha * q2 + alpha * q1 + q0;
-    r.d0 = 2 * alpha * q2 + q1;
-    r.d1 = 2 * q2 + (q2 == 0.0f ? MINVAL : 0.0f);
-    return r;
-  }
-  // generic (nefc > 64) variant: rows strided over lanes, values re-read from LDS
-  DEV LSPoint ls_point_lds(float alpha, float g0, float g1, float g2) const {
-    const float *D = s + p.D, *Jaref = s + p.Jaref, *jvv = s + p.jv;
-    float q0 = 0, q1 = 0, q2 = 0;
-    for (int r = lane; r < m.nefc; r += AMX_WAVE) {
-      const float ja = Jaref[r], jv = jvv[r], d = D[r];
-      if (ja + alpha * jv < 0 || r < m.neq) { q0 += 0.5f * ja * ja * d; q1 += jv * ja * d; q2 += 0.5f * jv * jv * d; }
-    }
+    float q0 = act ? 0.5f * rJaref * rJaref * rD : 0.0f, q1 = act ? rJv * rJaref * rD : 0.0f, q2 = act ? 0.5f * rJv * rJv * rD : 0.0f;
     q0 = wave_sum(q0) + g0; q1 = wave_sum(q1) + g1; q2 = wave_sum(q2) + g2;
     LSPoint r;
     r.alpha = alpha;
@@ -963,27 +901,20 @@ struct Env {
   }
 
   DEV void linesearch(float gauss) {
-    const int nv = m.nv, nefc = m.nefc;
-    float *search = s + p.search, *mv = s + p.mv, *jvv = s + p.jv, *Jaref = s + p.Jaref, *qacc = s + p.qacc, *Ma = s + p.Ma;
-    const float *fs = s + p.fsmooth, *D = s + p.D;
-    mul_M(search, mv);
-    for (int r = lane; r < nefc; r += AMX_WAVE) jvv[r] = row_dot(r, search);
-    WSYNC();
+    const int nv = m.nv;
+    const float mv = mul_M_row(D_SEARCH);
+    rJv = row_dot(D_SEARCH);
     float sn = 0, g1 = 0, g2 = 0;
-    for (int i = lane; i < nv; i += AMX_WAVE) {
-      const float si = search[i];
-      sn += si * si;
-      g1 += si * Ma[i] - si * fs[i];
-      g2 += 0.5f * si * mv[i];
+    if (lane < nv) {
+      const float si = dof(D_SEARCH, lane);
+      sn = si * si;
+      g1 = si * dof(D_MA, lane) - si * dof(D_FSMOOTH, lane);
+      g2 = 0.5f * si * mv;
     }
     sn = wave_sum(sn); g1 = wave_sum(g1); g2 = wave_sum(g2);
     const float gtol = m.tolerance * m.ls_tolerance * sqrtf(sn) * m.scale;
-    const bool small = nefc <= AMX_WAVE;
-    const bool valid = lane < nefc;
-    const float ja = (small && valid) ? Jaref[lane] : 0.0f, jv = (small && valid) ? jvv[lane] : 0.0f,
-                d = (small && valid) ? D[lane] : 0.0f;
-    const bool iseq = lane < m.neq;
-#define POINT(al) (small ? ls_point((al), ja, jv, d, iseq, valid, gauss, g1, g2) : ls_point_lds((al), gauss, g1, g2))
+    const bool valid = lane < m.nefc, iseq = lane < m.neq;
+#define POINT(al) ls_point((al), valid, iseq, gauss, g1, g2)
     const LSPoint p0 = POINT(0.0f);
     LSPoint lo = POINT(p0.alpha - p0.d0 / p0.d1), hi;
     if (lo.d0 < p0.d0) { hi = p0; } else { hi = lo; lo = p0; }
@@ -1013,44 +944,44 @@ struct Env {
     const bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
     const float alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
     if (improved) {
-      for (int i = lane; i < nv; i += AMX_WAVE) { qacc[i] += alpha * search[i]; Ma[i] += alpha * mv[i]; }
-      for (int r = lane; r < nefc; r += AMX_WAVE) Jaref[r] += alpha * jvv[r];
+      if (lane < nv) { dof(D_QACC, lane) += alpha * dof(D_SEARCH, lane); dof(D_MA, lane) += alpha * mv; }
+      rJaref += alpha * rJv;
     }
     WSYNC();
   }
 
-  DEV void solve(int *niter_out) {
+  DEV void solve() {
     const int nv = m.nv;
-    float *qacc = s + p.qacc, *search = s + p.search, *grad = s + p.grad, *Mgrad = s + p.Mgrad;
-    const float *as = s + p.asmooth, *warm = s + p.warm;
     float gauss, cost, prev_cost;
     bool use_warm = false;
+    // the warm start lives in slab field e_warm; copy it into a dof field so the helpers can address it
+    if (lane < nv) dof(D_TMP, lane) = lds[eb + m.e_warm + lane];
+    WSYNC();
     if (!(m.disableflags & DIS_WARMSTART)) {
-      init_context(warm);
-      const float cw = constraint_cost(warm, &gauss);
-      init_context(as);
-      const float cs = constraint_cost(as, &gauss);
+      init_context(D_TMP);
+      const float cw = constraint_cost(D_TMP, &gauss);
+      init_context(D_ASMOOTH);
+      const float cs = constraint_cost(D_ASMOOTH, &gauss);
       use_warm = cw < cs;
     }
-    for (int i = lane; i < nv; i += AMX_WAVE) qacc[i] = use_warm ? warm[i] : as[i];
+    if (lane < nv) dof(D_QACC, lane) = use_warm ? dof(D_TMP, lane) : dof(D_ASMOOTH, lane);
     WSYNC();
-    if (use_warm || (m.disableflags & DIS_WARMSTART)) init_context(qacc);
-    cost = constraint_cost(qacc, &gauss);
+    if (use_warm || (m.disableflags & DIS_WARMSTART)) init_context(D_QACC);
+    cost = constraint_cost(D_QACC, &gauss);
     prev_cost = INFINITY;
     PROF(9);
     constraint_force_and_grad();
     PROF(10);
     if (m.solver == 2) newton_direction();
-    else chol_solve(m.nchol, s + p.M, m.ldm, nv, s + p.Lb, grad, Mgrad, false, lane);
-    for (int i = lane; i < nv; i += AMX_WAVE) search[i] = -Mgrad[i];
+    else chol_solve(m.nchol, eb + m.e_M, m.ldm, nv, eb + m.e_Lb, dofoff(D_GRAD), dofoff(D_MGRAD), false, lane);
+    if (lane < nv) dof(D_SEARCH, lane) = -dof(D_MGRAD, lane);
     WSYNC();
     PROF(11);
     int niter = 0;
     while (true) {
       if (m.iterations != 1 || niter > 0) {
-        float gn = 0;
-        for (int i = lane; i < nv; i += AMX_WAVE) gn += grad[i] * grad[i];
-        gn = wave_sum(gn);
+        const float g = lane < nv ? dof(D_GRAD, lane) : 0.0f;
+        const float gn = wave_sum(g * g);
         bool done = niter >= m.iterations;
         done = done || ((prev_cost - cost) / m.scale < m.tolerance);
         done = done || (sqrtf(gn) / m.scale < m.tolerance);
@@ -1061,30 +992,31 @@ struct Env {
       PROF(13);
       float pg = 0;  // CG: keep grad.Mgrad of the previous iterate
       if (m.solver != 2) {
-        for (int i = lane; i < nv; i += AMX_WAVE) { pg += grad[i] * Mgrad[i]; s[p.tmp + i] = Mgrad[i]; }
+        if (lane < nv) { pg = dof(D_GRAD, lane) * dof(D_MGRAD, lane); dof(D_TMP, lane) = dof(D_MGRAD, lane); }
         pg = wave_sum(pg);
       }
       prev_cost = cost;
-      cost = constraint_cost(qacc, &gauss);
+      cost = constraint_cost(D_QACC, &gauss);
       constraint_force_and_grad();
       PROF(10);
       if (m.solver == 2) {
-        newton_direction();
-        PROF(11);
-        for (int i = lane; i < nv; i += AMX_WAVE) search[i] = -Mgrad[i];
+        // the search direction of an iteration that will not run is never read: skip its factorisation
+        if (niter + 1 < m.iterations) {
+          newton_direction();
+          PROF(11);
+          if (lane < nv) dof(D_SEARCH, lane) = -dof(D_MGRAD, lane);
+        }
       } else {
-        chol_solve(m.nchol, s + p.M, m.ldm, nv, s + p.Lb, grad, Mgrad, false, lane);
-        float num = 0;
-        for (int i = lane; i < nv; i += AMX_WAVE) num += grad[i] * (Mgrad[i] - s[p.tmp + i]);
+        chol_solve(m.nchol, eb + m.e_M, m.ldm, nv, eb + m.e_Lb, dofoff(D_GRAD), dofoff(D_MGRAD), false, lane);
+        float num = lane < nv ? dof(D_GRAD, lane) * (dof(D_MGRAD, lane) - dof(D_TMP, lane)) : 0.0f;
         num = wave_sum(num);
         const float beta = fmaxf(0.0f, num / fmaxf(MINVAL, pg));
-        for (int i = lane; i < nv; i += AMX_WAVE) search[i] = -Mgrad[i] + beta * search[i];
+        if (lane < nv) dof(D_SEARCH, lane) = -dof(D_MGRAD, lane) + beta * dof(D_SEARCH, lane);
       }
       WSYNC();
       ++niter;
       if (m.iterations == 1) break;
     }
-    *niter_out = niter;
   }
 
   // ------------------------------------------------------------------ forward (A9.1-A9.13)
@@ -1105,58 +1037,54 @@ struct Env {
     PROF(6);
     smooth_forces();
     PROF(7);
-    // qacc_smooth = M^-1 qfrc_smooth; the factor of M stays in Lb for the CG preconditioner
-    chol_solve(m.nchol, s + p.M, m.ldm, nv, s + p.Lb, s + p.fsmooth, s + p.asmooth, true, lane);
+    // qacc_smooth = M^-1 qfrc_smooth.  Newton: the factor is staged in the (still unused) H buffer;
+    // CG keeps it in Lb as its preconditioner.
+    chol_solve(m.nchol, eb + m.e_M, m.ldm, nv, m.solver == 2 ? eb + m.e_H : eb + m.e_Lb, dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), true, lane);
     PROF(8);
     if (m.nefc == 0) {
-      for (int i = lane; i < nv; i += AMX_WAVE) { s[p.qacc + i] = s[p.asmooth + i]; s[p.fcon + i] = 0; }
+      if (lane < nv) { dof(D_QACC, lane) = dof(D_ASMOOTH, lane); dof(D_FCON, lane) = 0; }
       WSYNC();
       return;
     }
-    int niter;
-    solve(&niter);
-    for (int i = lane; i < nv; i += AMX_WAVE) s[p.warm + i] = s[p.qacc + i];
+    solve();
+    if (lane < nv) lds[eb + m.e_warm + lane] = dof(D_QACC, lane);
     WSYNC();
     PROF(15);
   }
 
   // ------------------------------------------------------------------ A9.14 semi-implicit Euler
   DEV void euler() {
-    const int nv = m.nv, ldm = m.ldm;
-    float *qpos = s + p.qpos, *qvel = s + p.qvel;
-    const float *qacc = s + p.qacc;
-    float *acc = s + p.mv;
+    const int nv = m.nv, ldm = m.ldm, Mo = eb + m.e_M, Ho = eb + m.e_H;
+    const int qp = eb + m.e_qpos, qv = eb + m.e_qvel;
     if (!(m.disableflags & DIS_EULERDAMP)) {
-      const float *M = s + p.M;
-      float *H = s + p.H, *rhs = s + p.search;
-      for (int e = lane; e < nv * ldm; e += AMX_WAVE) H[e] = M[e];
-      for (int i = lane; i < nv; i += AMX_WAVE) rhs[i] = s[p.fsmooth + i] + s[p.fcon + i];
+      for (int e = lane; e < nv * ldm; e += AMX_WAVE) lds[Ho + e] = lds[Mo + e];
+      if (lane < nv) dof(D_SEARCH, lane) = dof(D_FSMOOTH, lane) + dof(D_FCON, lane);
       WSYNC();
-      for (int i = lane; i < nv; i += AMX_WAVE) H[i * ldm + i] += m.dt * FP(dof_damping, i);
+      if (lane < nv) lds[Ho + lane * ldm + lane] += m.dt * CF(m.c_dof + lane * DOF_S + 5);
       WSYNC();
-      chol_solve(m.nchol, H, ldm, nv, s + p.Lb, rhs, acc, true, lane);
+      chol_solve(m.nchol, Ho, ldm, nv, Ho, dofoff(D_SEARCH), dofoff(D_MV), true, lane);
     } else {
-      for (int i = lane; i < nv; i += AMX_WAVE) acc[i] = qacc[i];
+      if (lane < nv) dof(D_MV, lane) = dof(D_QACC, lane);
       WSYNC();
     }
     PROF(16);
-    for (int i = lane; i < nv; i += AMX_WAVE) qvel[i] += acc[i] * m.dt;
+    if (lane < nv) lds[qv + lane] += dof(D_MV, lane) * m.dt;
     WSYNC();
-    for (int j = lane; j < m.njnt; j += AMX_WAVE) {
-      const int t_ = IP(jnt_type, j), qa = IP(jnt_qadr, j), da = IP(jnt_dadr, j);
+    if (lane < m.njnt) {
+      const int jr = m.c_jnt + lane * JNT_S, t_ = CI(jr), qa = qp + CI(jr + 1), da = qv + CI(jr + 2);
       if (t_ == JFREE || t_ == JBALL) {
         int qq = qa, dd = da;
         if (t_ == JFREE) {
-          qpos[qa] += qvel[da] * m.dt; qpos[qa + 1] += qvel[da + 1] * m.dt; qpos[qa + 2] += qvel[da + 2] * m.dt;
+          lds[qa] += lds[da] * m.dt; lds[qa + 1] += lds[da + 1] * m.dt; lds[qa + 2] += lds[da + 2] * m.dt;
           qq = qa + 3; dd = da + 3;
         }
         float n;
-        f3 w = normalize3(mk3(qvel[dd], qvel[dd + 1], qvel[dd + 2]), &n);
-        f4 q = {qpos[qq], qpos[qq + 1], qpos[qq + 2], qpos[qq + 3]};
+        const f3 w = normalize3(mk3(lds[dd], lds[dd + 1], lds[dd + 2]), &n);
+        f4 q = {lds[qq], lds[qq + 1], lds[qq + 2], lds[qq + 3]};
         q = qnormalize(qmul(q, axisangle(w, m.dt * n)));
-        qpos[qq] = q.w; qpos[qq + 1] = q.x; qpos[qq + 2] = q.y; qpos[qq + 3] = q.z;
+        lds[qq] = q.w; lds[qq + 1] = q.x; lds[qq + 2] = q.y; lds[qq + 3] = q.z;
       } else {
-        qpos[qa] += qvel[da] * m.dt;
+        lds[qa] += lds[da] * m.dt;
       }
     }
     WSYNC();
@@ -1165,98 +1093,122 @@ struct Env {
 };
 
 // =====================================================================================================
-// Kernel: one workgroup (= one wavefront) per environment.
+// Kernels: AMX_WAVES_PER_BLOCK environments per workgroup, one wavefront each.  One kernel per entry
+// point of the C ABI so each carries only its own arguments in SGPRs.
 // =====================================================================================================
-extern "C" __global__ void __launch_bounds__(AMX_WAVE) amx_env_kernel(const DevModel m, const LdsPlan p, const LaunchArgs a) {
-  extern __shared__ float lds[];
-  const int lane = threadIdx.x, e = blockIdx.x;
-  if (e >= a.nenv) return;
-  float *s = lds;
-  const int nq = m.nq, nv = m.nv, nu = m.nu, nx = nq + nv;
-  // zero the whole slab once: J, M and H have static sparsity and are only written on their support
-  for (int i = lane; i < p.total; i += AMX_WAVE) s[i] = 0.0f;
-  WSYNC();
-  Env env(m, p, s, lane);
+#define AMX_BLOCK (AMX_WAVE * AMX_WAVES_PER_BLOCK)
+#define AMX_KERNEL_PROLOGUE()                                                                               \
+  const int lane = threadIdx.x & (AMX_WAVE - 1), wave = threadIdx.x / AMX_WAVE;                              \
+  const int e = blockIdx.x * AMX_WAVES_PER_BLOCK + wave;                                                     \
+  /* stage the model constants once per workgroup (coalesced, shared by its waves) */                       \
+  for (int i = threadIdx.x; i < m.nconst; i += AMX_BLOCK) lds[i] = m.image[i];                               \
+  __syncthreads(); /* the only workgroup barrier; the waves are independent from here on */                 \
+  if (e >= nenv) return;                                                                                     \
+  const int eb = m.nconst + wave * m.env_floats;                                                             \
+  const int nq = m.nq, nv = m.nv, nu = m.nu, nx = nq + nv;                                                   \
+  /* zero the slab once: J, M and H have static sparsity and are only written on their support */           \
+  for (int i = lane; i < m.env_floats; i += AMX_WAVE) lds[eb + i] = 0.0f;                                    \
+  WSYNC();                                                                                                   \
+  Env env(m, eb, lane);                                                                                      \
+  const int qp = eb + m.e_qpos, qv = eb + m.e_qvel;
+
+// vmap(shoot): state stays in LDS for the whole horizon; HBM sees one control row in and one state row out per step.
+extern "C" __global__ void __launch_bounds__(AMX_BLOCK, AMX_MIN_WAVES_PER_SIMD)
+amx_rollout_kernel(const DevModel m, int nenv, int nsteps, int x0_batched, const float *__restrict__ x0g, const float *__restrict__ usg,
+                   float *__restrict__ xs, float *__restrict__ xfinal, float *__restrict__ prof) {
+  AMX_KERNEL_PROLOGUE()
 #ifdef AMX_PROFILE
   env.prof_t = (unsigned)__builtin_amdgcn_s_memtime();
 #endif
-  if (a.mode == AMX_MODE_ROLLOUT) {
-    const float *x0 = a.x0 + (a.x0_batched ? (size_t)e * nx : 0);
-    for (int i = lane; i < nx; i += AMX_WAVE) {
-      const float v = x0[i];
-      if (i < nq) s[p.qpos + i] = v; else s[p.qvel + i - nq] = v;
-      if (a.xs) a.xs[(size_t)e * (a.nsteps + 1) * nx + i] = v;
-    }
-    WSYNC();
-    env.forward();  // shoot(): one forward before the scan; it seeds qacc_warmstart
-    const float *us = a.us + (size_t)e * a.nsteps * nu;
-    const bool one_pass = nu <= AMX_WAVE;  // control row fits one coalesced wave load: prefetch it a step ahead
-    float unext = (one_pass && lane < nu && a.nsteps > 0) ? us[lane] : 0.0f;
-    for (int t = 0; t < a.nsteps; ++t) {
-      if (one_pass) {
-        if (lane < nu) s[p.ctrl + lane] = unext;
-        if (t + 1 < a.nsteps && lane < nu) unext = us[(size_t)(t + 1) * nu + lane];
-      } else {
-        for (int i = lane; i < nu; i += AMX_WAVE) s[p.ctrl + i] = us[(size_t)t * nu + i];
-      }
-      WSYNC();
-      env.forward();
-      env.euler();
-      if (a.xs) {
-        float *row = a.xs + ((size_t)e * (a.nsteps + 1) + t + 1) * nx;
-        for (int i = lane; i < nx; i += AMX_WAVE) row[i] = i < nq ? s[p.qpos + i] : s[p.qvel + i - nq];
-      }
-#ifdef AMX_PROFILE
-      { unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); if (lane == 0) s[p.prof + 18] += (float)(t_ - env.prof_t); env.prof_t = t_; }
-#endif
-    }
-#ifdef AMX_PROFILE
-    WSYNC();
-    if (a.prof && lane < PROF_N) a.prof[(size_t)e * PROF_N + lane] = s[p.prof + lane];
-#endif
-    if (a.xfinal)
-      for (int i = lane; i < nx; i += AMX_WAVE) a.xfinal[(size_t)e * nx + i] = i < nq ? s[p.qpos + i] : s[p.qvel + i - nq];
-    return;
+  const float *x0 = x0g + (x0_batched ? (size_t)e * nx : 0);
+  for (int i = lane; i < nx; i += AMX_WAVE) {
+    const float v = x0[i];
+    if (i < nq) lds[qp + i] = v; else lds[qv + i - nq] = v;
+    if (xs) xs[(size_t)e * (nsteps + 1) * nx + i] = v;
   }
-  // step / forward: state comes from and returns to HBM
-  for (int i = lane; i < nq; i += AMX_WAVE) s[p.qpos + i] = a.qpos[(size_t)e * nq + i];
-  for (int i = lane; i < nv; i += AMX_WAVE) {
-    s[p.qvel + i] = a.qvel[(size_t)e * nv + i];
-    const float *w = a.mode == AMX_MODE_STEP ? a.warm : a.warm_in;
-    s[p.warm + i] = w ? w[(size_t)e * nv + i] : 0.0f;
-  }
-  for (int i = lane; i < nu; i += AMX_WAVE) s[p.ctrl + i] = a.us[(size_t)e * nu + i];
+  const float *us = usg + (size_t)e * nsteps * nu;
+  float unext = (lane < nu && nsteps > 0) ? us[lane] : 0.0f;  // control row prefetched one step ahead
   WSYNC();
-  if (a.mode == AMX_MODE_STEP) {
-    for (int t = 0; t < a.nsteps; ++t) { env.forward(); env.euler(); }
-    for (int i = lane; i < nq; i += AMX_WAVE) a.qpos[(size_t)e * nq + i] = s[p.qpos + i];
-    for (int i = lane; i < nv; i += AMX_WAVE) {
-      a.qvel[(size_t)e * nv + i] = s[p.qvel + i];
-      if (a.warm) a.warm[(size_t)e * nv + i] = s[p.warm + i];
+  // t = -1 is shoot()'s forward before the scan (ctrl = 0): it only seeds qacc_warmstart
+  for (int t = -1; t < nsteps; ++t) {
+    if (t >= 0) {
+      if (lane < nu) lds[eb + m.e_ctrl + lane] = unext;
+      if (t + 1 < nsteps && lane < nu) unext = us[(size_t)(t + 1) * nu + lane];
+      WSYNC();
     }
-    if (a.time && lane == 0) a.time[e] += m.dt * a.nsteps;
-    return;
+    env.forward();
+    if (t >= 0) {
+      env.euler();
+      if (xs) {
+        float *rowp = xs + ((size_t)e * (nsteps + 1) + t + 1) * nx;
+        for (int i = lane; i < nx; i += AMX_WAVE) rowp[i] = i < nq ? lds[qp + i] : lds[qv + i - nq];
+      }
+    }
+#ifdef AMX_PROFILE
+    { unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); if (lane == 0) lds[eb + m.e_prof + 18] += (float)(t_ - env.prof_t); env.prof_t = t_; }
+#endif
   }
+  if (xfinal)
+    for (int i = lane; i < nx; i += AMX_WAVE) xfinal[(size_t)e * nx + i] = i < nq ? lds[qp + i] : lds[qv + i - nq];
+#ifdef AMX_PROFILE
+  WSYNC();
+  if (prof && lane < PROF_N) prof[(size_t)e * PROF_N + lane] = lds[eb + m.e_prof + lane];
+#endif
+}
+
+// MjxEnv.pipeline_step: nsub physics steps with ctrl held; state comes from and returns to HBM.
+extern "C" __global__ void __launch_bounds__(AMX_BLOCK, AMX_MIN_WAVES_PER_SIMD)
+amx_step_kernel(const DevModel m, int nenv, int nsub, float *__restrict__ qpos, float *__restrict__ qvel, const float *__restrict__ ctrl,
+                float *__restrict__ warm, float *__restrict__ time) {
+  AMX_KERNEL_PROLOGUE()
+  for (int i = lane; i < nq; i += AMX_WAVE) lds[qp + i] = qpos[(size_t)e * nq + i];
+  if (lane < nv) {
+    lds[qv + lane] = qvel[(size_t)e * nv + lane];
+    lds[eb + m.e_warm + lane] = warm ? warm[(size_t)e * nv + lane] : 0.0f;
+  }
+  if (lane < nu) lds[eb + m.e_ctrl + lane] = ctrl[(size_t)e * nu + lane];
+  WSYNC();
+  for (int t = 0; t < nsub; ++t) { env.forward(); env.euler(); }
+  for (int i = lane; i < nq; i += AMX_WAVE) qpos[(size_t)e * nq + i] = lds[qp + i];
+  if (lane < nv) {
+    qvel[(size_t)e * nv + lane] = lds[qv + lane];
+    if (warm) warm[(size_t)e * nv + lane] = lds[eb + m.e_warm + lane];
+  }
+  if (time && lane == 0) time[e] += m.dt * nsub;
+}
+
+struct ForwardOut { float *qacc, *qacc_smooth, *qfrc_bias, *qfrc_constraint, *qM, *xpos, *xquat, *cdist; int *nefc; };
+
+// mjx.forward: derived quantities for a given state, no integration.
+extern "C" __global__ void __launch_bounds__(AMX_BLOCK, AMX_MIN_WAVES_PER_SIMD)
+amx_forward_kernel(const DevModel m, int nenv, const float *__restrict__ qpos, const float *__restrict__ qvel, const float *__restrict__ ctrl,
+                   const float *__restrict__ warm, const ForwardOut o) {
+  AMX_KERNEL_PROLOGUE()
+  for (int i = lane; i < nq; i += AMX_WAVE) lds[qp + i] = qpos[(size_t)e * nq + i];
+  if (lane < nv) {
+    lds[qv + lane] = qvel[(size_t)e * nv + lane];
+    lds[eb + m.e_warm + lane] = warm ? warm[(size_t)e * nv + lane] : 0.0f;
+  }
+  if (lane < nu) lds[eb + m.e_ctrl + lane] = ctrl[(size_t)e * nu + lane];
+  WSYNC();
   env.forward();
-  for (int i = lane; i < nv; i += AMX_WAVE) {
-    if (a.o_qacc) a.o_qacc[(size_t)e * nv + i] = s[p.qacc + i];
-    if (a.o_qacc_smooth) a.o_qacc_smooth[(size_t)e * nv + i] = s[p.asmooth + i];
-    if (a.o_qfrc_bias) a.o_qfrc_bias[(size_t)e * nv + i] = s[p.fbias + i];
-    if (a.o_qfrc_constraint) a.o_qfrc_constraint[(size_t)e * nv + i] = s[p.fcon + i];
+  if (lane < nv) {
+    if (o.qacc) o.qacc[(size_t)e * nv + lane] = env.dof(Env::D_QACC, lane);
+    if (o.qacc_smooth) o.qacc_smooth[(size_t)e * nv + lane] = env.dof(Env::D_ASMOOTH, lane);
+    if (o.qfrc_bias) o.qfrc_bias[(size_t)e * nv + lane] = env.dof(Env::D_FBIAS, lane);
+    if (o.qfrc_constraint) o.qfrc_constraint[(size_t)e * nv + lane] = env.dof(Env::D_FCON, lane);
   }
-  if (a.o_qM)
-    for (int k = lane; k < nv * nv; k += AMX_WAVE) a.o_qM[(size_t)e * nv * nv + k] = s[p.M + (k / nv) * m.ldm + (k % nv)];
-  if (a.o_xpos)
-    for (int k = lane; k < m.nb * 3; k += AMX_WAVE) a.o_xpos[(size_t)e * m.nb * 3 + k] = s[p.xpos + (k % 3) * m.nb + k / 3];
-  if (a.o_xquat)
-    for (int k = lane; k < m.nb * 4; k += AMX_WAVE) a.o_xquat[(size_t)e * m.nb * 4 + k] = s[p.xquat + (k % 4) * m.nb + k / 4];
-  if (a.o_cdist)
-    for (int k = lane; k < m.ncon; k += AMX_WAVE) a.o_cdist[(size_t)e * m.ncon + k] = s[p.cdist + k];
-  if (a.o_nefc) {
-    float cnt = 0;
-    for (int r = lane; r < m.nefc; r += AMX_WAVE) cnt += s[p.D + r] > 0 ? 1.0f : 0.0f;
-    cnt = wave_sum(cnt);
-    if (lane == 0) a.o_nefc[e] = (int)cnt;
+  if (o.qM)
+    for (int k = lane; k < nv * nv; k += AMX_WAVE) o.qM[(size_t)e * nv * nv + k] = lds[eb + m.e_M + (k / nv) * m.ldm + (k % nv)];
+  if (o.xpos)
+    for (int k = lane; k < m.nb * 3; k += AMX_WAVE) o.xpos[(size_t)e * m.nb * 3 + k] = env.body(k % 3, k / 3);
+  if (o.xquat)
+    for (int k = lane; k < m.nb * 4; k += AMX_WAVE) o.xquat[(size_t)e * m.nb * 4 + k] = env.body(3 + k % 4, k / 4);
+  if (o.cdist)
+    for (int k = lane; k < m.ncon; k += AMX_WAVE) o.cdist[(size_t)e * m.ncon + k] = env.con(0, k);
+  if (o.nefc) {
+    const unsigned long long mask = __ballot(lane < m.nefc && env.rD > 0);
+    if (lane == 0) o.nefc[e] = __popcll(mask);
   }
 }
 
