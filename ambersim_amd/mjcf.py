@@ -880,9 +880,9 @@ class _Compiler:
                         ctrl=_floats(e.get("ctrl"), m.nu) if e.get("ctrl") else np.zeros(m.nu)))
         m.nkey = len(keys)
         m.names_key = [k["name"] for k in keys]
-        m.key_qpos = np.array([k["qpos"] for k in keys]).reshape(-1, m.nq)
-        m.key_qvel = np.array([k["qvel"] for k in keys]).reshape(-1, m.nv)
-        m.key_ctrl = np.array([k["ctrl"] for k in keys]).reshape(-1, m.nu)
+        m.key_qpos = np.array([k["qpos"] for k in keys], dtype=float).reshape(len(keys), m.nq)
+        m.key_qvel = np.array([k["qvel"] for k in keys], dtype=float).reshape(len(keys), m.nv)
+        m.key_ctrl = np.array([k["ctrl"] for k in keys], dtype=float).reshape(len(keys), m.nu)
 
 
 # ----------------------------------------------------------------------------- derived constants
@@ -994,7 +994,8 @@ def _set_const(m: MjModel):
 # Pair functions the hot path implements; ids shared with oracle/ and csrc/.
 PAIR_PLANE_SPHERE, PAIR_PLANE_CAPSULE, PAIR_PLANE_CONVEX = 0, 1, 2
 PAIR_SPHERE_SPHERE, PAIR_SPHERE_CAPSULE, PAIR_CAPSULE_CAPSULE = 3, 4, 5
-_PAIR_NCON = {0: 1, 1: 2, 2: 4, 3: 1, 4: 1, 5: 1}
+PAIR_UNSUPPORTED = -1  # e.g. convex-convex (mesh/box vs mesh/box) or condim != 3: not built yet
+_PAIR_NCON = {0: 1, 1: 2, 2: 4, 3: 1, 4: 1, 5: 1, -1: 0}
 _BOX_CORNERS = np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], dtype=float)
 
 
@@ -1040,10 +1041,11 @@ def _make_collision_pairs(m: MjModel):
             elif ta == GEOM_CAPSULE and tb == GEOM_CAPSULE:
                 fn = PAIR_CAPSULE_CAPSULE
             else:
-                raise NotImplementedError(
-                    f"collision between geom types {ta} and {tb} ('{m.names_geom[a]}', '{m.names_geom[b]}')")
+                # the host model still loads (as MuJoCo's compiler would); putting it on the device raises
+                # NotImplementedError, like mjx.device_put does for unsupported collisions (reference io_utils.py:228-241)
+                fn = PAIR_UNSUPPORTED
             if max(m.geom_condim[a], m.geom_condim[b]) != 3:
-                raise NotImplementedError("only condim=3 contacts are supported")
+                fn = PAIR_UNSUPPORTED
             # parameter mixing (MuJoCo mj_contactParam)
             pa, pb = m.geom_priority[a], m.geom_priority[b]
             if pa != pb:
@@ -1079,6 +1081,7 @@ def _make_collision_pairs(m: MjModel):
                               solimp=np.array(solimp), includemargin=margin - gap, vadr=vadr, vnum=vnum))
     # contacts are grouped by pair function (as the reference physics groups them), stable in geom order
     pairs.sort(key=lambda p: p["fn"])
+    m.nunsupported_pairs = sum(1 for p in pairs if p["fn"] < 0)
     m.npair = len(pairs)
     m.pair_geom1 = np.array([p["g1"] for p in pairs], dtype=np.int32).reshape(-1)
     m.pair_geom2 = np.array([p["g2"] for p in pairs], dtype=np.int32).reshape(-1)

@@ -136,6 +136,10 @@ class Data:
 def put_model(mj: MjModel, device=None) -> Model:
     if mj.opt.integrator != 0:
         raise NotImplementedError("only the Euler integrator is implemented")
+    if getattr(mj, "nunsupported_pairs", 0):
+        raise NotImplementedError(
+            f"{mj.nunsupported_pairs} collision pairs need convex-convex (mesh/box) contact or condim != 3, which are not "
+            "implemented; disable contact (DisableBit.CONTACT) or restrict contype/conaffinity")
     return Model(mj, _dev(device))
 
 

@@ -53,6 +53,8 @@ class Oracle:
         self.dtype = np.dtype(dtype)
         self.lib = _lib(dtype)
         self.mj = mj_model
+        if getattr(mj_model, "nunsupported_pairs", 0):
+            raise NotImplementedError("model has collision pairs outside the implemented pair functions")
         self._desc = build_desc(mj_model)
         self.m = self.lib.amxo_model_create(C.byref(self._desc))
         self.d = self.lib.amxo_data_create(self.m)

@@ -1,0 +1,81 @@
+"""C-ABI library: loads without a GPU, exports every symbol include/amx.h declares, struct layout matches ctypes."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from ambersim_amd import _lib
+from ambersim_amd._desc import AmxModelDesc, build_desc
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "amx.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(amx_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = declared_functions()
+    assert set(names) == set(_lib.EXPORTS) and len(names) == 9
+    lib = _lib.lib()
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.amx_version() == 1
+
+
+def test_desc_layout_matches_c(tmp_path):
+    """sizeof/offsetof of amx_model_desc as gcc sees the header vs the ctypes mirror."""
+    fields = ["version", "nq", "nconvexvert", "timestep", "gravity", "meaninertia", "iterations", "disableflags",
+              "body_parentid", "body_invweight0", "jnt_type", "qpos_spring", "dof_invweight0", "geom_size", "pair_geom1",
+              "convex_vert", "actuator_trnid", "actuator_forcerange", "eq_obj1id", "eq_solimp"]
+    src = tmp_path / "layout.c"
+    lines = "".join(f'  printf("{f} %zu\\n", offsetof(amx_model_desc, {f}));\n' for f in fields)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "amx.h"\nint main(void){\n  printf("sizeof %zu\\n", sizeof(amx_model_desc));\n'
+                   + lines + "  return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    assert int(out["sizeof"]) == C.sizeof(AmxModelDesc)
+    for f in fields:
+        assert int(out[f]) == getattr(AmxModelDesc, f).offset, f
+
+
+def test_error_reporting_without_gpu(mj_models):
+    """Bad arguments come back as codes + messages, never exceptions across the boundary; codes map to the
+    exception types the reference's callers expect."""
+    lib = _lib.lib()
+    h = C.c_void_p()
+    assert lib.amx_model_create(None, 0, C.byref(h)) == _lib.AMX_EINVAL
+    assert b"null" in lib.amx_last_error()
+    d = build_desc(mj_models["pendulum"])
+    d.version = 99
+    assert lib.amx_model_create(C.byref(d), 0, C.byref(h)) == _lib.AMX_EINVAL
+    d = build_desc(mj_models["pendulum"])
+    d.integrator = 1
+    assert lib.amx_model_create(C.byref(d), 0, C.byref(h)) == _lib.AMX_EUNSUPPORTED
+    with pytest.raises(NotImplementedError):
+        _lib.check(_lib.AMX_EUNSUPPORTED)
+    with pytest.raises(ValueError):
+        _lib.check(_lib.AMX_EINVAL)
+    assert lib.amx_rollout(None, 1, 1, None, 0, None, None, None, None) == _lib.AMX_EINVAL
+    assert lib.amx_quadcost(1, 1, 1, 1, None, None, None, None, None, None, None, None) == _lib.AMX_EINVAL
+
+
+def test_capacity_limits_are_reported(mj_models):
+    """Models beyond the lane-role capacities are rejected up front (AMX_ECAPACITY -> NotImplementedError)."""
+    import numpy as np
+    from ambersim_amd.mjcf import MjModel
+    bodies = "".join(f'<body pos="0 {i} 0"><joint type="hinge" axis="0 0 1"/><geom type="sphere" size="0.1"/></body>' for i in range(40))
+    big = MjModel.from_xml_string(f"<mujoco><worldbody>{bodies}</worldbody></mujoco>")
+    assert big.nv == 40
+    lib = _lib.lib()
+    h = C.c_void_p()
+    d = build_desc(big)
+    assert lib.amx_model_create(C.byref(d), 0, C.byref(h)) == _lib.AMX_ECAPACITY
+    assert b"nv=40" in lib.amx_last_error()
