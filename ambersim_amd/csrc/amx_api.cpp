@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -36,6 +37,16 @@ struct amx_model {
   float *d_image;
   int ncon, nefc, lds_bytes;
 };
+
+template <int G> static hipError_t set_lds_limit_g(int bytes) {
+  hipError_t e;
+  if ((e = hipFuncSetAttribute((const void *)amx_rollout_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute((const void *)amx_step_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return e;
+  return hipFuncSetAttribute((const void *)amx_forward_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+static hipError_t set_lds_limit(int G, int bytes) {
+  return G == 16 ? set_lds_limit_g<16>(bytes) : (G == 32 ? set_lds_limit_g<32>(bytes) : set_lds_limit_g<64>(bytes));
+}
 
 namespace {
 // Builder of the constant image: floats, with ints stored bit-cast.
@@ -80,8 +91,8 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
   if (d->nv < 1) return fail(AMX_EUNSUPPORTED, "model has no degrees of freedom");
   if (d->nv > AMX_MAX_NV) return fail(AMX_ECAPACITY, "nv=%d exceeds the register-row factorisation capacity %d", d->nv, AMX_MAX_NV);
   const int nb = d->nbody, nv = d->nv, nq = d->nq, nu = d->nu, nj = d->njnt, np = d->npair;
-  if (nb > AMX_WAVE || nj > AMX_WAVE || nu > AMX_WAVE || np > AMX_WAVE)
-    return fail(AMX_ECAPACITY, "lane-role capacity: nbody=%d njnt=%d nu=%d npair=%d must each be <= %d", nb, nj, nu, np, AMX_WAVE);
+  if (nb > AMX_WAVE || nj > AMX_WAVE || np > AMX_WAVE)
+    return fail(AMX_ECAPACITY, "lane-role capacity: nbody=%d njnt=%d npair=%d must each be <= %d", nb, nj, np, AMX_WAVE);
 
   DevModel m;
   memset(&m, 0, sizeof(m));
@@ -90,7 +101,7 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
   m.dt = (float)d->timestep; m.gx = (float)d->gravity[0]; m.gy = (float)d->gravity[1]; m.gz = (float)d->gravity[2];
   m.tolerance = (float)d->tolerance; m.ls_tolerance = (float)d->ls_tolerance; m.impratio = (float)d->impratio;
   m.scale = (float)(d->meaninertia * (nv > 1 ? nv : 1));
-  m.ldm = nv | 1; m.ldj = nv | 1; m.nchol = nv;
+  m.nchol = nv;
   const bool refsafe = !(d->disableflags & 2048);
 
   // ---- tree structure
@@ -177,6 +188,8 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
   // pairs, contact slots, per-pair dof lists, Jacobian work items, Hessian work items
   m.c_pair = im.reserve(np * PAIR_S);
   std::vector<int> con_pair, pairdof, jac_items, hent;
+  std::vector<std::vector<int>> dofmem(nv);
+  int maxchain = 1;
   int ncon = 0;
   for (int p = 0; p < np; p++) {
     int g1 = d->pair_geom1[p], g2 = d->pair_geom2[p], fn = d->pair_fn[p], o = m.c_pair + p * PAIR_S;
@@ -203,12 +216,17 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
     for (int i = 0; i < nv; i++) if (sign[i]) pairdof.push_back(i | (sign[i] << 8));
     int dn = (int)pairdof.size() - d0;
     im.seti(o + 9, d0); im.seti(o + 10, dn);
+    if (dn > 31) return fail(AMX_ECAPACITY, "pair %d couples %d dofs (limit 31)", p, dn);
+    maxchain = std::max(maxchain, dn);
     im.seti(o + 23, (int)hent.size());
-    for (int a = 0; a < dn; a++)
-      for (int b = 0; b <= a; b++) hent.push_back((pairdof[d0 + a] & 255) | ((pairdof[d0 + b] & 255) << 8) | (p << 16));
+    for (int a = 0; a < dn; a++) {
+      dofmem[pairdof[d0 + a] & 255].push_back(p | (a << 8));
+      for (int b = 0; b <= a; b++)  // dof list ascending, so (dof_a, dof_b) is a lower-triangle entry
+        hent.push_back((pairdof[d0 + a] & 255) | ((pairdof[d0 + b] & 255) << 5) | (a << 10) | (b << 15) | (p << 20));
+    }
     im.seti(o + 24, dn * (dn + 1) / 2);
     for (int k = 0; k < PAIR_NCON[fn]; k++) {
-      for (int t = 0; t < dn; t++) jac_items.push_back((ncon + k) | ((d0 + t) << 8));
+      for (int t = 0; t < dn; t++) jac_items.push_back((ncon + k) | (t << 8) | ((d0 + t) << 16));
       con_pair.push_back(p);
     }
     ncon += PAIR_NCON[fn];
@@ -245,6 +263,12 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
   const bool con_off = d->disableflags & 1;
   m.nefc = con_off ? 0 : m.neq + m.nlim + 4 * m.ncon;
   if (m.nefc > AMX_WAVE) return fail(AMX_ECAPACITY, "%d constraint rows exceed the lane-role capacity %d", m.nefc, AMX_WAVE);
+  // lanes per environment: the smallest group that holds every lane-role index set
+  {
+    const int need = std::max({nb, nj, nv, np, m.ngc, m.nefc, 1});
+    m.G = need <= 16 ? 16 : (need <= 32 ? 32 : 64);
+    if (const char *force = getenv("AMX_FORCE_G")) { int g = atoi(force); if ((g == 16 || g == 32 || g == 64) && g >= m.G) m.G = g; }
+  }
   // lists
   auto add_ints = [&](const std::vector<int> &v) { int o = im.reserve((int)v.size()); for (size_t k = 0; k < v.size(); k++) im.seti(o + (int)k, v[k]); return o; };
   m.c_child = add_ints(child_list);
@@ -253,6 +277,15 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
   m.nM = (int)Mlist.size(); m.c_M = add_ints(Mlist);
   m.c_dofact = add_ints(dofact); m.c_pairdof = add_ints(pairdof); m.c_jac = add_ints(jac_items); m.c_hent = add_ints(hent);
   m.c_conpair = add_ints(con_pair); m.c_rootbody = add_ints(roots);
+  {
+    std::vector<int> adr(nv + 1, 0), flat;
+    for (int i = 0; i < nv; i++) { adr[i] = (int)flat.size(); flat.insert(flat.end(), dofmem[i].begin(), dofmem[i].end()); }
+    adr[nv] = (int)flat.size();
+    m.c_dofmemadr = add_ints(adr); m.c_dofmem = add_ints(flat);
+  }
+  m.ldc = maxchain | 1;
+  m.c_qpos0 = im.reserve(nq);
+  for (int k = 0; k < nq; k++) im.setf(m.c_qpos0 + k, d->qpos0[k]);
   m.c_vert = im.reserve(3 * d->nconvexvert);
   for (int k = 0; k < 3 * d->nconvexvert; k++) im.setf(m.c_vert + k, d->convex_vert[k]);
   m.nconst = im.size();
@@ -263,15 +296,19 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
   m.e_qpos = take(nq); m.e_qvel = take(nv); m.e_ctrl = take(nu); m.e_warm = take(nv);
   m.e_body = take(BODY_E * nb); m.e_jnt = take(JNT_E * nj); m.e_dof = take(DOF_E * nv);
   m.e_com = take(3 * m.nroot); m.e_actf = take(nu);
-  m.e_M = take(nv * m.ldm); m.e_H = take(nv * m.ldm); m.e_Lb = d->solver == 1 ? take(nv * m.ldm) : m.e_H;
-  m.e_row = take(ROW_E * m.nefc); m.e_J = take(m.nefc * m.ldj);
+  const int ntri = nv * (nv + 1) / 2;
+  m.e_M = take(ntri); m.e_H = take(ntri); m.e_Lb = d->solver == 1 ? take(ntri) : m.e_H;
+  m.e_row = take(ROW_E * m.nefc); m.e_J = take(4 * m.ncon * m.ldc);
   m.e_con = take(CON_E * m.ncon); m.e_frame = take(9 * np); m.e_geom = take(GEO_E * m.ngc);
+#ifdef AMX_PROFILE
   m.e_prof = take(24);
+#endif
   m.env_floats = off;
-  const int lds_bytes = (m.nconst + AMX_WAVES_PER_BLOCK * m.env_floats) * (int)sizeof(float);
+  const int envs_per_block = AMX_WAVES_PER_BLOCK * (AMX_WAVE / m.G);
+  const int lds_bytes = (m.nconst + envs_per_block * m.env_floats) * (int)sizeof(float);
   if (lds_bytes > 160 * 1024)
     return fail(AMX_ECAPACITY, "model needs %d bytes of LDS per workgroup (%d constants + %d x %d per environment; limit 163840)",
-                lds_bytes, m.nconst * 4, AMX_WAVES_PER_BLOCK, m.env_floats * 4);
+                lds_bytes, m.nconst * 4, envs_per_block, m.env_floats * 4);
 
   amx_model *h = new (std::nothrow) amx_model();
   if (!h) return fail(AMX_ENOMEM, "out of host memory");
@@ -279,9 +316,7 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
   hipError_t e;
   if ((e = hipSetDevice(device)) != hipSuccess || (e = hipMalloc((void **)&h->d_image, im.v.size() * sizeof(float))) != hipSuccess ||
       (e = hipMemcpy(h->d_image, im.v.data(), im.v.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess ||
-      (e = hipFuncSetAttribute((const void *)amx_rollout_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)) != hipSuccess ||
-      (e = hipFuncSetAttribute((const void *)amx_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)) != hipSuccess ||
-      (e = hipFuncSetAttribute((const void *)amx_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)) != hipSuccess) {
+      (e = set_lds_limit(m.G, lds_bytes)) != hipSuccess) {
     if (h->d_image) (void)hipFree(h->d_image);
     delete h;
     return fail(AMX_EHIP, "model upload failed: %s", hipGetErrorString(e));
@@ -310,17 +345,25 @@ extern "C" int amx_model_query(const amx_model *m, const char *name, int *out) {
   else if (n == "ncon") *out = m->ncon;
   else if (n == "nefc_max") *out = m->nefc;
   else if (n == "lds_bytes") *out = m->lds_bytes;
-  else if (n == "lanes_per_env") *out = AMX_WAVE;
-  else if (n == "envs_per_block") *out = AMX_WAVES_PER_BLOCK;
+  else if (n == "lanes_per_env") *out = m->dev.G;
+  else if (n == "envs_per_block") *out = AMX_WAVES_PER_BLOCK * (AMX_WAVE / m->dev.G);
   else return fail(AMX_EINVAL, "unknown query '%s'", name);
   return AMX_OK;
 }
 
 static int pre_launch(const amx_model *m, int nenv, dim3 *grid) {
   HIP_TRY(hipSetDevice(m->device));
-  *grid = dim3((nenv + AMX_WAVES_PER_BLOCK - 1) / AMX_WAVES_PER_BLOCK);
+  const int per_block = AMX_WAVES_PER_BLOCK * (AMX_WAVE / m->dev.G);
+  *grid = dim3((nenv + per_block - 1) / per_block);
   return AMX_OK;
 }
+// one instantiation per group width; the model picks its own at creation
+#define AMX_LAUNCH_G(kernel, m, grid, stream, ...)                                                                       \
+  do {                                                                                                                   \
+    if ((m)->dev.G == 16) hipLaunchKernelGGL(kernel<16>, grid, dim3(AMX_BLOCK), (m)->lds_bytes, (hipStream_t)stream, __VA_ARGS__);      \
+    else if ((m)->dev.G == 32) hipLaunchKernelGGL(kernel<32>, grid, dim3(AMX_BLOCK), (m)->lds_bytes, (hipStream_t)stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kernel<64>, grid, dim3(AMX_BLOCK), (m)->lds_bytes, (hipStream_t)stream, __VA_ARGS__);                       \
+  } while (0)
 
 extern "C" int amx_forward(const amx_model *m, int nenv, const float *qpos, const float *qvel, const float *ctrl,
                            const float *warm, const amx_forward_out *o, void *stream) {
@@ -335,7 +378,7 @@ extern "C" int amx_forward(const amx_model *m, int nenv, const float *qpos, cons
   }
   dim3 grid;
   if (int rc = pre_launch(m, nenv, &grid)) return rc;
-  hipLaunchKernelGGL(amx_forward_kernel, grid, dim3(AMX_BLOCK), m->lds_bytes, (hipStream_t)stream, m->dev, nenv, qpos, qvel, ctrl, warm, fo);
+  AMX_LAUNCH_G(amx_forward_kernel, m, grid, stream, m->dev, nenv, qpos, qvel, ctrl, warm, fo);
   HIP_TRY(hipGetLastError());
   return AMX_OK;
 }
@@ -346,7 +389,7 @@ extern "C" int amx_step(const amx_model *m, int nenv, int nsub, float *qpos, flo
   if (nenv == 0) return AMX_OK;
   dim3 grid;
   if (int rc = pre_launch(m, nenv, &grid)) return rc;
-  hipLaunchKernelGGL(amx_step_kernel, grid, dim3(AMX_BLOCK), m->lds_bytes, (hipStream_t)stream, m->dev, nenv, nsub, qpos, qvel, ctrl, warm, time);
+  AMX_LAUNCH_G(amx_step_kernel, m, grid, stream, m->dev, nenv, nsub, qpos, qvel, ctrl, warm, time);
   HIP_TRY(hipGetLastError());
   return AMX_OK;
 }
@@ -367,8 +410,7 @@ extern "C" int amx_rollout(const amx_model *m, int nenv, int nsteps, const float
 #ifdef AMX_PROFILE
   prof = g_prof;
 #endif
-  hipLaunchKernelGGL(amx_rollout_kernel, grid, dim3(AMX_BLOCK), m->lds_bytes, (hipStream_t)stream, m->dev, nenv, nsteps, x0_batched, x0, us, xs,
-                     xfinal, prof);
+  AMX_LAUNCH_G(amx_rollout_kernel, m, grid, stream, m->dev, nenv, nsteps, x0_batched, x0, us, xs, xfinal, prof);
   HIP_TRY(hipGetLastError());
   return AMX_OK;
 }

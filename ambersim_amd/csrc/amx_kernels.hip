@@ -4,18 +4,22 @@
 // Replaces mjx.forward / mjx.step under MjxEnv.pipeline_step (reference ambersim/rl/base.py:81-96)
 // and shoot (reference ambersim/trajopt/shooting.py:22-48).  Stage names follow SURVEY.md §8(a)
 // A9.1-A9.14.  Layout rules:
-//   * one wavefront = one environment, so every branch on solver state is wave-uniform; a workgroup
-//     holds AMX_WAVES_PER_BLOCK independent waves that share ONE LDS copy of the model constants
-//     (staged once, one s_barrier) and never synchronise again — phases inside a wave are ordered by
-//     wavefront-scope fences only (LDS operations of one wave execute in order);
-//   * static lane roles: lane b owns body b, lane i owns dof i, lane r owns constraint row r, so
+//   * a group of G lanes (G = 16, 32 or 64, the smallest that holds the model's bodies / dofs / rows)
+//     owns one environment, so a wavefront advances 64/G environments with one instruction stream;
+//     solver loops run to the slowest group of the wave with per-group predicates (a finished group's
+//     state is frozen, recomputing its derived vectors is idempotent);
+//   * a workgroup holds AMX_WAVES_PER_BLOCK independent waves that share ONE LDS copy of the model
+//     constants (staged once, one s_barrier) and never synchronise again — phases inside a wave are
+//     ordered by wavefront-scope fences only (LDS operations of one wave execute in order);
+//   * static lane roles inside a group: lane b owns body b, lane i owns dof i, lane r owns constraint row r, so
 //     per-row solver state (D, aref, Jaref, Jv) lives in registers and role constants are read from
 //     LDS records with odd strides (bank-conflict free), never through dependent HBM loads;
 //   * per-body / per-dof arrays are struct-of-arrays in LDS; dense matrices use an odd leading dimension;
 //   * tree scans run level by level; up-scans gather from a static child list instead of scattering;
 //   * the small dense factorisations (M, M+J'DJ, M+dt*damping) hold one matrix row per lane in
-//     registers and exchange pivots with v_readlane (no LDS traffic inside the factorisation);
-//   * wave reductions use DPP row operations + v_readlane, never LDS;
+//     registers; pivots travel by v_readlane (G = 64) or through the LDS crossbar (ds_bpermute, G < 64),
+//     which also moves half of the factorisation's instructions off the VALU;
+//   * group reductions use DPP row operations (+ one ds_swizzle / bpermute step across rows), never LDS memory;
 //   * HBM traffic of a rollout is the control stream in and the state rows out, both coalesced.
 #include <hip/hip_runtime.h>
 #include "amx_dev.h"
@@ -142,78 +146,99 @@ DEV float wave_sum(float x) {
   return (readlane_f(x, 0) + readlane_f(x, 16)) + (readlane_f(x, 32) + readlane_f(x, 48));
 }
 
+// ---- group-level primitives: a group is G consecutive lanes (G = 16, 32, 64)
+template <int G> DEV float gsum(float x) {  // every lane gets the sum over its group
+  x += dpp_f<0xB1>(x);
+  x += dpp_f<0x4E>(x);
+  x += dpp_f<0x141>(x);
+  x += dpp_f<0x140>(x);  // 16-lane row total in every lane of the row
+  if (G >= 32) x += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x401F));  // lane ^ 16 (crossbar, no LDS memory)
+  if (G >= 64) x += __shfl_xor(x, 32);
+  return x;
+}
+// value of lane `j` of my group (j compile-time or wave-uniform); gb4 = 4 * (first lane of my group)
+template <int G> DEV float gbcast(float x, int j, int gb4) {
+  if (G == 64) return readlane_f(x, j);
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(gb4 + 4 * j, __float_as_int(x)));
+}
+DEV bool wave_any(bool p) { return __ballot(p) != 0ull; }
+
 // ---- register-row dense Cholesky: lane i holds row i of the matrix at lds[A_off] (lower part).
-// Solves A x = rhs.  L is written row-major to lds[L_off] (may equal A_off: each lane overwrites only
+// Matrices are packed lower-triangular (row i at TRI(i)).  Solves A x = rhs.  L is written to lds[L_off] (may equal A_off: each lane overwrites only
 // its own row after reading it); the two substitutions re-read it masked (strict lower rows, then
 // strict lower columns), so every lane runs the same 3-instruction update per pivot.
 // `factor == false` reuses the factor already stored at L_off (CG preconditioner).
 // Pivot reciprocals use v_rsq_f32 + one Newton step (<= 1 ulp) instead of the IEEE sqrt/divide expansions.
-template <int N>
-__device__ __noinline__ void chol_solve_rows(int A_off, int ld, int n, int L_off, int rhs_off, int x_off, int vstride, bool factor, int lane) {
+// (see chol_solve_rows below)
+#define TRI(i) (((i) * ((i) + 1)) >> 1)  // offset of row i in packed lower-triangular storage
+
+template <int N, int G>
+__device__ __noinline__ void chol_solve_rows(int A_off, int n, int L_off, int rhs_off, int x_off, int vstride, bool factor, int gl, int gb4) {
   float a[N];
-  const int li = lane < n ? lane : 0, row = li * ld;
+  const int li = gl < n ? gl : 0, row = TRI(li);
   if (factor) {
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-      const float v = lds[A_off + row + (k < n ? k : 0)];
-      a[k] = (lane < n && k < n) ? v : (k == lane ? 1.0f : 0.0f);
+      const float v = lds[A_off + row + (k <= li ? k : li)];
+      a[k] = (gl < n && k <= gl) ? v : (k == gl ? 1.0f : 0.0f);
     }
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-      const float ajj = fmaxf(readlane_f(a[j], j), MINVAL);
+      const float ajj = fmaxf(gbcast<G>(a[j], j, gb4), MINVAL);
       float inv = __builtin_amdgcn_rsqf(ajj);
       inv = inv * __builtin_fmaf(-0.5f * ajj * inv, inv, 1.5f);
       const float lij = a[j] * inv;
       a[j] = lij;
 #pragma unroll
-      for (int k = j + 1; k < N; ++k) a[k] = __builtin_fmaf(-lij, readlane_f(lij, k), a[k]);
+      for (int k = j + 1; k < N; ++k) a[k] = __builtin_fmaf(-lij, gbcast<G>(lij, k, gb4), a[k]);
     }
-    if (lane < n) {
+    if (gl < n) {
 #pragma unroll
       for (int k = 0; k < N; ++k)
-        if (k < n) lds[L_off + row + k] = a[k];
+        if (k <= gl) lds[L_off + row + k] = a[k];
     }
     WSYNC();
   }
   const float dinv = 1.0f / lds[L_off + row + li];
 #pragma unroll
-  for (int k = 0; k < N; ++k) {  // strict lower part of row `lane`
-    const float v = lds[L_off + row + (k < n ? k : 0)];
-    a[k] = (lane < n && k < lane && k < n) ? v : 0.0f;
+  for (int k = 0; k < N; ++k) {  // strict lower part of row `gl`
+    const float v = lds[L_off + row + (k < li ? k : li)];
+    a[k] = (gl < n && k < gl) ? v : 0.0f;
   }
   float b = lds[rhs_off + li * vstride];
-  b = lane < n ? b : 0.0f;
+  b = gl < n ? b : 0.0f;
 #pragma unroll
   for (int j = 0; j < N; ++j) {  // forward: L y = rhs; lane j's b is final when pivot j is reached
-    const float yj = readlane_f(b * dinv, j);
+    const float yj = gbcast<G>(b * dinv, j, gb4);
     b = __builtin_fmaf(-a[j], yj, b);
   }
   b *= dinv;
 #pragma unroll
-  for (int k = 0; k < N; ++k) {  // strict lower part of column `lane`
-    const float v = lds[L_off + (k < n ? k : 0) * ld + li];
-    a[k] = (lane < n && k > lane && k < n) ? v : 0.0f;
+  for (int k = 0; k < N; ++k) {  // strict lower part of column `gl`: L[k][gl], k > gl
+    const float v = lds[L_off + TRI(k < n ? k : 0) + (k < n && k > li ? li : 0)];
+    a[k] = (gl < n && k > gl && k < n) ? v : 0.0f;
   }
 #pragma unroll
   for (int j = N - 1; j >= 0; --j) {  // backward: L' x = y
-    const float xj = readlane_f(b * dinv, j);
+    const float xj = gbcast<G>(b * dinv, j, gb4);
     b = __builtin_fmaf(-a[j], xj, b);
   }
-  if (lane < n) lds[x_off + lane * vstride] = b * dinv;
+  if (gl < n) lds[x_off + gl * vstride] = b * dinv;
   WSYNC();
 }
 
 // one out-of-line dispatcher so the call sites stay small
-__device__ __noinline__ void chol_solve(int nchol, int A_off, int ld, int n, int L_off, int rhs_off, int x_off, bool factor, int lane) {
+template <int G>
+__device__ __noinline__ void chol_solve(int nchol, int A_off, int n, int L_off, int rhs_off, int x_off, bool factor, int gl, int gb4) {
   const int vstride = DOF_E;
-  if (nchol <= 4) chol_solve_rows<4>(A_off, ld, n, L_off, rhs_off, x_off, vstride, factor, lane);
-  else if (nchol <= 8) chol_solve_rows<8>(A_off, ld, n, L_off, rhs_off, x_off, vstride, factor, lane);
-  else if (nchol <= 12) chol_solve_rows<12>(A_off, ld, n, L_off, rhs_off, x_off, vstride, factor, lane);
-  else if (nchol <= 16) chol_solve_rows<16>(A_off, ld, n, L_off, rhs_off, x_off, vstride, factor, lane);
-  else if (nchol <= 20) chol_solve_rows<20>(A_off, ld, n, L_off, rhs_off, x_off, vstride, factor, lane);
-  else if (nchol <= 24) chol_solve_rows<24>(A_off, ld, n, L_off, rhs_off, x_off, vstride, factor, lane);
-  else if (nchol <= 28) chol_solve_rows<28>(A_off, ld, n, L_off, rhs_off, x_off, vstride, factor, lane);
-  else chol_solve_rows<32>(A_off, ld, n, L_off, rhs_off, x_off, vstride, factor, lane);
+  if (nchol <= 4) chol_solve_rows<4, G>(A_off, n, L_off, rhs_off, x_off, vstride, factor, gl, gb4);
+  else if (nchol <= 8) chol_solve_rows<8, G>(A_off, n, L_off, rhs_off, x_off, vstride, factor, gl, gb4);
+  else if (nchol <= 12) chol_solve_rows<12, G>(A_off, n, L_off, rhs_off, x_off, vstride, factor, gl, gb4);
+  else if (nchol <= 16) chol_solve_rows<(G >= 16 ? 16 : 12), G>(A_off, n, L_off, rhs_off, x_off, vstride, factor, gl, gb4);
+  else if (nchol <= 20) chol_solve_rows<(G >= 32 ? 20 : 12), G>(A_off, n, L_off, rhs_off, x_off, vstride, factor, gl, gb4);
+  else if (nchol <= 24) chol_solve_rows<(G >= 32 ? 24 : 12), G>(A_off, n, L_off, rhs_off, x_off, vstride, factor, gl, gb4);
+  else if (nchol <= 28) chol_solve_rows<(G >= 32 ? 28 : 12), G>(A_off, n, L_off, rhs_off, x_off, vstride, factor, gl, gb4);
+  else chol_solve_rows<(G >= 32 ? 32 : 12), G>(A_off, n, L_off, rhs_off, x_off, vstride, factor, gl, gb4);
 }
 
 // impedance of one constraint row [A9.6]; k and b are folded on the host, rec points at {k,b,dmin,dmax,width,mid,power,ca,cb}
@@ -234,36 +259,44 @@ struct LSPoint { float alpha, cost, d0, d1; };
 #ifdef AMX_PROFILE
 #define PROF_N 24
 #define PROF_DECL unsigned prof_t;
-#define PROF(id) do { unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); if (lane == 0) lds[eb + m.e_prof + (id)] += (float)(t_ - prof_t); prof_t = t_; } while (0)
+#define PROF(id) do { unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); if (gl == 0) lds[eb + m.e_prof + (id)] += (float)(t_ - prof_t); prof_t = t_; } while (0)
 #else
 #define PROF_DECL
 #define PROF(id)
 #endif
 
 // =====================================================================================================
-// One environment's physics.  `eb` is this wave's slab in LDS; constants live at the front of LDS.
+// One environment's physics, run by a group of G lanes.  `eb` is the group's slab in LDS (per-lane value,
+// equal inside a group); `gl` is the lane's index inside its group; constants live at the front of LDS.
 // =====================================================================================================
+template <int G>
 struct Env {
   const DevModel &m;
-  const int eb, lane;
+  const int eb, gl, gb4;  // slab base, lane-in-group, 4 * first lane of the group (crossbar address base)
   // static role constants of this lane
   int b_parent, b_level, b_root, b_jntadr, b_jntnum, b_childadr, b_childnum;  // body `lane`
   int d_body, d_jnt, d_kind, d_axis, d_root;                                  // dof `lane`
   // per-row solver state of row `lane`
   float rD, rAref, rJaref, rJv;
+  float rJ1, rJ2;  // equality / limit row `gl`: Jacobian entries on dofs rd1, rd2 (contact rows live in LDS, chain-compressed)
+  int rd1, rd2;
   PROF_DECL
 
-  DEV Env(const DevModel &m_, int eb_, int lane_) : m(m_), eb(eb_), lane(lane_) {
+  DEV Env(const DevModel &m_, int eb_, int gl_, int gb4_) : m(m_), eb(eb_), gl(gl_), gb4(gb4_) {
+    const int lane = gl;
     const int br = m.c_body + (lane < m.nb ? lane : 0) * BODY_S;
     b_parent = CI(br); b_level = lane < m.nb ? CI(br + 1) : -1; b_root = CI(br + 2); b_jntadr = CI(br + 3); b_jntnum = CI(br + 4);
     b_childadr = CI(br + 5); b_childnum = CI(br + 6);
     const int dr = m.c_dof + (lane < m.nv ? lane : 0) * DOF_S;
     d_body = CI(dr); d_jnt = CI(dr + 1); d_kind = CI(dr + 2); d_axis = CI(dr + 3); d_root = CI(dr + 8);
-    rD = rAref = rJaref = rJv = 0.0f;
+    rD = rAref = rJaref = rJv = rJ1 = rJ2 = 0.0f;
+    rd1 = 0; rd2 = -1;
+    if (lane < m.neq) { const int er = m.c_eq + lane * EQ_S; rd1 = CI(er + 1); rd2 = CI(er + 3); }
+    else if (lane < m.neq + m.nlim) rd1 = CI(m.c_lim + (lane - m.neq) * LIM_S + 1);
   }
 
   // SoA accessors of the environment slab
-  // Records with odd compile-time strides: lane-per-record access is bank-conflict free and every field
+  // Records with odd compile-time strides: gl-per-record access is bank-conflict free and every field
   // is an immediate offset from one base address (no per-field address registers).
   DEV float &body(int f, int b) const { return lds[eb + m.e_body + b * BODY_E + f]; }
   DEV float &jnt(int f, int j) const { return lds[eb + m.e_jnt + j * JNT_E + f]; }
@@ -284,15 +317,17 @@ struct Env {
 #pragma unroll
     for (int k = 0; k < 6; ++k) dof(f0 + k, i) = v.v[k];
   }
-  enum { F_XPOS = 0, F_XQUAT = 3, F_CINERT = 7, F_CRB = 17, F_CVEL = 27, F_CACC = 33, F_CFRC = 39 };
-  enum { D_CDOF = 0, D_FCRB = 6, D_FSMOOTH = 12, D_ASMOOTH = 13, D_QACC = 14, D_MA = 15, D_GRAD = 16, D_MGRAD = 17,
-         D_SEARCH = 18, D_MV = 19, D_FCON = 20, D_TMP = 21, D_FBIAS = 22 };
+  // crb (10) is dead once M is built; cvel + cacc (12) reuse its space
+  enum { F_XPOS = 0, F_XQUAT = 3, F_CINERT = 7, F_CRB = 17, F_CVEL = 17, F_CACC = 23, F_CFRC = 29 };
+  // crb*cdof (6) is dead once M is built; the six solver vectors reuse its space
+  enum { D_CDOF = 0, D_FCRB = 6, D_MA = 6, D_GRAD = 7, D_MGRAD = 8, D_SEARCH = 9, D_MV = 10, D_FCON = 11,
+         D_FSMOOTH = 12, D_ASMOOTH = 13, D_QACC = 14, D_TMP = 15, D_FBIAS = 16 };
   DEV int dofoff(int f) const { return eb + m.e_dof + f; }  // element i of dof field f lives at dofoff(f) + i*DOF_E
 
   // ------------------------------------------------------------------ A9.1 kinematics
   DEV void kinematics() {
-    const int b = lane;
-    if (lane == 0) {
+    const int b = gl;
+    if (gl == 0) {
       body(0, 0) = 0; body(1, 0) = 0; body(2, 0) = 0;
       body(3, 0) = 1; body(4, 0) = 0; body(5, 0) = 0; body(6, 0) = 0;
     }
@@ -347,7 +382,7 @@ struct Env {
 
   // ------------------------------------------------------------------ A9.2 com_pos: tree COM, cinert, cdof (+ collision geom poses)
   DEV void com_pos() {
-    const int b = lane, nb = m.nb;
+    const int b = gl, nb = m.nb;
     const bool isb = b > 0 && b < nb;
     const int br = m.c_body + (isb ? b : 0) * BODY_S;
     f3 xi = mk3(0, 0, 0);
@@ -359,8 +394,8 @@ struct Env {
     }
     for (int r = 0; r < m.nroot; ++r) {
       const bool mine = isb && b_root == r;
-      float sx = wave_sum(mine ? xi.x * ms : 0.0f), sy = wave_sum(mine ? xi.y * ms : 0.0f), sz = wave_sum(mine ? xi.z * ms : 0.0f),
-            sm = wave_sum(mine ? ms : 0.0f);
+      float sx = gsum<G>(mine ? xi.x * ms : 0.0f), sy = gsum<G>(mine ? xi.y * ms : 0.0f), sz = gsum<G>(mine ? xi.z * ms : 0.0f),
+            sm = gsum<G>(mine ? ms : 0.0f);
       const int rb = CI(m.c_rootbody + r);
       if (b == rb) {  // the root body itself writes the tree's COM
         const int o = eb + m.e_com + 3 * r;
@@ -392,8 +427,8 @@ struct Env {
 #pragma unroll
       for (int k = 0; k < 10; ++k) body(F_CINERT + k, b) = r[k];
     }
-    if (lane < m.nv) {
-      const int i = lane, j = d_jnt;
+    if (gl < m.nv) {
+      const int i = gl, j = d_jnt;
       const f3 off = ld_com(d_root) - mk3(jnt(0, j), jnt(1, j), jnt(2, j));
       f3 w = mk3(0, 0, 0), l = mk3(0, 0, 0);
       if (d_kind == 0) {
@@ -410,8 +445,8 @@ struct Env {
       }
       dof(0, i) = w.x; dof(1, i) = w.y; dof(2, i) = w.z; dof(3, i) = l.x; dof(4, i) = l.y; dof(5, i) = l.z;
     }
-    if (lane < m.ngc) {
-      const int g = lane, gr = m.c_geom + g * GEOM_S, gb = CI(gr);
+    if (gl < m.ngc) {
+      const int g = gl, gr = m.c_geom + g * GEOM_S, gb = CI(gr);
       const f4 q = ld_xquat(gb);
       const f3 pos = ld_xpos(gb) + qrot(q, mk3(CF(gr + 2), CF(gr + 3), CF(gr + 4)));
       const f4 gq = {CF(gr + 5), CF(gr + 6), CF(gr + 7), CF(gr + 8)};
@@ -425,7 +460,7 @@ struct Env {
 
   // ------------------------------------------------------------------ A9.3 crb + mass matrix
   DEV void crb_and_M() {
-    const int b = lane, nv = m.nv, ldm = m.ldm;
+    const int b = gl, nv = m.nv;
     for (int L = m.nlevel - 1; L >= 1; --L) {
       if (b_level == L) {
         float r[10];
@@ -441,32 +476,31 @@ struct Env {
       }
       WSYNC();
     }
-    if (lane < nv) {
+    if (gl < nv) {
       float I[10];
 #pragma unroll
       for (int k = 0; k < 10; ++k) I[k] = body(F_CRB + k, d_body);
-      st_dsv(D_FCRB, lane, inert_mul(I, ld_dsv(D_CDOF, lane)));
+      st_dsv(D_FCRB, gl, inert_mul(I, ld_dsv(D_CDOF, gl)));
     }
     WSYNC();
     const int Mo = eb + m.e_M;
-    for (int e = lane; e < m.nM; e += AMX_WAVE) {
+    for (int e = gl; e < m.nM; e += G) {
       const int pk = CI(m.c_M + e), i = pk & 255, j = pk >> 8;
       const sv f = ld_dsv(D_FCRB, i), c = ld_dsv(D_CDOF, j);
       float v = 0;
 #pragma unroll
       for (int k = 0; k < 6; ++k) v += c.v[k] * f.v[k];
       if (i == j) v += CF(m.c_dof + i * DOF_S + 4);
-      lds[Mo + i * ldm + j] = v;
-      lds[Mo + j * ldm + i] = v;
+      lds[Mo + TRI(i) + j] = v;  // j is an ancestor of i: j <= i
     }
     WSYNC();
   }
 
   // ------------------------------------------------------------------ A9.8 com_vel + A9.10 rne (one down-scan, one up-scan)
   DEV void velocity_and_bias() {
-    const int b = lane;
+    const int b = gl;
     const int qv = eb + m.e_qvel;
-    if (lane == 0) {
+    if (gl == 0) {
       sv z = {{0, 0, 0, 0, 0, 0}};
       st_bsv(F_CVEL, 0, z);
       st_bsv(F_CFRC, 0, z);
@@ -540,19 +574,19 @@ struct Env {
   DEV void smooth_forces() {
     const int qp = eb + m.e_qpos, qv = eb + m.e_qvel;
     const bool act_on = m.nu > 0 && !(m.disableflags & DIS_ACTUATION);
-    if (act_on && lane < m.nu) {
-      const int ar = m.c_act + lane * ACT_S, fl = CI(ar + 2);
+    if (act_on && gl < m.nu) {
+      const int ar = m.c_act + gl * ACT_S, fl = CI(ar + 2);
       const float gear = CF(ar + 3);
-      float c = lds[eb + m.e_ctrl + lane];
+      float c = lds[eb + m.e_ctrl + gl];
       if (!(m.disableflags & DIS_CLAMPCTRL) && (fl & 1)) c = fminf(fmaxf(c, CF(ar + 8)), CF(ar + 9));
       float force = CF(ar + 4) * c;
       if (fl & 4) force += CF(ar + 5) + CF(ar + 6) * (lds[qp + CI(ar)] * gear) + CF(ar + 7) * (lds[qv + CI(ar + 1)] * gear);
       if (fl & 2) force = fminf(fmaxf(force, CF(ar + 10)), CF(ar + 11));
-      lds[eb + m.e_actf + lane] = gear * force;
+      lds[eb + m.e_actf + gl] = gear * force;
     }
     WSYNC();
-    if (lane < m.nv) {
-      const int i = lane, dr = m.c_dof + i * DOF_S;
+    if (gl < m.nv) {
+      const int i = gl, dr = m.c_dof + i * DOF_S;
       const sv c = ld_dsv(D_CDOF, i), f = ld_bsv(F_CFRC, d_body);
       float bias = 0;
 #pragma unroll
@@ -575,7 +609,7 @@ struct Env {
     WSYNC();
   }
 
-  // ------------------------------------------------------------------ A9.5 collision (one lane per static geom pair)
+  // ------------------------------------------------------------------ A9.5 collision (one gl per static geom pair)
   DEV void plane_sphere(f3 n, f3 ppos, f3 spos, float r, float *dist, f3 *pos) const {
     const float d = dot(spos - ppos, n) - r;
     *dist = d;
@@ -584,8 +618,8 @@ struct Env {
   DEV void st_contact(int c, float d, f3 cp) const { con(0, c) = d; con(1, c) = cp.x; con(2, c) = cp.y; con(3, c) = cp.z; }
   DEV void collision() {
     const int np = m.npair;
-    if (lane < np) {
-      const int pr = lane, rec = m.c_pair + pr * PAIR_S;
+    if (gl < np) {
+      const int pr = gl, rec = m.c_pair + pr * PAIR_S;
       const int g1 = CI(rec), g2 = CI(rec + 1), fn = CI(rec + 2), c0 = CI(rec + 3);
       const f3 pos1 = mk3(geo(0, g1), geo(1, g1), geo(2, g1)), pos2 = mk3(geo(0, g2), geo(1, g2), geo(2, g2));
       m33 R1, R2;
@@ -683,14 +717,15 @@ struct Env {
   // Row table (static): [0,neq) joint equalities, [neq,neq+nlim) joint limits, then 4 pyramid rows per
   // contact slot.  A row that is inactive this step gets D = 0 (the reference zeroes it instead).
   DEV void make_constraint() {
-    const int ldj = m.ldj, np = m.npair, Jo = eb + m.e_J;
+    const int Jo = eb + m.e_J, ldc = m.ldc;
     const int qp = eb + m.e_qpos, qv = eb + m.e_qvel;
     const bool con_on = !(m.disableflags & DIS_CONSTRAINT);
     const int row0 = m.neq + m.nlim;
     if (con_on && !(m.disableflags & DIS_CONTACT)) {
-      // contact Jacobian entries: one lane per (contact, dof of the pair's ancestor chains)
-      for (int t = lane; t < m.njac; t += AMX_WAVE) {
-        const int pk = CI(m.c_jac + t), c = pk & 255, pd = CI(m.c_pairdof + (pk >> 8)), i = pd & 255, sg = pd >> 8;
+      // contact Jacobian entries: one lane per (contact, dof of the pair's ancestor chains); rows are stored
+      // chain-compressed: Jc[contact row][slot], slot = position of the dof in the pair's dof list
+      for (int t = gl; t < m.njac; t += G) {
+        const int pk = CI(m.c_jac + t), c = pk & 255, slot = (pk >> 8) & 255, pd = CI(m.c_pairdof + (pk >> 16)), i = pd & 255, sg = pd >> 8;
         const int pr = CI(m.c_conpair + c), rec = m.c_pair + pr * PAIR_S;
         const float mu = CF(rec + 11);
         const f3 pt = mk3(con(1, c), con(2, c), con(3, c));
@@ -702,36 +737,36 @@ struct Env {
         if (sg & 1) jp = jp + (l + cross(w, pt - ld_com(CI(rec + 8))));
         if (sg & 2) jp = jp - (l + cross(w, pt - ld_com(CI(rec + 7))));
         const float jn = dot(fn_, jp), j1 = dot(ft1, jp), j2 = dot(ft2, jp);
-        const int r = Jo + (row0 + 4 * c) * ldj + i;
+        const int r = Jo + (4 * c) * ldc + slot;
         lds[r] = jn + mu * j1;
-        lds[r + ldj] = jn - mu * j1;
-        lds[r + 2 * ldj] = jn + mu * j2;
-        lds[r + 3 * ldj] = jn - mu * j2;
+        lds[r + ldc] = jn - mu * j1;
+        lds[r + 2 * ldc] = jn + mu * j2;
+        lds[r + 3 * ldc] = jn - mu * j2;
       }
     }
     WSYNC();
     float dd = 0, ar = 0;
-    if (con_on && lane < m.nefc) {
-      const int r = lane;
+    if (con_on && gl < m.nefc) {
+      const int r = gl;
       float pos = 0, invw = 0, jv = 0;
       bool active = false;
       int rec = 0;  // points at the {k,b,dmin,...} block of the row's record
       if (r < m.neq) {
         if (!(m.disableflags & DIS_EQUALITY)) {
           active = true;
-          const int er = m.c_eq + r * EQ_S, q1 = CI(er), d1 = CI(er + 1), q2 = CI(er + 2), d2 = CI(er + 3);
+          const int er = m.c_eq + r * EQ_S, q1 = CI(er), q2 = CI(er + 2);
           const float pos1 = lds[qp + q1] - CF(er + 19);
           invw = CF(er + 18);
-          lds[Jo + r * ldj + d1] = 1.0f;
-          jv = lds[qv + d1];
+          rJ1 = 1.0f; rJ2 = 0.0f;
+          jv = lds[qv + rd1];
           if (q2 >= 0) {
             const float dif = lds[qp + q2] - CF(er + 20);
             const float c0 = CF(er + 4), c1 = CF(er + 5), c2 = CF(er + 6), c3 = CF(er + 7), c4 = CF(er + 8);
             const float dp2 = dif * dif, dp3 = dp2 * dif, dp4 = dp3 * dif;
             const float deriv = c1 + c2 * dif * 2 + c3 * dp2 * 3 + c4 * dp3 * 4;
             pos = pos1 - (c0 + c1 * dif + c2 * dp2 + c3 * dp3 + c4 * dp4);
-            lds[Jo + r * ldj + d2] = -deriv;
-            jv += -deriv * lds[qv + d2];
+            rJ2 = -deriv;
+            jv += -deriv * lds[qv + rd2];
           } else {
             pos = pos1 - CF(er + 4);
           }
@@ -739,14 +774,13 @@ struct Env {
         }
       } else if (r < row0) {
         if (!(m.disableflags & DIS_LIMIT)) {
-          const int lr = m.c_lim + (r - m.neq) * LIM_S, da = CI(lr + 1);
+          const int lr = m.c_lim + (r - m.neq) * LIM_S;
           const float q = lds[qp + CI(lr)];
           const float dmin = q - CF(lr + 2), dmax = CF(lr + 3) - q;
           pos = fminf(dmin, dmax) - CF(lr + 4);
           active = pos < 0;
-          const float sgn = dmin < dmax ? 1.0f : -1.0f;
-          lds[Jo + r * ldj + da] = sgn;
-          jv = sgn * lds[qv + da];
+          rJ1 = dmin < dmax ? 1.0f : -1.0f;
+          jv = rJ1 * lds[qv + rd1];
           invw = CF(lr + 14);
           rec = lr + 5;
         }
@@ -760,10 +794,7 @@ struct Env {
         const float f = (k & 1) ? -mu : mu;
         invw = (tw + f * f * tw) * 2 * f * f / m.impratio;
         const int d0 = CI(prec + 9), dn = CI(prec + 10);
-        for (int t = 0; t < dn; ++t) {
-          const int i = CI(m.c_pairdof + d0 + t) & 255;
-          jv += lds[Jo + r * ldj + i] * lds[qv + i];
-        }
+        for (int t = 0; t < dn; ++t) jv += lds[Jo + cr * ldc + t] * lds[qv + (CI(m.c_pairdof + d0 + t) & 255)];
         rec = prec + 12;
       }
       if (active) {
@@ -778,120 +809,109 @@ struct Env {
   }
 
   // ------------------------------------------------------------------ A9.13 solver
-  DEV float mul_M_row(int vf) const {  // (M v)[lane], v = dof field vf
-    const int nv = m.nv, Mo = eb + m.e_M + (lane < nv ? lane : 0) * m.ldm, vo = dofoff(vf);
+  DEV float mul_M_row(int vf) const {  // (M v)[gl], v = dof field vf; M packed lower-triangular
+    const int nv = m.nv, i = gl < nv ? gl : 0, Mo = eb + m.e_M, ti = Mo + TRI(i), vo = dofoff(vf);
     float acc = 0;
-    for (int j = 0; j < nv; ++j) acc += lds[Mo + j] * lds[vo + j * DOF_E];
+    for (int j = 0; j < nv; ++j) acc += lds[j <= i ? ti + j : Mo + TRI(j) + i] * lds[vo + j * DOF_E];
     return acc;
   }
-  DEV float row_dot(int vf) const {  // J[lane,:] . v over the row's static support
-    const int r = lane, ldj = m.ldj, Jo = eb + m.e_J + r * ldj, vo = dofoff(vf);
+  DEV float row_dot(int vf) const {  // J[gl,:] . v over the row's static support
+    const int r = gl, vo = dofoff(vf);
     if (r >= m.nefc) return 0.0f;
-    if (r < m.neq) {
-      const int er = m.c_eq + r * EQ_S, d1 = CI(er + 1), d2 = CI(er + 3);
-      float a = lds[Jo + d1] * lds[vo + d1 * DOF_E];
-      if (d2 >= 0) a += lds[Jo + d2] * lds[vo + d2 * DOF_E];
+    if (r < m.neq + m.nlim) {
+      float a = rJ1 * lds[vo + rd1 * DOF_E];
+      if (rd2 >= 0) a += rJ2 * lds[vo + rd2 * DOF_E];
       return a;
-    } else if (r < m.neq + m.nlim) {
-      const int da = CI(m.c_lim + (r - m.neq) * LIM_S + 1);
-      return lds[Jo + da] * lds[vo + da * DOF_E];
     }
-    const int prec = m.c_pair + CI(m.c_conpair + ((r - m.neq - m.nlim) >> 2)) * PAIR_S;
-    const int d0 = CI(prec + 9), dn = CI(prec + 10);
+    const int cr = r - m.neq - m.nlim, prec = m.c_pair + CI(m.c_conpair + (cr >> 2)) * PAIR_S;
+    const int d0 = CI(prec + 9), dn = CI(prec + 10), Jr = eb + m.e_J + cr * m.ldc;
     float a = 0;
-    for (int t = 0; t < dn; ++t) {
-      const int i = CI(m.c_pairdof + d0 + t) & 255;
-      a += lds[Jo + i] * lds[vo + i * DOF_E];
-    }
+    for (int t = 0; t < dn; ++t) a += lds[Jr + t] * lds[vo + (CI(m.c_pairdof + d0 + t) & 255) * DOF_E];
     return a;
   }
   // Ma = M v, Jaref = J v - aref  (v = dof field vf)
   DEV void init_context(int vf) {
     const float ma = mul_M_row(vf);
-    if (lane < m.nv) dof(D_MA, lane) = ma;
+    if (gl < m.nv) dof(D_MA, gl) = ma;
     rJaref = row_dot(vf) - rAref;
     WSYNC();
   }
   DEV float constraint_cost(int vf, float *gauss_out) const {
-    const bool act = lane < m.nefc && (rJaref < 0 || lane < m.neq);
+    const bool act = gl < m.nefc && (rJaref < 0 || gl < m.neq);
     float c = act ? 0.5f * rD * rJaref * rJaref : 0.0f;
-    float g = lane < m.nv ? (dof(D_MA, lane) - dof(D_FSMOOTH, lane)) * (dof(vf, lane) - dof(D_ASMOOTH, lane)) : 0.0f;
-    c = wave_sum(c);
-    g = 0.5f * wave_sum(g);
+    float g = gl < m.nv ? (dof(D_MA, gl) - dof(D_FSMOOTH, gl)) * (dof(vf, gl) - dof(D_ASMOOTH, gl)) : 0.0f;
+    c = gsum<G>(c);
+    g = 0.5f * gsum<G>(g);
     *gauss_out = g;
     return c + g;
   }
   // qfrc_constraint = J' f with f = -D*Jaref on active rows, grad = Ma - qfrc_smooth - qfrc_constraint;
   // also publishes D*active per row for the Hessian assembly.
   DEV void constraint_force_and_grad() {
-    const int ldj = m.ldj, Jo = eb + m.e_J;
-    const bool act = lane < m.nefc && (rJaref < 0 || lane < m.neq) && rD > 0;
+    const int Jo = eb + m.e_J, ldc = m.ldc, row0 = m.neq + m.nlim;
+    const bool act = gl < m.nefc && (rJaref < 0 || gl < m.neq) && rD > 0;
     const float f = act ? -rD * rJaref : 0.0f;
-    if (lane < m.nefc) { row(0, lane) = act ? rD : 0.0f; row(1, lane) = f; }
-    unsigned long long mask = __ballot(act);
+    if (gl < m.nefc) { row(0, gl) = act ? rD : 0.0f; row(1, gl) = f; }
     WSYNC();
-    float acc = 0;
-    const int col = Jo + (lane < m.nv ? lane : 0);
-    while (mask) {
-      const int r = __builtin_ctzll(mask);
-      mask &= mask - 1;
-      acc += lds[col + r * ldj] * row(1, r);
+    // contact rows: dof lane i gathers over the (pair, slot) memberships of its dof
+    if (gl < m.nv) {
+      float acc = 0;
+      const int mem0 = CI(m.c_dofmemadr + gl), mem1 = CI(m.c_dofmemadr + gl + 1);
+      for (int t = mem0; t < mem1; ++t) {
+        const int pk = CI(m.c_dofmem + t), pr = pk & 255, slot = pk >> 8, prec = m.c_pair + pr * PAIR_S;
+        const int cr0 = 4 * CI(prec + 3), nr = 4 * CI(prec + 4);
+        for (int k = 0; k < nr; ++k) acc += lds[Jo + (cr0 + k) * ldc + slot] * row(1, row0 + cr0 + k);
+      }
+      dof(D_FCON, gl) = acc;
     }
-    if (lane < m.nv) {
-      dof(D_FCON, lane) = acc;
-      dof(D_GRAD, lane) = dof(D_MA, lane) - dof(D_FSMOOTH, lane) - acc;
+    WSYNC();
+    // equality / limit rows scatter their one or two entries
+    if (gl < row0 && f != 0.0f) {
+      atomicAdd(&dof(D_FCON, rd1), rJ1 * f);
+      if (rd2 >= 0) atomicAdd(&dof(D_FCON, rd2), rJ2 * f);
     }
+    WSYNC();
+    if (gl < m.nv) dof(D_GRAD, gl) = dof(D_MA, gl) - dof(D_FSMOOTH, gl) - dof(D_FCON, gl);
     WSYNC();
   }
-  DEV void newton_direction() {  // Mgrad = (M + J' D_active J)^-1 grad
-    const int nv = m.nv, ldm = m.ldm, ldj = m.ldj, Mo = eb + m.e_M, Ho = eb + m.e_H, Jo = eb + m.e_J;
-    for (int e = lane; e < nv * ldm; e += AMX_WAVE) lds[Ho + e] = lds[Mo + e];
+  DEV void newton_direction() {  // Mgrad = (M + J' D_active J)^-1 grad, H packed lower-triangular
+    const int nv = m.nv, Mo = eb + m.e_M, Ho = eb + m.e_H, Jo = eb + m.e_J, ldc = m.ldc;
+    for (int e = gl; e < TRI(nv); e += G) lds[Ho + e] = lds[Mo + e];
     WSYNC();
     const int row0 = m.neq + m.nlim;
-    if (lane < row0) {  // equality + limit rows: a handful of entries each
-      const int r = lane;
-      const float d = row(0, r);
+    if (gl < row0) {  // equality + limit rows: a handful of entries each, from registers
+      const float d = row(0, gl);
       if (d != 0.0f) {
-        if (r < m.neq) {
-          const int er = m.c_eq + r * EQ_S, d1 = CI(er + 1), d2 = CI(er + 3);
-          const float j1 = lds[Jo + r * ldj + d1];
-          atomicAdd(&lds[Ho + d1 * ldm + d1], d * j1 * j1);
-          if (d2 >= 0) {
-            const float j2 = lds[Jo + r * ldj + d2];
-            atomicAdd(&lds[Ho + d2 * ldm + d2], d * j2 * j2);
-            atomicAdd(&lds[Ho + d1 * ldm + d2], d * j1 * j2);
-            atomicAdd(&lds[Ho + d2 * ldm + d1], d * j1 * j2);
-          }
-        } else {
-          const int da = CI(m.c_lim + (r - m.neq) * LIM_S + 1);
-          atomicAdd(&lds[Ho + da * ldm + da], d);  // J = +-1
+        atomicAdd(&lds[Ho + TRI(rd1) + rd1], d * rJ1 * rJ1);
+        if (rd2 >= 0) {
+          atomicAdd(&lds[Ho + TRI(rd2) + rd2], d * rJ2 * rJ2);
+          const int hi = rd1 > rd2 ? rd1 : rd2, lo = rd1 > rd2 ? rd2 : rd1;
+          atomicAdd(&lds[Ho + TRI(hi) + lo], d * rJ1 * rJ2);
         }
       }
     }
     // contact rows: one lane per (pair, lower-triangle entry of the pair's dof block)
-    for (int t = lane; t < m.nhent; t += AMX_WAVE) {
-      const int pk = CI(m.c_hent + t), i = pk & 255, j = (pk >> 8) & 255, pr = pk >> 16;
-      const int prec = m.c_pair + pr * PAIR_S, r0 = row0 + 4 * CI(prec + 3), nr = 4 * CI(prec + 4);
+    for (int t = gl; t < m.nhent; t += G) {
+      const int pk = CI(m.c_hent + t), i = pk & 31, j = (pk >> 5) & 31, sa = (pk >> 10) & 31, sb = (pk >> 15) & 31, pr = pk >> 20;
+      const int prec = m.c_pair + pr * PAIR_S, cr0 = 4 * CI(prec + 3), nr = 4 * CI(prec + 4);
       float acc = 0;
       for (int k = 0; k < nr; ++k) {
-        const float d = row(0, r0 + k);
-        if (d != 0.0f) acc += d * lds[Jo + (r0 + k) * ldj + i] * lds[Jo + (r0 + k) * ldj + j];
+        const float d = row(0, row0 + cr0 + k);
+        const int Jr = Jo + (cr0 + k) * ldc;
+        if (d != 0.0f) acc += d * lds[Jr + sa] * lds[Jr + sb];
       }
-      if (acc != 0.0f) {
-        atomicAdd(&lds[Ho + i * ldm + j], acc);
-        if (i != j) atomicAdd(&lds[Ho + j * ldm + i], acc);
-      }
+      if (acc != 0.0f) atomicAdd(&lds[Ho + TRI(i) + j], acc);  // i >= j by construction
     }
     WSYNC();
     PROF(14);
-    chol_solve(m.nchol, Ho, ldm, nv, Ho, dofoff(D_GRAD), dofoff(D_MGRAD), true, lane);
+    chol_solve<G>(m.nchol, Ho, nv, Ho, dofoff(D_GRAD), dofoff(D_MGRAD), true, gl, gb4);
   }
 
   DEV LSPoint ls_point(float alpha, bool valid, bool iseq, float g0, float g1, float g2) const {
     const float x = rJaref + alpha * rJv;
     const bool act = valid && (x < 0 || iseq);
     float q0 = act ? 0.5f * rJaref * rJaref * rD : 0.0f, q1 = act ? rJv * rJaref * rD : 0.0f, q2 = act ? 0.5f * rJv * rJv * rD : 0.0f;
-    q0 = wave_sum(q0) + g0; q1 = wave_sum(q1) + g1; q2 = wave_sum(q2) + g2;
+    q0 = gsum<G>(q0) + g0; q1 = gsum<G>(q1) + g1; q2 = gsum<G>(q2) + g2;
     LSPoint r;
     r.alpha = alpha;
     r.cost = alpha * alpha * q2 + alpha * q1 + q0;
@@ -900,51 +920,56 @@ struct Env {
     return r;
   }
 
-  DEV void linesearch(float gauss) {
+  // MJX's bracketing line search.  `alive` freezes the state of a group that has already converged.
+  DEV void linesearch(float gauss, bool alive) {
     const int nv = m.nv;
     const float mv = mul_M_row(D_SEARCH);
     rJv = row_dot(D_SEARCH);
     float sn = 0, g1 = 0, g2 = 0;
-    if (lane < nv) {
-      const float si = dof(D_SEARCH, lane);
+    if (gl < nv) {
+      const float si = dof(D_SEARCH, gl);
       sn = si * si;
-      g1 = si * dof(D_MA, lane) - si * dof(D_FSMOOTH, lane);
+      g1 = si * dof(D_MA, gl) - si * dof(D_FSMOOTH, gl);
       g2 = 0.5f * si * mv;
     }
-    sn = wave_sum(sn); g1 = wave_sum(g1); g2 = wave_sum(g2);
+    sn = gsum<G>(sn); g1 = gsum<G>(g1); g2 = gsum<G>(g2);
     const float gtol = m.tolerance * m.ls_tolerance * sqrtf(sn) * m.scale;
-    const bool valid = lane < m.nefc, iseq = lane < m.neq;
+    const bool valid = gl < m.nefc, iseq = gl < m.neq;
 #define POINT(al) ls_point((al), valid, iseq, gauss, g1, g2)
+#define PICK(c, a, b) { (c) ? (a).alpha : (b).alpha, (c) ? (a).cost : (b).cost, (c) ? (a).d0 : (b).d0, (c) ? (a).d1 : (b).d1 }
     const LSPoint p0 = POINT(0.0f);
-    LSPoint lo = POINT(p0.alpha - p0.d0 / p0.d1), hi;
-    if (lo.d0 < p0.d0) { hi = p0; } else { hi = lo; lo = p0; }
+    const LSPoint p1 = POINT(p0.alpha - p0.d0 / p0.d1);
+    const bool first = p1.d0 < p0.d0;
+    LSPoint lo = PICK(first, p1, p0), hi = PICK(first, p0, p1);
     bool swap = true;
-    int it = 0;
-    while (true) {
-      bool done = it >= m.ls_iterations;
-      done = done || !swap;
+    for (int it = 0; it < m.ls_iterations; ++it) {
+      bool done = !swap;
       done = done || ((lo.d0 < 0) && (lo.d0 > -gtol));
       done = done || ((hi.d0 > 0) && (hi.d0 < gtol));
-      if (done) break;
+      if (!wave_any(!done && alive)) break;  // every group of the wave has finished its search
       const LSPoint lo_next = POINT(lo.alpha - lo.d0 / lo.d1);
       const LSPoint hi_next = POINT(hi.alpha - hi.d0 / hi.d1);
       const LSPoint mid = POINT(0.5f * (lo.alpha + hi.alpha));
-      const bool s_lo_next = (lo.d0 > 0) || (lo.d0 < lo_next.d0);
-      if (s_lo_next) lo = lo_next;
-      const bool s_lo_mid = (mid.d0 < 0) && (lo.d0 < mid.d0);
-      if (s_lo_mid) lo = mid;
-      const bool s_hi_next = (hi.d0 < 0) || (hi.d0 > hi_next.d0);
-      if (s_hi_next) hi = hi_next;
-      const bool s_hi_mid = (mid.d0 > 0) && (hi.d0 > mid.d0);
-      if (s_hi_mid) hi = mid;
-      swap = s_lo_next || s_lo_mid || s_hi_next || s_hi_mid;
-      ++it;
+      LSPoint nlo = lo, nhi = hi;
+      const bool s_lo_next = (nlo.d0 > 0) || (nlo.d0 < lo_next.d0);
+      { const LSPoint t = PICK(s_lo_next, lo_next, nlo); nlo = t; }
+      const bool s_lo_mid = (mid.d0 < 0) && (nlo.d0 < mid.d0);
+      { const LSPoint t = PICK(s_lo_mid, mid, nlo); nlo = t; }
+      const bool s_hi_next = (nhi.d0 < 0) || (nhi.d0 > hi_next.d0);
+      { const LSPoint t = PICK(s_hi_next, hi_next, nhi); nhi = t; }
+      const bool s_hi_mid = (mid.d0 > 0) && (nhi.d0 > mid.d0);
+      { const LSPoint t = PICK(s_hi_mid, mid, nhi); nhi = t; }
+      // a group whose search has ended keeps its bracket
+      { const LSPoint t = PICK(done, lo, nlo); lo = t; }
+      { const LSPoint t = PICK(done, hi, nhi); hi = t; }
+      swap = done ? false : (s_lo_next || s_lo_mid || s_hi_next || s_hi_mid);
     }
 #undef POINT
-    const bool improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
+#undef PICK
+    const bool improved = alive && ((lo.cost < p0.cost) || (hi.cost < p0.cost));
     const float alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
     if (improved) {
-      if (lane < nv) { dof(D_QACC, lane) += alpha * dof(D_SEARCH, lane); dof(D_MA, lane) += alpha * mv; }
+      if (gl < nv) { dof(D_QACC, gl) += alpha * dof(D_SEARCH, gl); dof(D_MA, gl) += alpha * mv; }
       rJaref += alpha * rJv;
     }
     WSYNC();
@@ -955,48 +980,60 @@ struct Env {
     float gauss, cost, prev_cost;
     bool use_warm = false;
     // the warm start lives in slab field e_warm; copy it into a dof field so the helpers can address it
-    if (lane < nv) dof(D_TMP, lane) = lds[eb + m.e_warm + lane];
+    if (gl < nv) dof(D_TMP, gl) = lds[eb + m.e_warm + gl];
     WSYNC();
+    float ma_warm = 0, ja_warm = 0;
     if (!(m.disableflags & DIS_WARMSTART)) {
       init_context(D_TMP);
       const float cw = constraint_cost(D_TMP, &gauss);
+      ma_warm = gl < nv ? dof(D_MA, gl) : 0.0f;
+      ja_warm = rJaref;
+      WSYNC();
       init_context(D_ASMOOTH);
       const float cs = constraint_cost(D_ASMOOTH, &gauss);
       use_warm = cw < cs;
     }
-    if (lane < nv) dof(D_QACC, lane) = use_warm ? dof(D_TMP, lane) : dof(D_ASMOOTH, lane);
+    if (gl < nv) {
+      dof(D_QACC, gl) = use_warm ? dof(D_TMP, gl) : dof(D_ASMOOTH, gl);
+      if (use_warm) dof(D_MA, gl) = ma_warm;  // context of the chosen start: M*qacc and J*qacc - aref
+    }
+    if (use_warm) rJaref = ja_warm;
     WSYNC();
-    if (use_warm || (m.disableflags & DIS_WARMSTART)) init_context(D_QACC);
+    if (m.disableflags & DIS_WARMSTART) init_context(D_QACC);
     cost = constraint_cost(D_QACC, &gauss);
     prev_cost = INFINITY;
     PROF(9);
     constraint_force_and_grad();
     PROF(10);
     if (m.solver == 2) newton_direction();
-    else chol_solve(m.nchol, eb + m.e_M, m.ldm, nv, eb + m.e_Lb, dofoff(D_GRAD), dofoff(D_MGRAD), false, lane);
-    if (lane < nv) dof(D_SEARCH, lane) = -dof(D_MGRAD, lane);
+    else chol_solve<G>(m.nchol, eb + m.e_M, nv, eb + m.e_Lb, dofoff(D_GRAD), dofoff(D_MGRAD), false, gl, gb4);
+    if (gl < nv) dof(D_SEARCH, gl) = -dof(D_MGRAD, gl);
     WSYNC();
     PROF(11);
-    int niter = 0;
-    while (true) {
-      if (m.iterations != 1 || niter > 0) {
-        const float g = lane < nv ? dof(D_GRAD, lane) : 0.0f;
-        const float gn = wave_sum(g * g);
-        bool done = niter >= m.iterations;
-        done = done || ((prev_cost - cost) / m.scale < m.tolerance);
+    bool alive = true;  // per group: still iterating
+    for (int niter = 0; niter < m.iterations; ++niter) {
+      if (m.iterations != 1) {
+        const float g = gl < nv ? dof(D_GRAD, gl) : 0.0f;
+        const float gn = gsum<G>(g * g);
+        bool done = ((prev_cost - cost) / m.scale < m.tolerance);
         done = done || (sqrtf(gn) / m.scale < m.tolerance);
-        if (done) break;
+        alive = alive && !done;
       }
+      if (!wave_any(alive)) break;
       PROF(12);
-      linesearch(gauss);
+      linesearch(gauss, alive);
       PROF(13);
       float pg = 0;  // CG: keep grad.Mgrad of the previous iterate
       if (m.solver != 2) {
-        if (lane < nv) { pg = dof(D_GRAD, lane) * dof(D_MGRAD, lane); dof(D_TMP, lane) = dof(D_MGRAD, lane); }
-        pg = wave_sum(pg);
+        if (gl < nv) { pg = dof(D_GRAD, gl) * dof(D_MGRAD, gl); dof(D_TMP, gl) = dof(D_MGRAD, gl); }
+        pg = gsum<G>(pg);
       }
-      prev_cost = cost;
-      cost = constraint_cost(D_QACC, &gauss);
+      // a finished group's state is frozen, so recomputing its cost / force / gradient below is idempotent
+      float ngauss;
+      const float ncost = constraint_cost(D_QACC, &ngauss);
+      prev_cost = alive ? cost : prev_cost;
+      cost = alive ? ncost : cost;
+      gauss = alive ? ngauss : gauss;
       constraint_force_and_grad();
       PROF(10);
       if (m.solver == 2) {
@@ -1004,18 +1041,16 @@ struct Env {
         if (niter + 1 < m.iterations) {
           newton_direction();
           PROF(11);
-          if (lane < nv) dof(D_SEARCH, lane) = -dof(D_MGRAD, lane);
+          if (gl < nv) dof(D_SEARCH, gl) = -dof(D_MGRAD, gl);
         }
       } else {
-        chol_solve(m.nchol, eb + m.e_M, m.ldm, nv, eb + m.e_Lb, dofoff(D_GRAD), dofoff(D_MGRAD), false, lane);
-        float num = lane < nv ? dof(D_GRAD, lane) * (dof(D_MGRAD, lane) - dof(D_TMP, lane)) : 0.0f;
-        num = wave_sum(num);
+        chol_solve<G>(m.nchol, eb + m.e_M, nv, eb + m.e_Lb, dofoff(D_GRAD), dofoff(D_MGRAD), false, gl, gb4);
+        float num = gl < nv ? dof(D_GRAD, gl) * (dof(D_MGRAD, gl) - dof(D_TMP, gl)) : 0.0f;
+        num = gsum<G>(num);
         const float beta = fmaxf(0.0f, num / fmaxf(MINVAL, pg));
-        if (lane < nv) dof(D_SEARCH, lane) = -dof(D_MGRAD, lane) + beta * dof(D_SEARCH, lane);
+        if (alive && gl < nv) dof(D_SEARCH, gl) = -dof(D_MGRAD, gl) + beta * dof(D_SEARCH, gl);
       }
       WSYNC();
-      ++niter;
-      if (m.iterations == 1) break;
     }
   }
 
@@ -1039,39 +1074,39 @@ struct Env {
     PROF(7);
     // qacc_smooth = M^-1 qfrc_smooth.  Newton: the factor is staged in the (still unused) H buffer;
     // CG keeps it in Lb as its preconditioner.
-    chol_solve(m.nchol, eb + m.e_M, m.ldm, nv, m.solver == 2 ? eb + m.e_H : eb + m.e_Lb, dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), true, lane);
+    chol_solve<G>(m.nchol, eb + m.e_M, nv, m.solver == 2 ? eb + m.e_H : eb + m.e_Lb, dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), true, gl, gb4);
     PROF(8);
     if (m.nefc == 0) {
-      if (lane < nv) { dof(D_QACC, lane) = dof(D_ASMOOTH, lane); dof(D_FCON, lane) = 0; }
+      if (gl < nv) { dof(D_QACC, gl) = dof(D_ASMOOTH, gl); dof(D_FCON, gl) = 0; }
       WSYNC();
       return;
     }
     solve();
-    if (lane < nv) lds[eb + m.e_warm + lane] = dof(D_QACC, lane);
+    if (gl < nv) lds[eb + m.e_warm + gl] = dof(D_QACC, gl);
     WSYNC();
     PROF(15);
   }
 
   // ------------------------------------------------------------------ A9.14 semi-implicit Euler
   DEV void euler() {
-    const int nv = m.nv, ldm = m.ldm, Mo = eb + m.e_M, Ho = eb + m.e_H;
+    const int nv = m.nv, Mo = eb + m.e_M, Ho = eb + m.e_H;
     const int qp = eb + m.e_qpos, qv = eb + m.e_qvel;
     if (!(m.disableflags & DIS_EULERDAMP)) {
-      for (int e = lane; e < nv * ldm; e += AMX_WAVE) lds[Ho + e] = lds[Mo + e];
-      if (lane < nv) dof(D_SEARCH, lane) = dof(D_FSMOOTH, lane) + dof(D_FCON, lane);
+      for (int e = gl; e < TRI(nv); e += G) lds[Ho + e] = lds[Mo + e];
+      if (gl < nv) dof(D_SEARCH, gl) = dof(D_FSMOOTH, gl) + dof(D_FCON, gl);
       WSYNC();
-      if (lane < nv) lds[Ho + lane * ldm + lane] += m.dt * CF(m.c_dof + lane * DOF_S + 5);
+      if (gl < nv) lds[Ho + TRI(gl) + gl] += m.dt * CF(m.c_dof + gl * DOF_S + 5);
       WSYNC();
-      chol_solve(m.nchol, Ho, ldm, nv, Ho, dofoff(D_SEARCH), dofoff(D_MV), true, lane);
+      chol_solve<G>(m.nchol, Ho, nv, Ho, dofoff(D_SEARCH), dofoff(D_MV), true, gl, gb4);
     } else {
-      if (lane < nv) dof(D_MV, lane) = dof(D_QACC, lane);
+      if (gl < nv) dof(D_MV, gl) = dof(D_QACC, gl);
       WSYNC();
     }
     PROF(16);
-    if (lane < nv) lds[qv + lane] += dof(D_MV, lane) * m.dt;
+    if (gl < nv) lds[qv + gl] += dof(D_MV, gl) * m.dt;
     WSYNC();
-    if (lane < m.njnt) {
-      const int jr = m.c_jnt + lane * JNT_S, t_ = CI(jr), qa = qp + CI(jr + 1), da = qv + CI(jr + 2);
+    if (gl < m.njnt) {
+      const int jr = m.c_jnt + gl * JNT_S, t_ = CI(jr), qa = qp + CI(jr + 1), da = qv + CI(jr + 2);
       if (t_ == JFREE || t_ == JBALL) {
         int qq = qa, dd = da;
         if (t_ == JFREE) {
@@ -1093,123 +1128,142 @@ struct Env {
 };
 
 // =====================================================================================================
-// Kernels: AMX_WAVES_PER_BLOCK environments per workgroup, one wavefront each.  One kernel per entry
-// point of the C ABI so each carries only its own arguments in SGPRs.
+// Kernels: AMX_WAVES_PER_BLOCK wavefronts per workgroup, 64/G environments per wavefront.  One kernel per
+// entry point of the C ABI so each carries only its own arguments in SGPRs.
 // =====================================================================================================
 #define AMX_BLOCK (AMX_WAVE * AMX_WAVES_PER_BLOCK)
 #define AMX_KERNEL_PROLOGUE()                                                                               \
   const int lane = threadIdx.x & (AMX_WAVE - 1), wave = threadIdx.x / AMX_WAVE;                              \
-  const int e = blockIdx.x * AMX_WAVES_PER_BLOCK + wave;                                                     \
+  const int gl = lane & (G - 1), grp = lane / G, gb4 = 4 * (lane & ~(G - 1));                                \
+  const int slot = wave * (AMX_WAVE / G) + grp; /* environment slot inside the workgroup */                 \
+  const int e = blockIdx.x * (AMX_WAVES_PER_BLOCK * (AMX_WAVE / G)) + slot;                                  \
   /* stage the model constants once per workgroup (coalesced, shared by its waves) */                       \
   for (int i = threadIdx.x; i < m.nconst; i += AMX_BLOCK) lds[i] = m.image[i];                               \
   __syncthreads(); /* the only workgroup barrier; the waves are independent from here on */                 \
-  if (e >= nenv) return;                                                                                     \
-  const int eb = m.nconst + wave * m.env_floats;                                                             \
+  if (blockIdx.x * (AMX_WAVES_PER_BLOCK * (AMX_WAVE / G)) + wave * (AMX_WAVE / G) >= nenv) return; /* whole wave idle */ \
+  const bool live = e < nenv; /* a trailing group without an environment still runs, on a zero slab, and never touches HBM */ \
+  const int eb = m.nconst + slot * m.env_floats;                                                             \
   const int nq = m.nq, nv = m.nv, nu = m.nu, nx = nq + nv;                                                   \
   /* zero the slab once: J, M and H have static sparsity and are only written on their support */           \
-  for (int i = lane; i < m.env_floats; i += AMX_WAVE) lds[eb + i] = 0.0f;                                    \
+  for (int i = gl; i < m.env_floats; i += G) lds[eb + i] = 0.0f;                                             \
+  if (!live && gl < nq) lds[eb + m.e_qpos + gl] = CF(m.c_qpos0 + gl); /* keep the idle group's state finite */ \
   WSYNC();                                                                                                   \
-  Env env(m, eb, lane);                                                                                      \
+  Env<G> env(m, eb, gl, gb4);                                                                                \
   const int qp = eb + m.e_qpos, qv = eb + m.e_qvel;
 
 // vmap(shoot): state stays in LDS for the whole horizon; HBM sees one control row in and one state row out per step.
-extern "C" __global__ void __launch_bounds__(AMX_BLOCK, AMX_MIN_WAVES_PER_SIMD)
+template <int G>
+__global__ void __launch_bounds__(AMX_BLOCK, AMX_MIN_WAVES_PER_SIMD)
 amx_rollout_kernel(const DevModel m, int nenv, int nsteps, int x0_batched, const float *__restrict__ x0g, const float *__restrict__ usg,
                    float *__restrict__ xs, float *__restrict__ xfinal, float *__restrict__ prof) {
   AMX_KERNEL_PROLOGUE()
 #ifdef AMX_PROFILE
   env.prof_t = (unsigned)__builtin_amdgcn_s_memtime();
 #endif
-  const float *x0 = x0g + (x0_batched ? (size_t)e * nx : 0);
-  for (int i = lane; i < nx; i += AMX_WAVE) {
-    const float v = x0[i];
-    if (i < nq) lds[qp + i] = v; else lds[qv + i - nq] = v;
-    if (xs) xs[(size_t)e * (nsteps + 1) * nx + i] = v;
+  const float *x0 = x0g + ((x0_batched && live) ? (size_t)e * nx : 0);
+  if (live) {
+    for (int i = gl; i < nx; i += G) {
+      const float v = x0[i];
+      if (i < nq) lds[qp + i] = v; else lds[qv + i - nq] = v;
+      if (xs) xs[(size_t)e * (nsteps + 1) * nx + i] = v;
+    }
   }
-  const float *us = usg + (size_t)e * nsteps * nu;
-  float unext = (lane < nu && nsteps > 0) ? us[lane] : 0.0f;  // control row prefetched one step ahead
+  const float *us = usg + (live ? (size_t)e * nsteps * nu : 0);
+  // control row prefetched one step ahead (rows wider than a group are read in place)
+  float unext = (live && gl < nu && nsteps > 0) ? us[gl] : 0.0f;
   WSYNC();
   // t = -1 is shoot()'s forward before the scan (ctrl = 0): it only seeds qacc_warmstart
   for (int t = -1; t < nsteps; ++t) {
     if (t >= 0) {
-      if (lane < nu) lds[eb + m.e_ctrl + lane] = unext;
-      if (t + 1 < nsteps && lane < nu) unext = us[(size_t)(t + 1) * nu + lane];
+      if (gl < nu) lds[eb + m.e_ctrl + gl] = unext;
+      if (live) for (int i = gl + G; i < nu; i += G) lds[eb + m.e_ctrl + i] = us[(size_t)t * nu + i];
+      if (live && t + 1 < nsteps && gl < nu) unext = us[(size_t)(t + 1) * nu + gl];
       WSYNC();
     }
     env.forward();
     if (t >= 0) {
       env.euler();
-      if (xs) {
+      if (xs && live) {
         float *rowp = xs + ((size_t)e * (nsteps + 1) + t + 1) * nx;
-        for (int i = lane; i < nx; i += AMX_WAVE) rowp[i] = i < nq ? lds[qp + i] : lds[qv + i - nq];
+        for (int i = gl; i < nx; i += G) rowp[i] = i < nq ? lds[qp + i] : lds[qv + i - nq];
       }
     }
 #ifdef AMX_PROFILE
-    { unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); if (lane == 0) lds[eb + m.e_prof + 18] += (float)(t_ - env.prof_t); env.prof_t = t_; }
+    { unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); if (gl == 0) lds[eb + m.e_prof + 18] += (float)(t_ - env.prof_t); env.prof_t = t_; }
 #endif
   }
-  if (xfinal)
-    for (int i = lane; i < nx; i += AMX_WAVE) xfinal[(size_t)e * nx + i] = i < nq ? lds[qp + i] : lds[qv + i - nq];
+  if (xfinal && live)
+    for (int i = gl; i < nx; i += G) xfinal[(size_t)e * nx + i] = i < nq ? lds[qp + i] : lds[qv + i - nq];
 #ifdef AMX_PROFILE
   WSYNC();
-  if (prof && lane < PROF_N) prof[(size_t)e * PROF_N + lane] = lds[eb + m.e_prof + lane];
+  if (prof && live && gl < PROF_N) prof[(size_t)e * PROF_N + gl] = lds[eb + m.e_prof + gl];
+  if (prof && live && G < PROF_N && gl + G < PROF_N) prof[(size_t)e * PROF_N + gl + G] = lds[eb + m.e_prof + gl + G];
 #endif
 }
 
 // MjxEnv.pipeline_step: nsub physics steps with ctrl held; state comes from and returns to HBM.
-extern "C" __global__ void __launch_bounds__(AMX_BLOCK, AMX_MIN_WAVES_PER_SIMD)
+template <int G>
+__global__ void __launch_bounds__(AMX_BLOCK, AMX_MIN_WAVES_PER_SIMD)
 amx_step_kernel(const DevModel m, int nenv, int nsub, float *__restrict__ qpos, float *__restrict__ qvel, const float *__restrict__ ctrl,
                 float *__restrict__ warm, float *__restrict__ time) {
   AMX_KERNEL_PROLOGUE()
-  for (int i = lane; i < nq; i += AMX_WAVE) lds[qp + i] = qpos[(size_t)e * nq + i];
-  if (lane < nv) {
-    lds[qv + lane] = qvel[(size_t)e * nv + lane];
-    lds[eb + m.e_warm + lane] = warm ? warm[(size_t)e * nv + lane] : 0.0f;
+  if (live) {
+    for (int i = gl; i < nq; i += G) lds[qp + i] = qpos[(size_t)e * nq + i];
+    if (gl < nv) {
+      lds[qv + gl] = qvel[(size_t)e * nv + gl];
+      lds[eb + m.e_warm + gl] = warm ? warm[(size_t)e * nv + gl] : 0.0f;
+    }
+    for (int i = gl; i < nu; i += G) lds[eb + m.e_ctrl + i] = ctrl[(size_t)e * nu + i];
   }
-  if (lane < nu) lds[eb + m.e_ctrl + lane] = ctrl[(size_t)e * nu + lane];
   WSYNC();
   for (int t = 0; t < nsub; ++t) { env.forward(); env.euler(); }
-  for (int i = lane; i < nq; i += AMX_WAVE) qpos[(size_t)e * nq + i] = lds[qp + i];
-  if (lane < nv) {
-    qvel[(size_t)e * nv + lane] = lds[qv + lane];
-    if (warm) warm[(size_t)e * nv + lane] = lds[eb + m.e_warm + lane];
+  if (!live) return;
+  for (int i = gl; i < nq; i += G) qpos[(size_t)e * nq + i] = lds[qp + i];
+  if (gl < nv) {
+    qvel[(size_t)e * nv + gl] = lds[qv + gl];
+    if (warm) warm[(size_t)e * nv + gl] = lds[eb + m.e_warm + gl];
   }
-  if (time && lane == 0) time[e] += m.dt * nsub;
+  if (time && gl == 0) time[e] += m.dt * nsub;
 }
 
 struct ForwardOut { float *qacc, *qacc_smooth, *qfrc_bias, *qfrc_constraint, *qM, *xpos, *xquat, *cdist; int *nefc; };
 
 // mjx.forward: derived quantities for a given state, no integration.
-extern "C" __global__ void __launch_bounds__(AMX_BLOCK, AMX_MIN_WAVES_PER_SIMD)
+template <int G>
+__global__ void __launch_bounds__(AMX_BLOCK, AMX_MIN_WAVES_PER_SIMD)
 amx_forward_kernel(const DevModel m, int nenv, const float *__restrict__ qpos, const float *__restrict__ qvel, const float *__restrict__ ctrl,
                    const float *__restrict__ warm, const ForwardOut o) {
   AMX_KERNEL_PROLOGUE()
-  for (int i = lane; i < nq; i += AMX_WAVE) lds[qp + i] = qpos[(size_t)e * nq + i];
-  if (lane < nv) {
-    lds[qv + lane] = qvel[(size_t)e * nv + lane];
-    lds[eb + m.e_warm + lane] = warm ? warm[(size_t)e * nv + lane] : 0.0f;
+  if (live) {
+    for (int i = gl; i < nq; i += G) lds[qp + i] = qpos[(size_t)e * nq + i];
+    if (gl < nv) {
+      lds[qv + gl] = qvel[(size_t)e * nv + gl];
+      lds[eb + m.e_warm + gl] = warm ? warm[(size_t)e * nv + gl] : 0.0f;
+    }
+    for (int i = gl; i < nu; i += G) lds[eb + m.e_ctrl + i] = ctrl[(size_t)e * nu + i];
   }
-  if (lane < nu) lds[eb + m.e_ctrl + lane] = ctrl[(size_t)e * nu + lane];
   WSYNC();
   env.forward();
-  if (lane < nv) {
-    if (o.qacc) o.qacc[(size_t)e * nv + lane] = env.dof(Env::D_QACC, lane);
-    if (o.qacc_smooth) o.qacc_smooth[(size_t)e * nv + lane] = env.dof(Env::D_ASMOOTH, lane);
-    if (o.qfrc_bias) o.qfrc_bias[(size_t)e * nv + lane] = env.dof(Env::D_FBIAS, lane);
-    if (o.qfrc_constraint) o.qfrc_constraint[(size_t)e * nv + lane] = env.dof(Env::D_FCON, lane);
+  const int nactive = __popcll(__ballot(gl < m.nefc && env.rD > 0) >> (lane & ~(G - 1)) & (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1)));
+  if (!live) return;
+  if (gl < nv) {
+    if (o.qacc) o.qacc[(size_t)e * nv + gl] = env.dof(Env<G>::D_QACC, gl);
+    if (o.qacc_smooth) o.qacc_smooth[(size_t)e * nv + gl] = env.dof(Env<G>::D_ASMOOTH, gl);
+    if (o.qfrc_bias) o.qfrc_bias[(size_t)e * nv + gl] = env.dof(Env<G>::D_FBIAS, gl);
+    if (o.qfrc_constraint) o.qfrc_constraint[(size_t)e * nv + gl] = env.dof(Env<G>::D_FCON, gl);
   }
   if (o.qM)
-    for (int k = lane; k < nv * nv; k += AMX_WAVE) o.qM[(size_t)e * nv * nv + k] = lds[eb + m.e_M + (k / nv) * m.ldm + (k % nv)];
+    for (int k = gl; k < nv * nv; k += G) {
+      const int r = k / nv, c = k % nv, hi = r > c ? r : c, lo = r > c ? c : r;
+      o.qM[(size_t)e * nv * nv + k] = lds[eb + m.e_M + TRI(hi) + lo];
+    }
   if (o.xpos)
-    for (int k = lane; k < m.nb * 3; k += AMX_WAVE) o.xpos[(size_t)e * m.nb * 3 + k] = env.body(k % 3, k / 3);
+    for (int k = gl; k < m.nb * 3; k += G) o.xpos[(size_t)e * m.nb * 3 + k] = env.body(k % 3, k / 3);
   if (o.xquat)
-    for (int k = lane; k < m.nb * 4; k += AMX_WAVE) o.xquat[(size_t)e * m.nb * 4 + k] = env.body(3 + k % 4, k / 4);
+    for (int k = gl; k < m.nb * 4; k += G) o.xquat[(size_t)e * m.nb * 4 + k] = env.body(3 + k % 4, k / 4);
   if (o.cdist)
-    for (int k = lane; k < m.ncon; k += AMX_WAVE) o.cdist[(size_t)e * m.ncon + k] = env.con(0, k);
-  if (o.nefc) {
-    const unsigned long long mask = __ballot(lane < m.nefc && env.rD > 0);
-    if (lane == 0) o.nefc[e] = __popcll(mask);
-  }
+    for (int k = gl; k < m.ncon; k += G) o.cdist[(size_t)e * m.ncon + k] = env.con(0, k);
+  if (o.nefc && gl == 0) o.nefc[e] = nactive;
 }
 
 // Batched StaticGoalQuadraticCost.cost (reference ambersim/trajopt/cost.py:62-85): one wave per rollout.

@@ -52,7 +52,8 @@ def test_native_library_is_loaded(cases):
     """The product path is the in-tree HIP library, not a fallback."""
     maps = open("/proc/self/maps").read()
     assert "ambersim_amd/csrc/libamx.so" in maps
-    assert cases["pendulum"][1]._h.query("lanes_per_env") == 64
+    assert cases["pendulum"][1]._h.query("lanes_per_env") == 16 and cases["quadruped"][1]._h.query("lanes_per_env") == 32
+    assert cases["biped"][1]._h.query("lanes_per_env") == 64
 
 
 def test_pendulum_c1_closed_form(cases, golden):
@@ -100,11 +101,12 @@ def test_single_step_parity(cases, golden, name):
     assert worst < max(TOL, 3 * floor) and worst < 3e-5, (worst, floor)
 
 
-@pytest.mark.parametrize("name,steps,tol", [("bh280", 10, 1e-5), ("quadruped", 5, 5e-5), ("biped", 5, 5e-5)])
+@pytest.mark.parametrize("name,steps,tol", [("bh280", 10, 3e-5), ("quadruped", 5, 5e-5), ("biped", 5, 5e-5)])
 def test_short_rollout_vs_golden(cases, golden, name, steps, tol):
-    """Multi-step rollouts vs the committed fp64 fixtures.  bh280 (no contact) holds 1e-5 over the whole 10-step horizon
-    of the reference's own fixture; with contacts, fp32 rounding moves active sets, so the bound is 5e-5 over 5 steps
-    (the fp32 CPU oracle differs from the fp64 one by the same amount, tests/test_golden_cpu.py)."""
+    """Multi-step rollouts vs the committed fp64 fixtures.  The fp32 CPU oracle is itself 1.2e-5 away from the fp64
+    fixture on bh280 (10-step horizon of the reference's own fixture, started outside the joint limits) and ~5e-5 away
+    on the contact models after 5 steps (rounding moves active sets): bounds are 3e-5 and 5e-5 (tests/test_golden_cpu.py
+    has the CPU fp32-vs-fp64 counterpart)."""
     mj, model, x0, us = cases[name]
     xs = gpu_rollout(model, x0, us)
     ref = golden[name + "_xs"]
