@@ -227,6 +227,56 @@ __device__ __noinline__ void chol_solve_rows(int A_off, int n, int L_off, int rh
   WSYNC();
 }
 
+// ---- one-shot SPD solve by Gauss-Jordan elimination, one matrix row per lane in registers.
+// Used where the factor is not reused (qacc_smooth, the Newton direction, the Euler damping solve).
+// Pivot j: every lane fetches row j's remaining entries through one crossbar hop (they are also column j
+// by symmetry of the Schur complement only for rows below, so the pivot ROW is what is broadcast), scales
+// its own column-j entry by 1/pivot and updates its row and right-hand side.  No substitutions, no LDS
+// traffic besides the initial row load, and one cross-lane latency per pivot instead of two plus 2n
+// serial substitution steps for Cholesky.
+template <int N, int G>
+__device__ __noinline__ void spd_solve_rows(int A_off, int n, int rhs_off, int x_off, int vstride, int gl, int gb4) {
+  float a[N];
+  const int li = gl < n ? gl : 0, row = TRI(li);
+#pragma unroll
+  for (int k = 0; k < N; ++k) {  // full symmetric row from packed lower-triangular storage
+    const int kk = k < n ? k : 0;
+    const float v = lds[A_off + (kk <= li ? row + kk : TRI(kk) + li)];
+    a[k] = (gl < n && k < n) ? v : (k == gl ? 1.0f : 0.0f);
+  }
+  float b = lds[rhs_off + li * vstride];
+  b = gl < n ? b : 0.0f;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const float piv = fmaxf(gbcast<G>(a[j], j, gb4), MINVAL);
+    const float bj = gbcast<G>(b, j, gb4);
+    float f = a[j] * __builtin_amdgcn_rcpf(piv);
+    f = gl == j ? 0.0f : f;  // the pivot row itself is left alone
+    b = __builtin_fmaf(-f, bj, b);
+#pragma unroll
+    for (int k = j + 1; k < N; ++k) a[k] = __builtin_fmaf(-f, gbcast<G>(a[k], j, gb4), a[k]);
+  }
+  // the matrix is now diagonal: x_i = b_i / a_ii.  a[gl] is a runtime register index, so select it.
+  float d = 1.0f;
+#pragma unroll
+  for (int k = 0; k < N; ++k) d = (k == gl) ? a[k] : d;
+  if (gl < n) lds[x_off + gl * vstride] = b / d;
+  WSYNC();
+}
+
+template <int G>
+__device__ __noinline__ void spd_solve(int nchol, int A_off, int n, int rhs_off, int x_off, int gl, int gb4) {
+  const int vstride = DOF_E;
+  if (nchol <= 4) spd_solve_rows<4, G>(A_off, n, rhs_off, x_off, vstride, gl, gb4);
+  else if (nchol <= 8) spd_solve_rows<8, G>(A_off, n, rhs_off, x_off, vstride, gl, gb4);
+  else if (nchol <= 12) spd_solve_rows<12, G>(A_off, n, rhs_off, x_off, vstride, gl, gb4);
+  else if (nchol <= 16) spd_solve_rows<(G >= 16 ? 16 : 12), G>(A_off, n, rhs_off, x_off, vstride, gl, gb4);
+  else if (nchol <= 20) spd_solve_rows<(G >= 32 ? 20 : 12), G>(A_off, n, rhs_off, x_off, vstride, gl, gb4);
+  else if (nchol <= 24) spd_solve_rows<(G >= 32 ? 24 : 12), G>(A_off, n, rhs_off, x_off, vstride, gl, gb4);
+  else if (nchol <= 28) spd_solve_rows<(G >= 32 ? 28 : 12), G>(A_off, n, rhs_off, x_off, vstride, gl, gb4);
+  else spd_solve_rows<(G >= 32 ? 32 : 12), G>(A_off, n, rhs_off, x_off, vstride, gl, gb4);
+}
+
 // one out-of-line dispatcher so the call sites stay small
 template <int G>
 __device__ __noinline__ void chol_solve(int nchol, int A_off, int n, int L_off, int rhs_off, int x_off, bool factor, int gl, int gb4) {
@@ -904,7 +954,7 @@ struct Env {
     }
     WSYNC();
     PROF(14);
-    chol_solve<G>(m.nchol, Ho, nv, Ho, dofoff(D_GRAD), dofoff(D_MGRAD), true, gl, gb4);
+    spd_solve<G>(m.nchol, Ho, nv, dofoff(D_GRAD), dofoff(D_MGRAD), gl, gb4);
   }
 
   DEV LSPoint ls_point(float alpha, bool valid, bool iseq, float g0, float g1, float g2) const {
@@ -1072,9 +1122,10 @@ struct Env {
     PROF(6);
     smooth_forces();
     PROF(7);
-    // qacc_smooth = M^-1 qfrc_smooth.  Newton: the factor is staged in the (still unused) H buffer;
-    // CG keeps it in Lb as its preconditioner.
-    chol_solve<G>(m.nchol, eb + m.e_M, nv, m.solver == 2 ? eb + m.e_H : eb + m.e_Lb, dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), true, gl, gb4);
+    // qacc_smooth = M^-1 qfrc_smooth.  Newton never reuses the factor: one-shot Gauss-Jordan solve;
+    // CG keeps a Cholesky factor in Lb as its preconditioner.
+    if (m.solver == 2) spd_solve<G>(m.nchol, eb + m.e_M, nv, dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), gl, gb4);
+    else chol_solve<G>(m.nchol, eb + m.e_M, nv, eb + m.e_Lb, dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), true, gl, gb4);
     PROF(8);
     if (m.nefc == 0) {
       if (gl < nv) { dof(D_QACC, gl) = dof(D_ASMOOTH, gl); dof(D_FCON, gl) = 0; }
@@ -1097,7 +1148,7 @@ struct Env {
       WSYNC();
       if (gl < nv) lds[Ho + TRI(gl) + gl] += m.dt * CF(m.c_dof + gl * DOF_S + 5);
       WSYNC();
-      chol_solve<G>(m.nchol, Ho, nv, Ho, dofoff(D_SEARCH), dofoff(D_MV), true, gl, gb4);
+      spd_solve<G>(m.nchol, Ho, nv, dofoff(D_SEARCH), dofoff(D_MV), gl, gb4);
     } else {
       if (gl < nv) dof(D_MV, gl) = dof(D_QACC, gl);
       WSYNC();
