@@ -33,7 +33,7 @@ static int fail(int code, const char *fmt, ...) {
 
 struct amx_model {
   DevModel dev;
-  int device;
+  int device, ncu;
   float *d_image;
   int ncon, nefc, lds_bytes;
 };
@@ -293,18 +293,29 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
   // ---- environment slab plan (floats)
   int off = 0;
   auto take = [&](int n) { int o = off; off += (n > 0 ? n : 1); return o; };
-  m.e_qpos = take(nq); m.e_qvel = take(nv); m.e_ctrl = take(nu); m.e_warm = take(nv);
-  m.e_body = take(BODY_E * nb); m.e_jnt = take(JNT_E * nj); m.e_dof = take(DOF_E * nv);
+  m.e_qpos = take(nq); m.e_qvel = take(nv); m.e_ctrl = take(nu);
+  m.e_body = take(BODY_E * nb); m.e_dof = take(DOF_E * nv);
   m.e_com = take(3 * m.nroot); m.e_actf = take(nu);
   const int ntri = nv * (nv + 1) / 2;
-  m.e_M = take(ntri); m.e_H = take(ntri); m.e_Lb = d->solver == 1 ? take(ntri) : m.e_H;
-  m.e_row = take(ROW_E * m.nefc); m.e_J = take(4 * m.ncon * m.ldc);
-  m.e_con = take(CON_E * m.ncon); m.e_frame = take(9 * np); m.e_geom = take(GEO_E * m.ngc);
+  // joint anchors/axes (kinematics -> cdof) are dead before H is first written: they share its space
+  m.e_M = take(ntri); m.e_H = take(std::max(ntri, JNT_E * nj)); m.e_jnt = m.e_H; m.e_Lb = d->solver == 1 ? take(ntri) : m.e_H;
+  m.e_row = take(ROW_E * m.nefc);
+  // collision geom poses (com_pos -> collision) are dead before the contact rows are written: they share their space
+  m.e_J = take(std::max(4 * m.ncon * m.ldc, GEO_E * m.ngc)); m.e_geom = m.e_J;
+  m.e_con = take(CON_E * m.ncon); m.e_frame = take(9 * np);
 #ifdef AMX_PROFILE
   m.e_prof = take(24);
 #endif
   m.env_floats = off;
-  const int envs_per_block = AMX_WAVES_PER_BLOCK * (AMX_WAVE / m.G);
+  // waves per workgroup: each workgroup carries one copy of the constants, so pick the size that keeps the most
+  // waves resident per CU (160 KiB of LDS, at most AMX_MIN_WAVES_PER_SIMD*4 waves by registers); ties go to the larger
+  int best_w = 0;  // largest workgroup (in waves) whose LDS fits; each launch picks 1..best_w (choose_wpb)
+  for (int w = 1; w <= AMX_WAVES_PER_BLOCK; w++)
+    if ((m.nconst + w * (AMX_WAVE / m.G) * m.env_floats) * (int)sizeof(float) <= 160 * 1024) best_w = w;
+  if (best_w == 0)
+    return fail(AMX_ECAPACITY, "model needs %d bytes of LDS for one wave (limit 163840)", (m.nconst + (AMX_WAVE / m.G) * m.env_floats) * 4);
+  m.wpb = best_w;
+  const int envs_per_block = m.wpb * (AMX_WAVE / m.G);
   const int lds_bytes = (m.nconst + envs_per_block * m.env_floats) * (int)sizeof(float);
   if (lds_bytes > 160 * 1024)
     return fail(AMX_ECAPACITY, "model needs %d bytes of LDS per workgroup (%d constants + %d x %d per environment; limit 163840)",
@@ -312,6 +323,7 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
 
   amx_model *h = new (std::nothrow) amx_model();
   if (!h) return fail(AMX_ENOMEM, "out of host memory");
+  h->ncu = 0;
   h->device = device; h->ncon = m.ncon; h->nefc = m.nefc; h->lds_bytes = lds_bytes; h->d_image = nullptr;
   hipError_t e;
   if ((e = hipSetDevice(device)) != hipSuccess || (e = hipMalloc((void **)&h->d_image, im.v.size() * sizeof(float))) != hipSuccess ||
@@ -323,6 +335,7 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
   }
   m.image = h->d_image;
   h->dev = m;
+  { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) h->ncu = n; }
   *out = h;
   return AMX_OK;
 }
@@ -346,23 +359,45 @@ extern "C" int amx_model_query(const amx_model *m, const char *name, int *out) {
   else if (n == "nefc_max") *out = m->nefc;
   else if (n == "lds_bytes") *out = m->lds_bytes;
   else if (n == "lanes_per_env") *out = m->dev.G;
-  else if (n == "envs_per_block") *out = AMX_WAVES_PER_BLOCK * (AMX_WAVE / m->dev.G);
+  else if (n == "envs_per_block") *out = m->dev.wpb * (AMX_WAVE / m->dev.G);
+  else if (n == "env_slab_bytes") *out = m->dev.env_floats * 4;
+  else if (n == "const_bytes") *out = m->dev.nconst * 4;
   else return fail(AMX_EINVAL, "unknown query '%s'", name);
   return AMX_OK;
 }
 
-static int pre_launch(const amx_model *m, int nenv, dim3 *grid) {
+// Waves per workgroup for this launch.  Every workgroup carries one copy of the constants, so fewer, larger
+// workgroups keep more environments resident per CU; but a batch that does not fill a whole number of residency
+// rounds leaves the last round partly empty.  Pick the size with the best fill of its rounds, then the most resident waves.
+static int choose_wpb(const amx_model *m, int nenv) {
+  if (const char *force = getenv("AMX_FORCE_WPB")) { int w = atoi(force); if (w >= 1 && w <= m->dev.wpb) return w; }
+  const int epw = AMX_WAVE / m->dev.G, nwaves = (nenv + epw - 1) / epw, ncu = m->ncu > 0 ? m->ncu : 256;
+  int best = 1; double best_fill = -1; int best_res = 0;
+  for (int w = 1; w <= m->dev.wpb; w++) {
+    const int bytes = (m->dev.nconst + w * epw * m->dev.env_floats) * (int)sizeof(float);
+    const int per_cu = std::min((160 * 1024 / bytes) * w, AMX_MIN_WAVES_PER_SIMD * 4);
+    if (per_cu < w) continue;
+    const long res = (long)(per_cu / w) * w * ncu;
+    const long rounds = (nwaves + res - 1) / res;
+    const double fill = (double)nwaves / (double)(rounds * res);
+    if (fill > best_fill + 1e-9 || (fill > best_fill - 1e-9 && per_cu >= best_res)) { best_fill = fill; best = w; best_res = per_cu; }
+  }
+  return best;
+}
+static int pre_launch(const amx_model *m, int nenv, dim3 *grid, int *wpb, int *lds_bytes) {
   HIP_TRY(hipSetDevice(m->device));
-  const int per_block = AMX_WAVES_PER_BLOCK * (AMX_WAVE / m->dev.G);
+  *wpb = choose_wpb(m, nenv);
+  const int per_block = *wpb * (AMX_WAVE / m->dev.G);
+  *lds_bytes = (m->dev.nconst + per_block * m->dev.env_floats) * (int)sizeof(float);
   *grid = dim3((nenv + per_block - 1) / per_block);
   return AMX_OK;
 }
 // one instantiation per group width; the model picks its own at creation
 #define AMX_LAUNCH_G(kernel, m, grid, stream, ...)                                                                       \
   do {                                                                                                                   \
-    if ((m)->dev.G == 16) hipLaunchKernelGGL(kernel<16>, grid, dim3(AMX_BLOCK), (m)->lds_bytes, (hipStream_t)stream, __VA_ARGS__);      \
-    else if ((m)->dev.G == 32) hipLaunchKernelGGL(kernel<32>, grid, dim3(AMX_BLOCK), (m)->lds_bytes, (hipStream_t)stream, __VA_ARGS__); \
-    else hipLaunchKernelGGL(kernel<64>, grid, dim3(AMX_BLOCK), (m)->lds_bytes, (hipStream_t)stream, __VA_ARGS__);                       \
+    if ((m)->dev.G == 16) hipLaunchKernelGGL(kernel<16>, grid, dim3(AMX_WAVE * wpb), lds_bytes, (hipStream_t)stream, __VA_ARGS__);      \
+    else if ((m)->dev.G == 32) hipLaunchKernelGGL(kernel<32>, grid, dim3(AMX_WAVE * wpb), lds_bytes, (hipStream_t)stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kernel<64>, grid, dim3(AMX_WAVE * wpb), lds_bytes, (hipStream_t)stream, __VA_ARGS__);                       \
   } while (0)
 
 extern "C" int amx_forward(const amx_model *m, int nenv, const float *qpos, const float *qvel, const float *ctrl,
@@ -377,7 +412,8 @@ extern "C" int amx_forward(const amx_model *m, int nenv, const float *qpos, cons
     fo.cdist = o->contact_dist_dev; fo.nefc = o->nefc_dev;
   }
   dim3 grid;
-  if (int rc = pre_launch(m, nenv, &grid)) return rc;
+  int wpb, lds_bytes;
+  if (int rc = pre_launch(m, nenv, &grid, &wpb, &lds_bytes)) return rc;
   AMX_LAUNCH_G(amx_forward_kernel, m, grid, stream, m->dev, nenv, qpos, qvel, ctrl, warm, fo);
   HIP_TRY(hipGetLastError());
   return AMX_OK;
@@ -388,7 +424,8 @@ extern "C" int amx_step(const amx_model *m, int nenv, int nsub, float *qpos, flo
   if (!m || !qpos || !qvel || (m->dev.nu > 0 && !ctrl) || nenv < 0 || nsub < 0) return fail(AMX_EINVAL, "amx_step: bad argument");
   if (nenv == 0) return AMX_OK;
   dim3 grid;
-  if (int rc = pre_launch(m, nenv, &grid)) return rc;
+  int wpb, lds_bytes;
+  if (int rc = pre_launch(m, nenv, &grid, &wpb, &lds_bytes)) return rc;
   AMX_LAUNCH_G(amx_step_kernel, m, grid, stream, m->dev, nenv, nsub, qpos, qvel, ctrl, warm, time);
   HIP_TRY(hipGetLastError());
   return AMX_OK;
@@ -405,7 +442,8 @@ extern "C" int amx_rollout(const amx_model *m, int nenv, int nsteps, const float
   if (!m || !x0 || nenv < 0 || nsteps < 0 || (nsteps > 0 && m->dev.nu > 0 && !us)) return fail(AMX_EINVAL, "amx_rollout: bad argument");
   if (nenv == 0) return AMX_OK;
   dim3 grid;
-  if (int rc = pre_launch(m, nenv, &grid)) return rc;
+  int wpb, lds_bytes;
+  if (int rc = pre_launch(m, nenv, &grid, &wpb, &lds_bytes)) return rc;
   float *prof = nullptr;
 #ifdef AMX_PROFILE
   prof = g_prof;

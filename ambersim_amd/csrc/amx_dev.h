@@ -14,7 +14,7 @@
 
 // Record strides (floats) of the constant image.  All odd, so lane-per-record LDS reads are conflict free.
 // Record strides (floats) of the per-environment slab, also odd.
-enum { BODY_E = 35, JNT_E = 7, DOF_E = 17, ROW_E = 3, CON_E = 5, GEO_E = 13 };
+enum { BODY_E = 29, JNT_E = 7, DOF_E = 17, ROW_E = 3, CON_E = 5, GEO_E = 13 };
 enum { BODY_S = 25, JNT_S = 13, DOF_S = 9, ACT_S = 13, GEOM_S = 13, PAIR_S = 29, LIM_S = 15, EQ_S = 21 };
 // BodyRec: 0 parent 1 level 2 rootslot 3 jntadr 4 jntnum 5 childadr 6 childnum 7-9 pos 10-13 quat 14-16 ipos 17-20 iquat 21 mass 22-24 inertia
 // JntRec : 0 type 1 qadr 2 dadr 3 body 4-6 pos 7-9 axis 10 qpos0 11 stiffness 12 springref
@@ -32,17 +32,18 @@ struct DevModel {
   int nconst;
   int nq, nv, nu, nb, njnt, ngc, npair, ncon, neq, nlim, nefc, nlevel, nM, nroot, ldc /*contact-row stride: longest pair dof list, odd*/, nchol, njac, nhent;
   int iterations, ls_iterations, solver, disableflags;
-  int G;  // lanes per environment: 16, 32 or 64
+  int G;    // lanes per environment: 16, 32 or 64
+  int wpb;  // wavefronts per workgroup (1..AMX_WAVES_PER_BLOCK), chosen to maximise resident waves per CU
   float dt, gx, gy, gz, tolerance, ls_tolerance, impratio, scale /* meaninertia*max(1,nv) */;
   // bases inside the constant image (float offsets)
   int c_body, c_jnt, c_dof, c_act, c_geom, c_pair, c_lim, c_eq;
   int c_qpos0 /*[nq]*/, c_child, c_M /*packed i|j<<8*/, c_dofact, c_pairdof /*packed dof|sign<<8*/, c_jac /*packed contact|slot<<8|pairdof index<<16*/,
       c_hent /*packed i|j<<5|slot_i<<10|slot_j<<15|pair<<20*/, c_dofmemadr /*[nv+1]*/, c_dofmem /*packed pair|slot<<8*/, c_conpair /*[ncon]*/, c_vert, c_rootbody;
   // bases inside one environment slab (float offsets from the slab start)
-  int e_qpos, e_qvel, e_ctrl, e_warm;
-  int e_body /* records [nb][BODY_E]: xpos 0-2 xquat 3-6 cinert 7-16 crb 17-26 (then cvel 17-22 cacc 23-28) cfrc 29-34 */;
+  int e_qpos, e_qvel, e_ctrl;
+  int e_body /* records [nb][BODY_E]: xpos 0-2 xquat 3-6 cinert 7-16 (then cfrc 7-12) crb 17-26 (then cvel 17-22 cacc 23-28) */;
   int e_jnt  /* records [njnt][JNT_E]: xanchor 0-2 xaxis 3-5 */;
-  int e_dof  /* records [nv][DOF_E]: cdof 0-5 fcrb 6-11 (then Ma grad Mgrad search mv fcon) fsmooth 12 asmooth 13 qacc 14 tmp 15 fbias 16 */;
+  int e_dof  /* records [nv][DOF_E]: cdof 0-5 fcrb 6-11 (then Ma grad Mgrad search mv fcon) fsmooth 12 asmooth 13 qacc 14 warm 15 fbias 16 */;
   int e_com, e_actf;
   int e_M, e_H, e_Lb /* packed lower-triangular nv(nv+1)/2 each; Lb only allocated for the CG solver */;
   int e_row /* records [nefc][ROW_E]: Dact 0 frow 1 */;

@@ -235,28 +235,78 @@ __device__ __noinline__ void chol_solve_rows(int A_off, int n, int L_off, int rh
 // its own column-j entry by 1/pivot and updates its row and right-hand side.  No substitutions, no LDS
 // traffic besides the initial row load, and one cross-lane latency per pivot instead of two plus 2n
 // serial substitution steps for Cholesky.
+// Pivot-row broadcast for groups narrower than a wave uses BOTH cross-lane paths, because each is a separate pipe:
+// the LDS crossbar (ds_bpermute: one instruction serves every group of the wave, but the crossbar is shared by the
+// whole CU - 38 cycles per op with 8 waves/CU) and v_readlane under the group's exec mask (VALU, per SIMD, one pass per
+// group).  The columns of a pivot row are split between the two; profiles/r01_microbench_primitives.txt has the rates.
+// Measured on the quadruped (G = 32, 4096 envs): all crossbar 57.0 M env-steps/s, 3/4 54.0, 1/2 54.0, 1/4 53.3, all
+// readlane 52.7 - so the default sends the whole row through the crossbar; the split stays as a build-time knob.
+#ifndef AMX_XBAR_NUM
+#define AMX_XBAR_NUM 1  // AMX_XBAR_NUM/AMX_XBAR_DEN of each pivot row goes through the crossbar
+#define AMX_XBAR_DEN 1
+#endif
+template <int N, int OFF, int J> DEV void gj_readlane_cols(float (&a)[N], float f, int k_begin) {
+#pragma unroll
+  for (int k0 = J + 1; k0 < N; k0 += 8) {
+    float u[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i] = readlane_f(a[k0 + i < N ? k0 + i : N - 1], J + OFF);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) if (k0 + i < N && k0 + i >= k_begin) a[k0 + i] = __builtin_fmaf(-f, u[i], a[k0 + i]);
+  }
+}
+template <int N, int G, int J> DEV void gj_pivot(float (&a)[N], float &b, int gl, int gb4) {
+  // columns [J+1, ksplit) through the crossbar, [ksplit, N) by masked readlane (all of them when G == 64)
+  constexpr int ksplit = G == 64 ? J + 1 : J + 1 + ((N - J - 1) * AMX_XBAR_NUM) / AMX_XBAR_DEN;
+  float u[N];
+  const float piv = gbcast<G>(a[J], J, gb4);
+  const float bj = gbcast<G>(b, J, gb4);
+#pragma unroll
+  for (int k = J + 1; k < ksplit; ++k) u[k] = gbcast<G>(a[k], J, gb4);
+  float f = a[J] * __builtin_amdgcn_rcpf(fmaxf(piv, MINVAL));
+  f = gl == J ? 0.0f : f;  // the pivot row itself is left alone
+  b = __builtin_fmaf(-f, bj, b);
+  if (ksplit < N) {
+    if (G == 64) {
+#pragma unroll
+      for (int k = ksplit; k < N; ++k) a[k] = __builtin_fmaf(-f, readlane_f(a[k], J), a[k]);
+    } else if (G == 32) {
+      if (gb4 == 0) {
+#pragma unroll
+        for (int k = ksplit; k < N; ++k) a[k] = __builtin_fmaf(-f, readlane_f(a[k], J), a[k]);
+      } else {
+#pragma unroll
+        for (int k = ksplit; k < N; ++k) a[k] = __builtin_fmaf(-f, readlane_f(a[k], J + 32), a[k]);
+      }
+    } else {
+#pragma unroll
+      for (int k = ksplit; k < N; ++k) a[k] = __builtin_fmaf(-f, gbcast<G>(a[k], J, gb4), a[k]);
+    }
+  }
+#pragma unroll
+  for (int k = J + 1; k < ksplit; ++k) a[k] = __builtin_fmaf(-f, u[k], a[k]);
+}
+template <int N, int G, int J> struct GJ {
+  static DEV void run(float (&a)[N], float &b, int gl, int gb4) {
+    gj_pivot<N, G, J>(a, b, gl, gb4);
+    GJ<N, G, J + 1>::run(a, b, gl, gb4);
+  }
+};
+template <int N, int G> struct GJ<N, G, N> { static DEV void run(float (&)[N], float &, int, int) {} };
+
 template <int N, int G>
 __device__ __noinline__ void spd_solve_rows(int A_off, int n, int rhs_off, int x_off, int vstride, int gl, int gb4) {
   float a[N];
-  const int li = gl < n ? gl : 0, row = TRI(li);
+  const int li = gl < n ? gl : 0, row = A_off + TRI(li), last = A_off + TRI(n) - 1;
 #pragma unroll
-  for (int k = 0; k < N; ++k) {  // full symmetric row from packed lower-triangular storage
-    const int kk = k < n ? k : 0;
-    const float v = lds[A_off + (kk <= li ? row + kk : TRI(kk) + li)];
+  for (int k = 0; k < N; ++k) {  // full symmetric row from packed lower-triangular storage (branch-free addresses)
+    const int addr = k <= li ? row + k : A_off + TRI(k) + li;
+    const float v = lds[addr < last ? addr : last];
     a[k] = (gl < n && k < n) ? v : (k == gl ? 1.0f : 0.0f);
   }
   float b = lds[rhs_off + li * vstride];
   b = gl < n ? b : 0.0f;
-#pragma unroll
-  for (int j = 0; j < N; ++j) {
-    const float piv = fmaxf(gbcast<G>(a[j], j, gb4), MINVAL);
-    const float bj = gbcast<G>(b, j, gb4);
-    float f = a[j] * __builtin_amdgcn_rcpf(piv);
-    f = gl == j ? 0.0f : f;  // the pivot row itself is left alone
-    b = __builtin_fmaf(-f, bj, b);
-#pragma unroll
-    for (int k = j + 1; k < N; ++k) a[k] = __builtin_fmaf(-f, gbcast<G>(a[k], j, gb4), a[k]);
-  }
+  GJ<N, G, 0>::run(a, b, gl, gb4);
   // the matrix is now diagonal: x_i = b_i / a_ii.  a[gl] is a runtime register index, so select it.
   float d = 1.0f;
 #pragma unroll
@@ -369,10 +419,11 @@ struct Env {
     for (int k = 0; k < 6; ++k) dof(f0 + k, i) = v.v[k];
   }
   // crb (10) is dead once M is built; cvel + cacc (12) reuse its space
-  enum { F_XPOS = 0, F_XQUAT = 3, F_CINERT = 7, F_CRB = 17, F_CVEL = 17, F_CACC = 23, F_CFRC = 29 };
+  // and cfrc (6) overwrites the body's own cinert once its local force has been formed from it
+  enum { F_XPOS = 0, F_XQUAT = 3, F_CINERT = 7, F_CFRC = 7, F_CRB = 17, F_CVEL = 17, F_CACC = 23 };
   // crb*cdof (6) is dead once M is built; the six solver vectors reuse its space
   enum { D_CDOF = 0, D_FCRB = 6, D_MA = 6, D_GRAD = 7, D_MGRAD = 8, D_SEARCH = 9, D_MV = 10, D_FCON = 11,
-         D_FSMOOTH = 12, D_ASMOOTH = 13, D_QACC = 14, D_TMP = 15, D_FBIAS = 16 };
+         D_FSMOOTH = 12, D_ASMOOTH = 13, D_QACC = 14, D_WARM = 15, D_FBIAS = 16 };
   DEV int dofoff(int f) const { return eb + m.e_dof + f; }  // element i of dof field f lives at dofoff(f) + i*DOF_E
 
   // ------------------------------------------------------------------ A9.1 kinematics
@@ -1034,13 +1085,10 @@ struct Env {
     const int nv = m.nv;
     float gauss, cost, prev_cost;
     bool use_warm = false;
-    // the warm start lives in slab field e_warm; copy it into a dof field so the helpers can address it
-    if (gl < nv) dof(D_TMP, gl) = lds[eb + m.e_warm + gl];
-    WSYNC();
     float ma_warm = 0, ja_warm = 0;
     if (!(m.disableflags & DIS_WARMSTART)) {
-      init_context(D_TMP);
-      const float cw = constraint_cost(D_TMP, &gauss);
+      init_context(D_WARM);
+      const float cw = constraint_cost(D_WARM, &gauss);
       ma_warm = gl < nv ? dof(D_MA, gl) : 0.0f;
       ja_warm = rJaref;
       WSYNC();
@@ -1049,7 +1097,7 @@ struct Env {
       use_warm = cw < cs;
     }
     if (gl < nv) {
-      dof(D_QACC, gl) = use_warm ? dof(D_TMP, gl) : dof(D_ASMOOTH, gl);
+      dof(D_QACC, gl) = use_warm ? dof(D_WARM, gl) : dof(D_ASMOOTH, gl);
       if (use_warm) dof(D_MA, gl) = ma_warm;  // context of the chosen start: M*qacc and J*qacc - aref
     }
     if (use_warm) rJaref = ja_warm;
@@ -1080,7 +1128,7 @@ struct Env {
       PROF(13);
       float pg = 0;  // CG: keep grad.Mgrad of the previous iterate
       if (m.solver != 2) {
-        if (gl < nv) { pg = dof(D_GRAD, gl) * dof(D_MGRAD, gl); dof(D_TMP, gl) = dof(D_MGRAD, gl); }
+        if (gl < nv) { pg = dof(D_GRAD, gl) * dof(D_MGRAD, gl); lds[eb + m.e_H + gl] = dof(D_MGRAD, gl); }  // CG scratch: the H buffer is idle
         pg = gsum<G>(pg);
       }
       // a finished group's state is frozen, so recomputing its cost / force / gradient below is idempotent
@@ -1100,7 +1148,7 @@ struct Env {
         }
       } else {
         chol_solve<G>(m.nchol, eb + m.e_M, nv, eb + m.e_Lb, dofoff(D_GRAD), dofoff(D_MGRAD), false, gl, gb4);
-        float num = gl < nv ? dof(D_GRAD, gl) * (dof(D_MGRAD, gl) - dof(D_TMP, gl)) : 0.0f;
+        float num = gl < nv ? dof(D_GRAD, gl) * (dof(D_MGRAD, gl) - lds[eb + m.e_H + gl]) : 0.0f;
         num = gsum<G>(num);
         const float beta = fmaxf(0.0f, num / fmaxf(MINVAL, pg));
         if (alive && gl < nv) dof(D_SEARCH, gl) = -dof(D_MGRAD, gl) + beta * dof(D_SEARCH, gl);
@@ -1138,7 +1186,7 @@ struct Env {
       return;
     }
     solve();
-    if (gl < nv) lds[eb + m.e_warm + gl] = dof(D_QACC, gl);
+    if (gl < nv) dof(D_WARM, gl) = dof(D_QACC, gl);
     WSYNC();
     PROF(15);
   }
@@ -1187,16 +1235,17 @@ struct Env {
 // Kernels: AMX_WAVES_PER_BLOCK wavefronts per workgroup, 64/G environments per wavefront.  One kernel per
 // entry point of the C ABI so each carries only its own arguments in SGPRs.
 // =====================================================================================================
-#define AMX_BLOCK (AMX_WAVE * AMX_WAVES_PER_BLOCK)
+#define AMX_BLOCK (AMX_WAVE * AMX_WAVES_PER_BLOCK)  // largest workgroup; the host launches 1..AMX_WAVES_PER_BLOCK waves per workgroup
 #define AMX_KERNEL_PROLOGUE()                                                                               \
   const int lane = threadIdx.x & (AMX_WAVE - 1), wave = threadIdx.x / AMX_WAVE;                              \
   const int gl = lane & (G - 1), grp = lane / G, gb4 = 4 * (lane & ~(G - 1));                                \
   const int slot = wave * (AMX_WAVE / G) + grp; /* environment slot inside the workgroup */                 \
-  const int e = blockIdx.x * (AMX_WAVES_PER_BLOCK * (AMX_WAVE / G)) + slot;                                  \
+  const int wpb = blockDim.x / AMX_WAVE; /* waves in this workgroup, chosen by the host to fill the CU's LDS */ \
+  const int e = blockIdx.x * (wpb * (AMX_WAVE / G)) + slot;                                  \
   /* stage the model constants once per workgroup (coalesced, shared by its waves) */                       \
-  for (int i = threadIdx.x; i < m.nconst; i += AMX_BLOCK) lds[i] = m.image[i];                               \
+  for (int i = threadIdx.x; i < m.nconst; i += blockDim.x) lds[i] = m.image[i];                               \
   __syncthreads(); /* the only workgroup barrier; the waves are independent from here on */                 \
-  if (blockIdx.x * (AMX_WAVES_PER_BLOCK * (AMX_WAVE / G)) + wave * (AMX_WAVE / G) >= nenv) return; /* whole wave idle */ \
+  if (blockIdx.x * (wpb * (AMX_WAVE / G)) + wave * (AMX_WAVE / G) >= nenv) return; /* whole wave idle */ \
   const bool live = e < nenv; /* a trailing group without an environment still runs, on a zero slab, and never touches HBM */ \
   const int eb = m.nconst + slot * m.env_floats;                                                             \
   const int nq = m.nq, nv = m.nv, nu = m.nu, nx = nq + nv;                                                   \
@@ -1267,7 +1316,7 @@ amx_step_kernel(const DevModel m, int nenv, int nsub, float *__restrict__ qpos, 
     for (int i = gl; i < nq; i += G) lds[qp + i] = qpos[(size_t)e * nq + i];
     if (gl < nv) {
       lds[qv + gl] = qvel[(size_t)e * nv + gl];
-      lds[eb + m.e_warm + gl] = warm ? warm[(size_t)e * nv + gl] : 0.0f;
+      env.dof(Env<G>::D_WARM, gl) = warm ? warm[(size_t)e * nv + gl] : 0.0f;
     }
     for (int i = gl; i < nu; i += G) lds[eb + m.e_ctrl + i] = ctrl[(size_t)e * nu + i];
   }
@@ -1277,7 +1326,7 @@ amx_step_kernel(const DevModel m, int nenv, int nsub, float *__restrict__ qpos, 
   for (int i = gl; i < nq; i += G) qpos[(size_t)e * nq + i] = lds[qp + i];
   if (gl < nv) {
     qvel[(size_t)e * nv + gl] = lds[qv + gl];
-    if (warm) warm[(size_t)e * nv + gl] = lds[eb + m.e_warm + gl];
+    if (warm) warm[(size_t)e * nv + gl] = env.dof(Env<G>::D_WARM, gl);
   }
   if (time && gl == 0) time[e] += m.dt * nsub;
 }
@@ -1294,7 +1343,7 @@ amx_forward_kernel(const DevModel m, int nenv, const float *__restrict__ qpos, c
     for (int i = gl; i < nq; i += G) lds[qp + i] = qpos[(size_t)e * nq + i];
     if (gl < nv) {
       lds[qv + gl] = qvel[(size_t)e * nv + gl];
-      lds[eb + m.e_warm + gl] = warm ? warm[(size_t)e * nv + gl] : 0.0f;
+      env.dof(Env<G>::D_WARM, gl) = warm ? warm[(size_t)e * nv + gl] : 0.0f;
     }
     for (int i = gl; i < nu; i += G) lds[eb + m.e_ctrl + i] = ctrl[(size_t)e * nu + i];
   }

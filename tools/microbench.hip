@@ -45,6 +45,24 @@ template <int MODE> __global__ void __launch_bounds__(64) bench(float *out, unsi
     } else if (MODE == 5) {  // 100 ds_bpermute dependent
 #pragma unroll
       for (int k = 0; k < 100; ++k) acc = __shfl(acc, (lane + k) & 63) + 1.0f;
+    } else if (MODE == 7) {  // 100 independent ds_bpermute + fma (pivot-row broadcast through the crossbar)
+#pragma unroll
+      for (int r = 0; r < 5; ++r)
+#pragma unroll
+        for (int k = 0; k < 20; ++k) a[k] = __builtin_fmaf(-acc, __int_as_float(__builtin_amdgcn_ds_bpermute(((lane & 32) + k + r) * 4, __float_as_int(a[k]))), a[k]);
+      acc += a[3];
+    } else if (MODE == 8) {  // 100 independent (2 readlane + select) + fma
+#pragma unroll
+      for (int r = 0; r < 5; ++r)
+#pragma unroll
+        for (int k = 0; k < 20; ++k) { float lo = readlane_f(a[k], k + r), hi = readlane_f(a[k], k + r + 32); a[k] = __builtin_fmaf(-acc, (lane & 32) ? hi : lo, a[k]); }
+      acc += a[3];
+    } else if (MODE == 9) {  // 100 independent ds_swizzle + add
+#pragma unroll
+      for (int r = 0; r < 5; ++r)
+#pragma unroll
+        for (int k = 0; k < 20; ++k) a[k] += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(a[k]), 0x401F));
+      acc += a[3];
     } else if (MODE == 6) {  // 20 x (readlane pivot -> rsq -> mul) dependent chain, the Cholesky pivot path
 #pragma unroll
       for (int k = 0; k < 20; ++k) {
@@ -76,7 +94,7 @@ template <int MODE> void run(const char *name, int per_iter, int blocks_per_cu) 
   hipFree(out); hipFree(cyc);
 }
 int main() {
-  for (int w : {1, 4, 8, 12}) {
+  for (int w : {1, 8, 16}) {
     run<0>("dependent v_fma chain", 100, w);
     run<1>("independent readlane+fma pairs", 100, w);
     run<2>("wave_sum (4 dpp + 4 readlane + 3 add)", 10, w);
@@ -84,6 +102,9 @@ int main() {
     run<4>("independent LDS read + add", 100, w);
     run<5>("dependent ds_bpermute (__shfl)", 100, w);
     run<6>("chol pivot chain (readlane,rsq,NR,mul,update)", 20, w);
+    run<7>("independent ds_bpermute + fma", 100, w);
+    run<8>("independent 2x readlane + select + fma", 100, w);
+    run<9>("independent ds_swizzle + add", 100, w);
   }
   return 0;
 }

@@ -24,4 +24,6 @@ for path, nenv, N in (("models/quadruped/quadruped.xml", 4096, 200), ("models/bi
     t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
     t0.record(); xs = mjx.rollout(model, x0, us); t1.record(); torch.cuda.synchronize()
     ms = t0.elapsed_time(t1)
-    print(f"  {path.split('/')[-1]:14s} {nenv}x{N}: {ms:.2f} ms -> {nenv*N/ms*1e3/1e6:.2f} M env-steps/s  finite={bool(torch.isfinite(xs).all())} lds={model._h.query('lds_bytes')}")
+    q = model._h.query
+    print(f"  {path.split('/')[-1]:14s} {nenv}x{N}: {ms:.2f} ms -> {nenv*N/ms*1e3/1e6:.2f} M env-steps/s  finite={bool(torch.isfinite(xs).all())} "
+          f"lds={q('lds_bytes')} slab={q('env_slab_bytes')} const={q('const_bytes')} envs/block={q('envs_per_block')} G={q('lanes_per_env')}")
