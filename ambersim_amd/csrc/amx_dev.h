@@ -8,7 +8,7 @@
 #define AMX_WAVES_PER_BLOCK 4  // wavefronts per workgroup; they share one LDS copy of the model constants
 #endif
 #ifndef AMX_MIN_WAVES_PER_SIMD
-#define AMX_MIN_WAVES_PER_SIMD 3  // launch bound: caps VGPRs at 168; measured best of 2/3/4 on the quadruped and biped rollouts
+#define AMX_MIN_WAVES_PER_SIMD 2  // launch bound: 256 VGPRs.  4096 envs give at most 2 waves/SIMD at G=32 and LDS allows no more at G=64, and 168/128 spill
 #endif
 #define AMX_MAX_NV 32           // register-row Cholesky capacity (one matrix row per lane, <=32 columns)
 
@@ -38,7 +38,7 @@ struct DevModel {
   // bases inside the constant image (float offsets)
   int c_body, c_jnt, c_dof, c_act, c_geom, c_pair, c_lim, c_eq;
   int c_qpos0 /*[nq]*/, c_child, c_M /*packed i|j<<8*/, c_dofact, c_pairdof /*packed dof|sign<<8*/, c_jac /*packed contact|slot<<8|pairdof index<<16*/,
-      c_hent /*packed i|j<<5|slot_i<<10|slot_j<<15|pair<<20*/, c_dofmemadr /*[nv+1]*/, c_dofmem /*packed pair|slot<<8*/, c_conpair /*[ncon]*/, c_vert, c_rootbody;
+      c_hent /*[nhent] packed H entry index|member count<<16*/, c_hentadr /*[nhent]*/, c_hmem /*packed first contact row|rows<<8|slot_i<<16|slot_j<<24*/, c_dofmemadr /*[nv+1]*/, c_dofmem /*packed first contact row|rows<<8|slot<<16*/, c_conpair /*[ncon]*/, c_vert, c_rootbody;
   // bases inside one environment slab (float offsets from the slab start)
   int e_qpos, e_qvel, e_ctrl;
   int e_body /* records [nb][BODY_E]: xpos 0-2 xquat 3-6 cinert 7-16 (then cfrc 7-12) crb 17-26 (then cvel 17-22 cacc 23-28) */;

@@ -379,6 +379,7 @@ struct Env {
   int d_body, d_jnt, d_kind, d_axis, d_root;                                  // dof `lane`
   // per-row solver state of row `lane`
   float rD, rAref, rJaref, rJv;
+  int rchain[4], rdn, rcr;  // contact row `gl`: its pair's dof list (<=16 dofs, one byte each), its length, its contact-row index
   float rJ1, rJ2;  // equality / limit row `gl`: Jacobian entries on dofs rd1, rd2 (contact rows live in LDS, chain-compressed)
   int rd1, rd2;
   PROF_DECL
@@ -394,6 +395,22 @@ struct Env {
     rd1 = 0; rd2 = -1;
     if (lane < m.neq) { const int er = m.c_eq + lane * EQ_S; rd1 = CI(er + 1); rd2 = CI(er + 3); }
     else if (lane < m.neq + m.nlim) rd1 = CI(m.c_lim + (lane - m.neq) * LIM_S + 1);
+    rchain[0] = rchain[1] = rchain[2] = rchain[3] = 0; rdn = 0; rcr = 0;
+    if (lane >= m.neq + m.nlim && lane < m.nefc) {
+      rcr = lane - m.neq - m.nlim;
+      const int prec = m.c_pair + CI(m.c_conpair + (rcr >> 2)) * PAIR_S, d0 = CI(prec + 9);
+      rdn = CI(prec + 10);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {  // static register indices only (a runtime-indexed array would live in scratch)
+        int pk = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int t = 4 * w + q;
+          if (t < rdn) pk |= (CI(m.c_pairdof + d0 + t) & 255) << (8 * q);
+        }
+        rchain[w] = pk;
+      }
+    }
   }
 
   // SoA accessors of the environment slab
@@ -895,9 +912,15 @@ struct Env {
         const float mu = CF(prec + 11), tw = CF(prec + 22);
         const float f = (k & 1) ? -mu : mu;
         invw = (tw + f * f * tw) * 2 * f * f / m.impratio;
-        const int d0 = CI(prec + 9), dn = CI(prec + 10);
-#pragma unroll 4
-        for (int t = 0; t < dn; ++t) jv += lds[Jo + cr * ldc + t] * lds[qv + (CI(m.c_pairdof + d0 + t) & 255)];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const int pk = rchain[w];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int t = 4 * w + q;
+            if (t < rdn) jv += lds[Jo + cr * ldc + t] * lds[qv + ((pk >> (8 * q)) & 255)];
+          }
+        }
         rec = prec + 12;
       }
       if (active) {
@@ -913,10 +936,16 @@ struct Env {
 
   // ------------------------------------------------------------------ A9.13 solver
   DEV float mul_M_row(int vf) const {  // (M v)[gl], v = dof field vf; M packed lower-triangular
-    const int nv = m.nv, i = gl < nv ? gl : 0, Mo = eb + m.e_M, ti = Mo + TRI(i), vo = dofoff(vf);
+    const int nv = m.nv, i = gl < nv ? gl : 0, Mo = eb + m.e_M, tri_i = TRI(i), vo = dofoff(vf);
     float acc = 0;
+    int tri_j = 0;  // TRI(j), kept incrementally in a scalar register
 #pragma unroll 6
-    for (int j = 0; j < nv; ++j) acc += lds[j <= i ? ti + j : Mo + TRI(j) + i] * lds[vo + j * DOF_E];
+    for (int j = 0; j < nv; ++j) {
+      tri_j += j;
+      // M(i,j) lives at TRI(max) + min: two value selects, no branches, no multiply
+      const int thi = j <= i ? tri_i : tri_j, lo = j <= i ? j : i;
+      acc += lds[Mo + thi + lo] * lds[vo + j * DOF_E];
+    }
     return acc;
   }
   DEV float row_dot(int vf) const {  // J[gl,:] . v over the row's static support
@@ -927,11 +956,17 @@ struct Env {
       if (rd2 >= 0) a += rJ2 * lds[vo + rd2 * DOF_E];
       return a;
     }
-    const int cr = r - m.neq - m.nlim, prec = m.c_pair + CI(m.c_conpair + (cr >> 2)) * PAIR_S;
-    const int d0 = CI(prec + 9), dn = CI(prec + 10), Jr = eb + m.e_J + cr * m.ldc;
+    const int Jr = eb + m.e_J + rcr * m.ldc;
     float a = 0;
-#pragma unroll 4
-    for (int t = 0; t < dn; ++t) a += lds[Jr + t] * lds[vo + (CI(m.c_pairdof + d0 + t) & 255) * DOF_E];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {  // dof list from registers: no metadata loads on this path
+      const int pk = rchain[w];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int t = 4 * w + q;
+        if (t < rdn) a += lds[Jr + t] * lds[vo + ((pk >> (8 * q)) & 255) * DOF_E];
+      }
+    }
     return a;
   }
   // Ma = M v, Jaref = J v - aref  (v = dof field vf)
@@ -963,8 +998,7 @@ struct Env {
       float acc = 0;
       const int mem0 = CI(m.c_dofmemadr + gl), mem1 = CI(m.c_dofmemadr + gl + 1);
       for (int t = mem0; t < mem1; ++t) {
-        const int pk = CI(m.c_dofmem + t), pr = pk & 255, slot = pk >> 8, prec = m.c_pair + pr * PAIR_S;
-        const int cr0 = 4 * CI(prec + 3), nr = 4 * CI(prec + 4);
+        const int pk = CI(m.c_dofmem + t), cr0 = pk & 255, nr = (pk >> 8) & 255, slot = pk >> 16;  // resolved on the host
 #pragma unroll 4
         for (int k = 0; k < nr; ++k) acc += lds[Jo + (cr0 + k) * ldc + slot] * row(1, row0 + cr0 + k);
       }
@@ -984,6 +1018,7 @@ struct Env {
     const int nv = m.nv, Mo = eb + m.e_M, Ho = eb + m.e_H, Jo = eb + m.e_J, ldc = m.ldc;
     for (int e = gl; e < TRI(nv); e += G) lds[Ho + e] = lds[Mo + e];
     WSYNC();
+    PROF(19);
     const int row0 = m.neq + m.nlim;
     if (gl < row0) {  // equality + limit rows: a handful of entries each, from registers
       const float d = row(0, gl);
@@ -996,17 +1031,22 @@ struct Env {
         }
       }
     }
-    // contact rows: one lane per (pair, lower-triangle entry of the pair's dof block)
+    WSYNC();
+    PROF(20);
+    // contact rows: one lane per H entry that some contact pair touches; the lane sums over every pair containing
+    // both dofs and every row of those pairs, then adds to its entry - no atomics, one writer per entry
     for (int t = gl; t < m.nhent; t += G) {
-      const int pk = CI(m.c_hent + t), i = pk & 31, j = (pk >> 5) & 31, sa = (pk >> 10) & 31, sb = (pk >> 15) & 31, pr = pk >> 20;
-      const int prec = m.c_pair + pr * PAIR_S, cr0 = 4 * CI(prec + 3), nr = 4 * CI(prec + 4);
+      const int pk = CI(m.c_hent + t), ent = pk & 0xFFFF, cnt = pk >> 16, m0 = CI(m.c_hentadr + t);
       float acc = 0;
+      for (int q = 0; q < cnt; ++q) {
+        const int mk = CI(m.c_hmem + m0 + q), cr0 = mk & 255, nr = (mk >> 8) & 255, sa = (mk >> 16) & 255, sb = mk >> 24;  // resolved on the host
 #pragma unroll 4
-      for (int k = 0; k < nr; ++k) {  // rows come four per contact; inactive rows have D = 0 and finite J
-        const int Jr = Jo + (cr0 + k) * ldc;
-        acc += row(0, row0 + cr0 + k) * lds[Jr + sa] * lds[Jr + sb];
+        for (int k = 0; k < nr; ++k) {  // rows come four per contact; inactive rows have D = 0 and finite J
+          const int Jr = Jo + (cr0 + k) * ldc;
+          acc += row(0, row0 + cr0 + k) * lds[Jr + sa] * lds[Jr + sb];
+        }
       }
-      if (acc != 0.0f) atomicAdd(&lds[Ho + TRI(i) + j], acc);  // i >= j by construction
+      lds[Ho + ent] += acc;
     }
     WSYNC();
     PROF(14);
@@ -1039,6 +1079,7 @@ struct Env {
       g2 = 0.5f * si * mv;
     }
     sn = gsum<G>(sn); g1 = gsum<G>(g1); g2 = gsum<G>(g2);
+    PROF(21);
     const float gtol = m.tolerance * m.ls_tolerance * sqrtf(sn) * m.scale;
     const bool valid = gl < m.nefc, iseq = gl < m.neq;
 #define POINT(al) ls_point((al), valid, iseq, gauss, g1, g2)
@@ -1072,6 +1113,7 @@ struct Env {
     }
 #undef POINT
 #undef PICK
+    PROF(22);
     const bool improved = alive && ((lo.cost < p0.cost) || (hi.cost < p0.cost));
     const float alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
     if (improved) {
