@@ -216,30 +216,26 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
     for (int i = 0; i < nv; i++) if (sign[i]) pairdof.push_back(i | (sign[i] << 8));
     int dn = (int)pairdof.size() - d0;
     im.seti(o + 9, d0); im.seti(o + 10, dn);
-    if (dn > 16) return fail(AMX_ECAPACITY, "pair %d couples %d dofs (limit 16: the row lanes keep the dof list in registers)", p, dn);
+    if (dn > 16 || nv > 32) return fail(AMX_ECAPACITY, "pair %d couples %d dofs (limit 16: the row lanes keep the dof list in registers)", p, dn);
     maxchain = std::max(maxchain, dn);
     for (int a = 0; a < dn; a++) {
-      dofmem[pairdof[d0 + a] & 255].push_back((4 * ncon) | ((4 * PAIR_NCON[fn]) << 8) | (a << 16));
+      for (int k = 0; k < PAIR_NCON[fn]; k++) dofmem[pairdof[d0 + a] & 255].push_back((4 * (ncon + k)) | (a << 8));
       for (int b = 0; b <= a; b++) {  // dof list ascending, so (dof_a, dof_b) is a lower-triangle entry of H
         const int di = pairdof[d0 + a] & 255, dj = pairdof[d0 + b] & 255;
-        hmembers[di * (di + 1) / 2 + dj].push_back((4 * ncon) | ((4 * PAIR_NCON[fn]) << 8) | (a << 16) | (b << 24));
+        for (int k = 0; k < PAIR_NCON[fn]; k++) hmembers[di * (di + 1) / 2 + dj].push_back(((4 * (ncon + k)) << 10) | (a << 18) | (b << 23));
       }
     }
     for (int k = 0; k < PAIR_NCON[fn]; k++) {
-      for (int t = 0; t < dn; t++) jac_items.push_back((ncon + k) | (t << 8) | ((d0 + t) << 16));
+      for (int t = 0; t < dn; t++)  // contact | slot<<6 | dof<<11 | chain sign<<16 | pair<<18
+        jac_items.push_back((ncon + k) | (t << 6) | ((pairdof[d0 + t] & 255) << 11) | ((pairdof[d0 + t] >> 8) << 16) | (p << 18));
       con_pair.push_back(p);
     }
     ncon += PAIR_NCON[fn];
   }
-  std::vector<int> hentadr, hmem;
-  for (int t = 0; t < nv * (nv + 1) / 2; t++) {
-    if (hmembers[t].empty()) continue;
-    hent.push_back(t | ((int)hmembers[t].size() << 16));
-    hentadr.push_back((int)hmem.size());
-    hmem.insert(hmem.end(), hmembers[t].begin(), hmembers[t].end());
-  }
+  for (int t = 0; t < nv * (nv + 1) / 2; t++)
+    for (int w : hmembers[t]) hent.push_back(t | w);  // one term per (H entry, contact)
   m.ncon = ncon; m.njac = (int)jac_items.size(); m.nhent = (int)hent.size();
-  if (4 * ncon > 255) return fail(AMX_ECAPACITY, "%d contact slots exceed 63", ncon);
+  if (ncon > 63) return fail(AMX_ECAPACITY, "%d contact slots exceed 63", ncon);
   // limit rows, equality rows
   std::vector<int> lim_j;
   for (int j = 0; j < nj; j++) if (d->jnt_limited[j]) lim_j.push_back(j);
@@ -282,7 +278,7 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
   std::vector<int> Mlist;
   for (int i = 0; i < nv; i++) for (int j = i; j >= 0; j = d->dof_parentid[j]) Mlist.push_back(i | (j << 8));
   m.nM = (int)Mlist.size(); m.c_M = add_ints(Mlist);
-  m.c_dofact = add_ints(dofact); m.c_pairdof = add_ints(pairdof); m.c_jac = add_ints(jac_items); m.c_hent = add_ints(hent); m.c_hentadr = add_ints(hentadr); m.c_hmem = add_ints(hmem);
+  m.c_dofact = add_ints(dofact); m.c_pairdof = add_ints(pairdof); m.c_jac = add_ints(jac_items); m.c_hent = add_ints(hent);
   m.c_conpair = add_ints(con_pair); m.c_rootbody = add_ints(roots);
   {
     std::vector<int> adr(nv + 1, 0), flat;

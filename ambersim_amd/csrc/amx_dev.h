@@ -37,8 +37,8 @@ struct DevModel {
   float dt, gx, gy, gz, tolerance, ls_tolerance, impratio, scale /* meaninertia*max(1,nv) */;
   // bases inside the constant image (float offsets)
   int c_body, c_jnt, c_dof, c_act, c_geom, c_pair, c_lim, c_eq;
-  int c_qpos0 /*[nq]*/, c_child, c_M /*packed i|j<<8*/, c_dofact, c_pairdof /*packed dof|sign<<8*/, c_jac /*packed contact|slot<<8|pairdof index<<16*/,
-      c_hent /*[nhent] packed H entry index|member count<<16*/, c_hentadr /*[nhent]*/, c_hmem /*packed first contact row|rows<<8|slot_i<<16|slot_j<<24*/, c_dofmemadr /*[nv+1]*/, c_dofmem /*packed first contact row|rows<<8|slot<<16*/, c_conpair /*[ncon]*/, c_vert, c_rootbody;
+  int c_qpos0 /*[nq]*/, c_child, c_M /*packed i|j<<8*/, c_dofact, c_pairdof /*packed dof|sign<<8*/, c_jac /*packed contact|slot<<6|dof<<11|chain sign<<16|pair<<18*/,
+      c_hent /*[nhent] terms: packed H entry|first contact row<<10|slot_i<<18|slot_j<<23*/, c_dofmemadr /*[nv+1]*/, c_dofmem /*terms: packed first contact row|slot<<8*/, c_conpair /*[ncon]*/, c_vert, c_rootbody;
   // bases inside one environment slab (float offsets from the slab start)
   int e_qpos, e_qvel, e_ctrl;
   int e_body /* records [nb][BODY_E]: xpos 0-2 xquat 3-6 cinert 7-16 (then cfrc 7-12) crb 17-26 (then cvel 17-22 cacc 23-28) */;

@@ -318,17 +318,16 @@ __device__ __noinline__ void spd_solve_rows(int A_off, int n, int rhs_off, int x
 template <int G>
 __device__ __noinline__ void spd_solve(int nchol, int A_off, int n, int rhs_off, int x_off, int gl, int gb4) {
   const int vstride = DOF_E;
+  // one instantiation per even size (a pivot costs a crossbar round trip, so padding rows are not free);
+  // a group of G lanes holds at most G rows
+#define AMX_SPD_CASE(NN) else if (nchol <= NN && NN <= G) spd_solve_rows<(NN <= G ? NN : 4), G>(A_off, n, rhs_off, x_off, vstride, gl, gb4);
   if (nchol <= 4) spd_solve_rows<4, G>(A_off, n, rhs_off, x_off, vstride, gl, gb4);
-  else if (nchol <= 8) spd_solve_rows<8, G>(A_off, n, rhs_off, x_off, vstride, gl, gb4);
-  else if (nchol <= 12) spd_solve_rows<12, G>(A_off, n, rhs_off, x_off, vstride, gl, gb4);
-  else if (nchol <= 16) spd_solve_rows<(G >= 16 ? 16 : 12), G>(A_off, n, rhs_off, x_off, vstride, gl, gb4);
-  else if (nchol <= 20) spd_solve_rows<(G >= 32 ? 20 : 12), G>(A_off, n, rhs_off, x_off, vstride, gl, gb4);
-  else if (nchol <= 24) spd_solve_rows<(G >= 32 ? 24 : 12), G>(A_off, n, rhs_off, x_off, vstride, gl, gb4);
-  else if (nchol <= 28) spd_solve_rows<(G >= 32 ? 28 : 12), G>(A_off, n, rhs_off, x_off, vstride, gl, gb4);
-  else spd_solve_rows<(G >= 32 ? 32 : 12), G>(A_off, n, rhs_off, x_off, vstride, gl, gb4);
+  AMX_SPD_CASE(6) AMX_SPD_CASE(8) AMX_SPD_CASE(10) AMX_SPD_CASE(12) AMX_SPD_CASE(14) AMX_SPD_CASE(16) AMX_SPD_CASE(18)
+  AMX_SPD_CASE(20) AMX_SPD_CASE(22) AMX_SPD_CASE(24) AMX_SPD_CASE(26) AMX_SPD_CASE(28) AMX_SPD_CASE(30) AMX_SPD_CASE(32)
+#undef AMX_SPD_CASE
 }
 
-// one out-of-line dispatcher so the call sites stay small
+// one out-of-line dispatcher so the call sites stay small (CG preconditioner only)
 template <int G>
 __device__ __noinline__ void chol_solve(int nchol, int A_off, int n, int L_off, int rhs_off, int x_off, bool factor, int gl, int gb4) {
   const int vstride = DOF_E;
@@ -844,8 +843,8 @@ struct Env {
       // contact Jacobian entries: one lane per (contact, dof of the pair's ancestor chains); rows are stored
       // chain-compressed: Jc[contact row][slot], slot = position of the dof in the pair's dof list
       for (int t = gl; t < m.njac; t += G) {
-        const int pk = CI(m.c_jac + t), c = pk & 255, slot = (pk >> 8) & 255, pd = CI(m.c_pairdof + (pk >> 16)), i = pd & 255, sg = pd >> 8;
-        const int pr = CI(m.c_conpair + c), rec = m.c_pair + pr * PAIR_S;
+        const int pk = CI(m.c_jac + t), c = pk & 63, slot = (pk >> 6) & 31, i = (pk >> 11) & 31, sg = (pk >> 16) & 3, pr = pk >> 18;  // resolved on the host
+        const int rec = m.c_pair + pr * PAIR_S;
         const float mu = CF(rec + 11);
         const f3 pt = mk3(con(1, c), con(2, c), con(3, c));
         const int fo = eb + m.e_frame + pr * 9;
@@ -997,10 +996,13 @@ struct Env {
     if (gl < m.nv) {
       float acc = 0;
       const int mem0 = CI(m.c_dofmemadr + gl), mem1 = CI(m.c_dofmemadr + gl + 1);
-      for (int t = mem0; t < mem1; ++t) {
-        const int pk = CI(m.c_dofmem + t), cr0 = pk & 255, nr = (pk >> 8) & 255, slot = pk >> 16;  // resolved on the host
-#pragma unroll 4
-        for (int k = 0; k < nr; ++k) acc += lds[Jo + (cr0 + k) * ldc + slot] * row(1, row0 + cr0 + k);
+      for (int t = mem0; t < mem1; ++t) {  // one term per contact whose ancestor chain holds this dof
+        const int pk = CI(m.c_dofmem + t), cr0 = pk & 255, slot = pk >> 8;
+        const int Jr = Jo + cr0 * ldc + slot, Fr = eb + m.e_row + (row0 + cr0) * ROW_E + 1;
+        float j[4], f[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { j[k] = lds[Jr + k * ldc]; f[k] = lds[Fr + k * ROW_E]; }
+        acc += (j[0] * f[0] + j[1] * f[1]) + (j[2] * f[2] + j[3] * f[3]);
       }
       dof(D_FCON, gl) = acc;
     }
@@ -1033,20 +1035,16 @@ struct Env {
     }
     WSYNC();
     PROF(20);
-    // contact rows: one lane per H entry that some contact pair touches; the lane sums over every pair containing
-    // both dofs and every row of those pairs, then adds to its entry - no atomics, one writer per entry
+    // contact rows: one lane per term (H entry, contact): the twelve operands of the contact's four pyramid rows are
+    // fetched back to back, then reduced and added to the entry (ds_add_f32; entries are shared between contacts)
     for (int t = gl; t < m.nhent; t += G) {
-      const int pk = CI(m.c_hent + t), ent = pk & 0xFFFF, cnt = pk >> 16, m0 = CI(m.c_hentadr + t);
-      float acc = 0;
-      for (int q = 0; q < cnt; ++q) {
-        const int mk = CI(m.c_hmem + m0 + q), cr0 = mk & 255, nr = (mk >> 8) & 255, sa = (mk >> 16) & 255, sb = mk >> 24;  // resolved on the host
-#pragma unroll 4
-        for (int k = 0; k < nr; ++k) {  // rows come four per contact; inactive rows have D = 0 and finite J
-          const int Jr = Jo + (cr0 + k) * ldc;
-          acc += row(0, row0 + cr0 + k) * lds[Jr + sa] * lds[Jr + sb];
-        }
-      }
-      lds[Ho + ent] += acc;
+      const int pk = CI(m.c_hent + t), ent = pk & 1023, cr0 = (pk >> 10) & 255, sa = (pk >> 18) & 31, sb = pk >> 23;
+      const int Jr = Jo + cr0 * ldc, Dr = eb + m.e_row + (row0 + cr0) * ROW_E;
+      float d[4], ja[4], jb[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { d[k] = lds[Dr + k * ROW_E]; ja[k] = lds[Jr + k * ldc + sa]; jb[k] = lds[Jr + k * ldc + sb]; }
+      const float acc = (d[0] * ja[0] * jb[0] + d[1] * ja[1] * jb[1]) + (d[2] * ja[2] * jb[2] + d[3] * ja[3] * jb[3]);
+      if (acc != 0.0f) atomicAdd(&lds[Ho + ent], acc);
     }
     WSYNC();
     PROF(14);
