@@ -291,6 +291,7 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
   for (int k = 0; k < nq; k++) im.setf(m.c_qpos0 + k, d->qpos0[k]);
   m.c_vert = im.reserve(3 * d->nconvexvert);
   for (int k = 0; k < 3 * d->nconvexvert; k++) im.setf(m.c_vert + k, d->convex_vert[k]);
+  while (im.size() & 3) im.reserve(1);  // environment slabs start 16-byte aligned
   m.nconst = im.size();
 
   // ---- environment slab plan (floats)
@@ -301,7 +302,9 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
   m.e_com = take(3 * m.nroot); m.e_actf = take(nu);
   const int ntri = nv * (nv + 1) / 2;
   // joint anchors/axes (kinematics -> cdof) are dead before H is first written: they share its space
-  m.e_M = take(ntri); m.e_H = take(std::max(ntri, JNT_E * nj)); m.e_jnt = m.e_H; m.e_Lb = d->solver == 1 ? take(ntri) : m.e_H;
+  m.e_M = take(ntri);
+  off = (off + 3) & ~3;  // H doubles as the solver's 16-byte-aligned pivot-row scratch (spd_solve_rows)
+  m.e_H = take(std::max(std::max(ntri, JNT_E * nj), nv + 8)); m.e_jnt = m.e_H; m.e_Lb = d->solver == 1 ? take(ntri) : m.e_H;
   m.e_row = take(ROW_E * m.nefc);
   // collision geom poses (com_pos -> collision) are dead before the contact rows are written: they share their space
   m.e_J = take(std::max(4 * m.ncon * m.ldc, GEO_E * m.ngc)); m.e_geom = m.e_J;
@@ -309,7 +312,7 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
 #ifdef AMX_PROFILE
   m.e_prof = take(24);
 #endif
-  m.env_floats = off;
+  m.env_floats = (off + 3) & ~3;  // slabs keep 16-byte alignment
   // waves per workgroup: each workgroup carries one copy of the constants, so pick the size that keeps the most
   // waves resident per CU (160 KiB of LDS, at most AMX_MIN_WAVES_PER_SIMD*4 waves by registers); ties go to the larger
   int best_w = 0;  // largest workgroup (in waves) whose LDS fits; each launch picks 1..best_w (choose_wpb)

@@ -286,16 +286,60 @@ template <int N, int G, int J> DEV void gj_pivot(float (&a)[N], float &b, int gl
 #pragma unroll
   for (int k = J + 1; k < ksplit; ++k) a[k] = __builtin_fmaf(-f, u[k], a[k]);
 }
+// Pivot-row broadcast through LDS memory (groups narrower than a wave): the pivot lane of every group stores its
+// remaining row and right-hand side as 16-byte chunks into the group's scratch row, and every lane reads the chunks
+// back (same address within a group: a broadcast read).  A pivot row of n values costs ceil(n/4) ds_read_b128
+// instead of n ds_bpermute_b32 - the crossbar is shared by the whole CU and was the limiter (see profiles/).
+// LDS operations of one wave execute in order, so no barrier is needed between the store and the loads or between
+// pivots.  Chunk c holds columns 4c..4c+3; column N is the right-hand side.
+#ifndef AMX_GJ_LDS
+#define AMX_GJ_LDS 0
+#endif
+#ifndef AMX_GJ_LDS_MAXN
+#define AMX_GJ_LDS_MAXN 24
+#endif
+template <int N, int G, int J> DEV void gj_pivot_lds(float (&a)[N], float &b, int gl, int sbuf) {
+  constexpr int NC = (N + 4) / 4, C0 = J / 4;  // chunks [C0, NC) cover columns J..N
+  float4 *row = reinterpret_cast<float4 *>(lds + sbuf);
+  if (gl == J) {
+#pragma unroll
+    for (int c = C0; c < NC; ++c) {
+      float4 v;
+      v.x = 4 * c < N ? a[4 * c < N ? 4 * c : 0] : (4 * c == N ? b : 0.0f);
+      v.y = 4 * c + 1 < N ? a[4 * c + 1 < N ? 4 * c + 1 : 0] : (4 * c + 1 == N ? b : 0.0f);
+      v.z = 4 * c + 2 < N ? a[4 * c + 2 < N ? 4 * c + 2 : 0] : (4 * c + 2 == N ? b : 0.0f);
+      v.w = 4 * c + 3 < N ? a[4 * c + 3 < N ? 4 * c + 3 : 0] : (4 * c + 3 == N ? b : 0.0f);
+      row[c] = v;
+    }
+  }
+  // cross-lane hand-off: keeps the compiler from hoisting the other lanes' loads above the store
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  float u[4 * NC];
+#pragma unroll
+  for (int c = C0; c < NC; ++c) {
+    const float4 v = row[c];
+    u[4 * c] = v.x; u[4 * c + 1] = v.y; u[4 * c + 2] = v.z; u[4 * c + 3] = v.w;
+  }
+  float f = a[J] * __builtin_amdgcn_rcpf(fmaxf(u[J], MINVAL));
+  f = gl == J ? 0.0f : f;  // the pivot row itself is left alone
+  b = __builtin_fmaf(-f, u[N], b);
+#pragma unroll
+  for (int k = J + 1; k < N; ++k) a[k] = __builtin_fmaf(-f, u[k], a[k]);
+}
 template <int N, int G, int J> struct GJ {
-  static DEV void run(float (&a)[N], float &b, int gl, int gb4) {
-    gj_pivot<N, G, J>(a, b, gl, gb4);
-    GJ<N, G, J + 1>::run(a, b, gl, gb4);
+  static DEV void run(float (&a)[N], float &b, int gl, int gb4, int sbuf) {
+    if (AMX_GJ_LDS && G < 64 && N <= AMX_GJ_LDS_MAXN) gj_pivot_lds<N, G, J>(a, b, gl, sbuf);
+    else gj_pivot<N, G, J>(a, b, gl, gb4);
+    GJ<N, G, J + 1>::run(a, b, gl, gb4, sbuf);
   }
 };
-template <int N, int G> struct GJ<N, G, N> { static DEV void run(float (&)[N], float &, int, int) {} };
+template <int N, int G> struct GJ<N, G, N> { static DEV void run(float (&)[N], float &, int, int, int) {} };
 
+// `sbuf`: LDS float offset (multiple of 4) of N+4 floats of scratch private to the group; it may alias the matrix,
+// whose rows are all in registers before the first pivot stores.
 template <int N, int G>
-__device__ __noinline__ void spd_solve_rows(int A_off, int n, int rhs_off, int x_off, int vstride, int gl, int gb4) {
+__device__ __noinline__ void spd_solve_rows(int A_off, int n, int rhs_off, int x_off, int vstride, int gl, int gb4, int sbuf) {
   float a[N];
   const int li = gl < n ? gl : 0, row = A_off + TRI(li), last = A_off + TRI(n) - 1;
 #pragma unroll
@@ -306,7 +350,7 @@ __device__ __noinline__ void spd_solve_rows(int A_off, int n, int rhs_off, int x
   }
   float b = lds[rhs_off + li * vstride];
   b = gl < n ? b : 0.0f;
-  GJ<N, G, 0>::run(a, b, gl, gb4);
+  GJ<N, G, 0>::run(a, b, gl, gb4, sbuf);
   // the matrix is now diagonal: x_i = b_i / a_ii.  a[gl] is a runtime register index, so select it.
   float d = 1.0f;
 #pragma unroll
@@ -316,12 +360,12 @@ __device__ __noinline__ void spd_solve_rows(int A_off, int n, int rhs_off, int x
 }
 
 template <int G>
-__device__ __noinline__ void spd_solve(int nchol, int A_off, int n, int rhs_off, int x_off, int gl, int gb4) {
+__device__ __noinline__ void spd_solve(int nchol, int A_off, int n, int rhs_off, int x_off, int gl, int gb4, int sbuf) {
   const int vstride = DOF_E;
   // one instantiation per even size (a pivot costs a crossbar round trip, so padding rows are not free);
   // a group of G lanes holds at most G rows
-#define AMX_SPD_CASE(NN) else if (nchol <= NN && NN <= G) spd_solve_rows<(NN <= G ? NN : 4), G>(A_off, n, rhs_off, x_off, vstride, gl, gb4);
-  if (nchol <= 4) spd_solve_rows<4, G>(A_off, n, rhs_off, x_off, vstride, gl, gb4);
+#define AMX_SPD_CASE(NN) else if (nchol <= NN && NN <= G) spd_solve_rows<(NN <= G ? NN : 4), G>(A_off, n, rhs_off, x_off, vstride, gl, gb4, sbuf);
+  if (nchol <= 4) spd_solve_rows<4, G>(A_off, n, rhs_off, x_off, vstride, gl, gb4, sbuf);
   AMX_SPD_CASE(6) AMX_SPD_CASE(8) AMX_SPD_CASE(10) AMX_SPD_CASE(12) AMX_SPD_CASE(14) AMX_SPD_CASE(16) AMX_SPD_CASE(18)
   AMX_SPD_CASE(20) AMX_SPD_CASE(22) AMX_SPD_CASE(24) AMX_SPD_CASE(26) AMX_SPD_CASE(28) AMX_SPD_CASE(30) AMX_SPD_CASE(32)
 #undef AMX_SPD_CASE
@@ -1048,7 +1092,7 @@ struct Env {
     }
     WSYNC();
     PROF(14);
-    spd_solve<G>(m.nchol, Ho, nv, dofoff(D_GRAD), dofoff(D_MGRAD), gl, gb4);
+    spd_solve<G>(m.nchol, Ho, nv, dofoff(D_GRAD), dofoff(D_MGRAD), gl, gb4, Ho);
   }
 
   DEV LSPoint ls_point(float alpha, bool valid, bool iseq, float g0, float g1, float g2) const {
@@ -1217,7 +1261,7 @@ struct Env {
     PROF(7);
     // qacc_smooth = M^-1 qfrc_smooth.  Newton never reuses the factor: one-shot Gauss-Jordan solve;
     // CG keeps a Cholesky factor in Lb as its preconditioner.
-    if (m.solver == 2) spd_solve<G>(m.nchol, eb + m.e_M, nv, dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), gl, gb4);
+    if (m.solver == 2) spd_solve<G>(m.nchol, eb + m.e_M, nv, dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), gl, gb4, eb + m.e_H);
     else chol_solve<G>(m.nchol, eb + m.e_M, nv, eb + m.e_Lb, dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), true, gl, gb4);
     PROF(8);
     if (m.nefc == 0) {
@@ -1241,7 +1285,7 @@ struct Env {
       WSYNC();
       if (gl < nv) lds[Ho + TRI(gl) + gl] += m.dt * CF(m.c_dof + gl * DOF_S + 5);
       WSYNC();
-      spd_solve<G>(m.nchol, Ho, nv, dofoff(D_SEARCH), dofoff(D_MV), gl, gb4);
+      spd_solve<G>(m.nchol, Ho, nv, dofoff(D_SEARCH), dofoff(D_MV), gl, gb4, Ho);
     } else {
       if (gl < nv) dof(D_MV, gl) = dof(D_QACC, gl);
       WSYNC();
@@ -1274,9 +1318,26 @@ struct Env {
 // =====================================================================================================
 // Kernels: AMX_WAVES_PER_BLOCK wavefronts per workgroup, 64/G environments per wavefront.  One kernel per
 // entry point of the C ABI so each carries only its own arguments in SGPRs.
+// The by-value model descriptor arrives as a few s_load_dwordx16 tuples.  It does not fit the SGPR file next to the
+// exec-mask temporaries, and a spilled TUPLE is reloaded whole (16 v_readlane for one field) at every use inside the
+// hot loops.  Copying each word through its own s_mov gives the allocator independent 32-bit values: one v_readlane
+// per reload.
+DEV DevModel split_scalars(const DevModel &in) {
+  constexpr int NW = sizeof(DevModel) / 4;
+  static_assert(sizeof(DevModel) % 4 == 0, "DevModel is a sequence of 32-bit words");
+  int w[NW];
+  __builtin_memcpy(w, &in, sizeof(DevModel));
+#pragma unroll
+  for (int k = 0; k < NW; ++k) asm volatile("s_mov_b32 %0, %1" : "=s"(w[k]) : "s"(w[k]));
+  DevModel out;
+  __builtin_memcpy(&out, w, sizeof(DevModel));
+  return out;
+}
+
 // =====================================================================================================
 #define AMX_BLOCK (AMX_WAVE * AMX_WAVES_PER_BLOCK)  // largest workgroup; the host launches 1..AMX_WAVES_PER_BLOCK waves per workgroup
 #define AMX_KERNEL_PROLOGUE()                                                                               \
+  const DevModel m = split_scalars(m_in);                                                                    \
   const int lane = threadIdx.x & (AMX_WAVE - 1), wave = threadIdx.x / AMX_WAVE;                              \
   const int gl = lane & (G - 1), grp = lane / G, gb4 = 4 * (lane & ~(G - 1));                                \
   const int slot = wave * (AMX_WAVE / G) + grp; /* environment slot inside the workgroup */                 \
@@ -1299,7 +1360,7 @@ struct Env {
 // vmap(shoot): state stays in LDS for the whole horizon; HBM sees one control row in and one state row out per step.
 template <int G>
 __global__ void __launch_bounds__(AMX_BLOCK, AMX_MIN_WAVES_PER_SIMD)
-amx_rollout_kernel(const DevModel m, int nenv, int nsteps, int x0_batched, const float *__restrict__ x0g, const float *__restrict__ usg,
+amx_rollout_kernel(const DevModel m_in, int nenv, int nsteps, int x0_batched, const float *__restrict__ x0g, const float *__restrict__ usg,
                    float *__restrict__ xs, float *__restrict__ xfinal, float *__restrict__ prof) {
   AMX_KERNEL_PROLOGUE()
 #ifdef AMX_PROFILE
@@ -1349,7 +1410,7 @@ amx_rollout_kernel(const DevModel m, int nenv, int nsteps, int x0_batched, const
 // MjxEnv.pipeline_step: nsub physics steps with ctrl held; state comes from and returns to HBM.
 template <int G>
 __global__ void __launch_bounds__(AMX_BLOCK, AMX_MIN_WAVES_PER_SIMD)
-amx_step_kernel(const DevModel m, int nenv, int nsub, float *__restrict__ qpos, float *__restrict__ qvel, const float *__restrict__ ctrl,
+amx_step_kernel(const DevModel m_in, int nenv, int nsub, float *__restrict__ qpos, float *__restrict__ qvel, const float *__restrict__ ctrl,
                 float *__restrict__ warm, float *__restrict__ time) {
   AMX_KERNEL_PROLOGUE()
   if (live) {
@@ -1376,7 +1437,7 @@ struct ForwardOut { float *qacc, *qacc_smooth, *qfrc_bias, *qfrc_constraint, *qM
 // mjx.forward: derived quantities for a given state, no integration.
 template <int G>
 __global__ void __launch_bounds__(AMX_BLOCK, AMX_MIN_WAVES_PER_SIMD)
-amx_forward_kernel(const DevModel m, int nenv, const float *__restrict__ qpos, const float *__restrict__ qvel, const float *__restrict__ ctrl,
+amx_forward_kernel(const DevModel m_in, int nenv, const float *__restrict__ qpos, const float *__restrict__ qvel, const float *__restrict__ ctrl,
                    const float *__restrict__ warm, const ForwardOut o) {
   AMX_KERNEL_PROLOGUE()
   if (live) {
