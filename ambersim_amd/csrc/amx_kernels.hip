@@ -409,6 +409,30 @@ struct LSPoint { float alpha, cost, d0, d1; };
 #define PROF(id)
 #endif
 
+// Item loops (one lane per item, items t = gl, gl+G, ...): `fetch(t)` only loads and computes, `commit(t, v)` stores.
+// Two items are fetched before either commits, so the LDS round trips of consecutive items overlap instead of
+// serialising behind each item's store (the compiler cannot hoist a load above a may-alias LDS store itself).
+// Out-of-range items fetch item n-1 again (valid addresses, no exec-mask branch) and skip the commit.
+template <int G, class F, class C> DEV void item_loop2(int n, int gl, F fetch, C commit) {
+  for (int t0 = 0; t0 < n; t0 += 2 * G) {
+    const int ta = t0 + gl, tb = ta + G;
+    const auto va = fetch(ta < n ? ta : n - 1);
+    const auto vb = fetch(tb < n ? tb : n - 1);
+    if (ta < n) commit(ta, va);
+    if (tb < n) commit(tb, vb);
+  }
+}
+// lds[dst + e] = lds[src + e], e < n, four loads in flight per lane
+template <int G> DEV void lds_copy(int dst, int src, int n, int gl) {
+  for (int e0 = 0; e0 < n; e0 += 4 * G) {
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int e = e0 + k * G + gl; v[k] = lds[src + (e < n ? e : n - 1)]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int e = e0 + k * G + gl; if (e < n) lds[dst + e] = v[k]; }
+  }
+}
+
 // =====================================================================================================
 // One environment's physics, run by a group of G lanes.  `eb` is the group's slab in LDS (per-lane value,
 // equal inside a group); `gl` is the lane's index inside its group; constants live at the front of LDS.
@@ -646,15 +670,17 @@ struct Env {
     }
     WSYNC();
     const int Mo = eb + m.e_M;
-    for (int e = gl; e < m.nM; e += G) {
-      const int pk = CI(m.c_M + e), i = pk & 255, j = pk >> 8;
-      const sv f = ld_dsv(D_FCRB, i), c = ld_dsv(D_CDOF, j);
-      float v = 0;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) v += c.v[k] * f.v[k];
-      if (i == j) v += CF(m.c_dof + i * DOF_S + 4);
-      lds[Mo + TRI(i) + j] = v;  // j is an ancestor of i: j <= i
-    }
+    struct MEnt { int at; float v; };
+    item_loop2<G>(m.nM, gl,
+      [&](int e) {
+        const int pk = CI(m.c_M + e), i = pk & 255, j = pk >> 8;
+        const sv f = ld_dsv(D_FCRB, i), c = ld_dsv(D_CDOF, j);
+        const float arm = CF(m.c_dof + i * DOF_S + 4);
+        float v = (c.v[0] * f.v[0] + c.v[1] * f.v[1]) + (c.v[2] * f.v[2] + c.v[3] * f.v[3]) + (c.v[4] * f.v[4] + c.v[5] * f.v[5]);
+        if (i == j) v += arm;
+        return MEnt{Mo + TRI(i) + j, v};  // j is an ancestor of i: j <= i
+      },
+      [&](int, const MEnt &r) { lds[r.at] = r.v; });
     WSYNC();
   }
 
@@ -886,25 +912,26 @@ struct Env {
     if (con_on && !(m.disableflags & DIS_CONTACT)) {
       // contact Jacobian entries: one lane per (contact, dof of the pair's ancestor chains); rows are stored
       // chain-compressed: Jc[contact row][slot], slot = position of the dof in the pair's dof list
-      for (int t = gl; t < m.njac; t += G) {
-        const int pk = CI(m.c_jac + t), c = pk & 63, slot = (pk >> 6) & 31, i = (pk >> 11) & 31, sg = (pk >> 16) & 3, pr = pk >> 18;  // resolved on the host
-        const int rec = m.c_pair + pr * PAIR_S;
-        const float mu = CF(rec + 11);
-        const f3 pt = mk3(con(1, c), con(2, c), con(3, c));
-        const int fo = eb + m.e_frame + pr * 9;
-        const f3 fn_ = mk3(lds[fo], lds[fo + 1], lds[fo + 2]), ft1 = mk3(lds[fo + 3], lds[fo + 4], lds[fo + 5]),
-                 ft2 = mk3(lds[fo + 6], lds[fo + 7], lds[fo + 8]);
-        const f3 w = mk3(dof(0, i), dof(1, i), dof(2, i)), l = mk3(dof(3, i), dof(4, i), dof(5, i));
-        f3 jp = mk3(0, 0, 0);
-        if (sg & 1) jp = jp + (l + cross(w, pt - ld_com(CI(rec + 8))));
-        if (sg & 2) jp = jp - (l + cross(w, pt - ld_com(CI(rec + 7))));
-        const float jn = dot(fn_, jp), j1 = dot(ft1, jp), j2 = dot(ft2, jp);
-        const int r = Jo + (4 * c) * ldc + slot;
-        lds[r] = jn + mu * j1;
-        lds[r + ldc] = jn - mu * j1;
-        lds[r + 2 * ldc] = jn + mu * j2;
-        lds[r + 3 * ldc] = jn - mu * j2;
-      }
+      struct JEnt { int at; float r0, r1, r2, r3; };
+      item_loop2<G>(m.njac, gl,
+        [&](int t) {
+          const int pk = CI(m.c_jac + t), c = pk & 63, slot = (pk >> 6) & 31, i = (pk >> 11) & 31, sg = (pk >> 16) & 3, pr = pk >> 18;  // resolved on the host
+          const int rec = m.c_pair + pr * PAIR_S;
+          const float mu = CF(rec + 11);
+          const int root1 = CI(rec + 7), root2 = CI(rec + 8);
+          const f3 pt = mk3(con(1, c), con(2, c), con(3, c));
+          const int fo = eb + m.e_frame + pr * 9;
+          const f3 fn_ = mk3(lds[fo], lds[fo + 1], lds[fo + 2]), ft1 = mk3(lds[fo + 3], lds[fo + 4], lds[fo + 5]),
+                   ft2 = mk3(lds[fo + 6], lds[fo + 7], lds[fo + 8]);
+          const f3 w = mk3(dof(0, i), dof(1, i), dof(2, i)), l = mk3(dof(3, i), dof(4, i), dof(5, i));
+          const f3 com1 = ld_com(root1), com2 = ld_com(root2);  // unconditional loads, selected below
+          f3 jp = mk3(0, 0, 0);
+          if (sg & 1) jp = jp + (l + cross(w, pt - com2));
+          if (sg & 2) jp = jp - (l + cross(w, pt - com1));
+          const float jn = dot(fn_, jp), j1 = dot(ft1, jp), j2 = dot(ft2, jp);
+          return JEnt{Jo + (4 * c) * ldc + slot, jn + mu * j1, jn - mu * j1, jn + mu * j2, jn - mu * j2};
+        },
+        [&](int, const JEnt &r) { lds[r.at] = r.r0; lds[r.at + ldc] = r.r1; lds[r.at + 2 * ldc] = r.r2; lds[r.at + 3 * ldc] = r.r3; });
     }
     WSYNC();
     float dd = 0, ar = 0;
@@ -1062,7 +1089,7 @@ struct Env {
   }
   DEV void newton_direction() {  // Mgrad = (M + J' D_active J)^-1 grad, H packed lower-triangular
     const int nv = m.nv, Mo = eb + m.e_M, Ho = eb + m.e_H, Jo = eb + m.e_J, ldc = m.ldc;
-    for (int e = gl; e < TRI(nv); e += G) lds[Ho + e] = lds[Mo + e];
+    lds_copy<G>(Ho, Mo, TRI(nv), gl);
     WSYNC();
     PROF(19);
     const int row0 = m.neq + m.nlim;
@@ -1081,15 +1108,17 @@ struct Env {
     PROF(20);
     // contact rows: one lane per term (H entry, contact): the twelve operands of the contact's four pyramid rows are
     // fetched back to back, then reduced and added to the entry (ds_add_f32; entries are shared between contacts)
-    for (int t = gl; t < m.nhent; t += G) {
-      const int pk = CI(m.c_hent + t), ent = pk & 1023, cr0 = (pk >> 10) & 255, sa = (pk >> 18) & 31, sb = pk >> 23;
-      const int Jr = Jo + cr0 * ldc, Dr = eb + m.e_row + (row0 + cr0) * ROW_E;
-      float d[4], ja[4], jb[4];
+    struct HEnt { int at; float v; };
+    item_loop2<G>(m.nhent, gl,
+      [&](int t) {
+        const int pk = CI(m.c_hent + t), ent = pk & 1023, cr0 = (pk >> 10) & 255, sa = (pk >> 18) & 31, sb = pk >> 23;
+        const int Jr = Jo + cr0 * ldc, Dr = eb + m.e_row + (row0 + cr0) * ROW_E;
+        float d[4], ja[4], jb[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { d[k] = lds[Dr + k * ROW_E]; ja[k] = lds[Jr + k * ldc + sa]; jb[k] = lds[Jr + k * ldc + sb]; }
-      const float acc = (d[0] * ja[0] * jb[0] + d[1] * ja[1] * jb[1]) + (d[2] * ja[2] * jb[2] + d[3] * ja[3] * jb[3]);
-      if (acc != 0.0f) atomicAdd(&lds[Ho + ent], acc);
-    }
+        for (int k = 0; k < 4; ++k) { d[k] = lds[Dr + k * ROW_E]; ja[k] = lds[Jr + k * ldc + sa]; jb[k] = lds[Jr + k * ldc + sb]; }
+        return HEnt{Ho + ent, (d[0] * ja[0] * jb[0] + d[1] * ja[1] * jb[1]) + (d[2] * ja[2] * jb[2] + d[3] * ja[3] * jb[3])};
+      },
+      [&](int, const HEnt &r) { if (r.v != 0.0f) atomicAdd(&lds[r.at], r.v); });
     WSYNC();
     PROF(14);
     spd_solve<G>(m.nchol, Ho, nv, dofoff(D_GRAD), dofoff(D_MGRAD), gl, gb4, Ho);
@@ -1280,7 +1309,7 @@ struct Env {
     const int nv = m.nv, Mo = eb + m.e_M, Ho = eb + m.e_H;
     const int qp = eb + m.e_qpos, qv = eb + m.e_qvel;
     if (!(m.disableflags & DIS_EULERDAMP)) {
-      for (int e = gl; e < TRI(nv); e += G) lds[Ho + e] = lds[Mo + e];
+      lds_copy<G>(Ho, Mo, TRI(nv), gl);
       if (gl < nv) dof(D_SEARCH, gl) = dof(D_FSMOOTH, gl) + dof(D_FCON, gl);
       WSYNC();
       if (gl < nv) lds[Ho + TRI(gl) + gl] += m.dt * CF(m.c_dof + gl * DOF_S + 5);

@@ -36,6 +36,23 @@ def make_inputs(mj, nenv, horizon, seed_state, seed_ctrl, device):
     return torch.tensor(x0, device=device), us
 
 
+def pmc_traffic(default_workload):
+    """HBM bytes per launch of the rollout kernel from the committed rocprofv3 PMC passes (profiles/, collected with
+    tools/pmc_collect.sh: FETCH_SIZE and WRITE_SIZE in separate passes, KiB).  gfx950 correction from the guide: FETCH_SIZE
+    tallies 128-byte read requests at 64 bytes, so it is doubled; WRITE_SIZE is exact.  Only valid for the default workload."""
+    path = os.path.join(ROOT, "profiles", "r01_rocprofv3_pmc_amx_rollout.csv")
+    if not default_workload or not os.path.exists(path):
+        return None
+    vals = {}
+    for line in open(path):
+        p = line.strip().split(",")
+        if len(p) >= 2 and p[0] in ("FETCH_SIZE", "WRITE_SIZE"):
+            vals[p[0]] = float(p[1])
+    if len(vals) != 2:
+        return None
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+
+
 def cpu_baseline(mj, x0_np, us_np, target_s=12.0):
     """Times the CPU oracle (oracle/amx_oracle.c, fp32, OpenMP over envs, all host threads) on a bounded sample of the
     same workload: whole-horizon rollouts of the first envs, repeated until about `target_s` seconds of wall time."""
@@ -134,8 +151,9 @@ def main():
                        "nenv_per_gpu": args.nenv, "horizon": args.horizon, "nq": mj.nq, "nv": mj.nv, "nu": mj.nu,
                        "gather": args.gather if world > 1 else "none", "outputs_finite": finite},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "amx_rollout_kernel", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": bytes_per_launch},
+                         "traffic": pmc_traffic(args.nenv == 4096 and args.horizon == 1000 and args.model.endswith("quadruped.xml")),
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_rocprofv3_pmc_amx_rollout.csv)",
+                         "kernel": "amx_rollout_kernel", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(mj, x0.cpu().numpy(), us.cpu().numpy())
