@@ -99,7 +99,7 @@ const char *amx_last_error(void);
 int amx_model_create(const amx_model_desc *desc, int device, amx_model **out);
 int amx_model_destroy(amx_model *m);
 /* Static sizes of a created model: name in {"nq","nv","nu","nbody","ncon","nefc_max",
- * "lds_bytes","lanes_per_env","envs_per_block"}. */
+ * "lds_bytes","lanes_per_env","envs_per_block","env_slab_bytes","const_bytes"}. */
 int amx_model_query(const amx_model *m, const char *name, int *out);
 
 /* mjx.forward: derived quantities for the given state, no integration.  `qacc_warmstart_dev`
