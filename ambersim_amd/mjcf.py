@@ -341,6 +341,7 @@ class _Compiler:
         self.boundmass = float(comp.get("boundmass", 0))
         self.boundinertia = float(comp.get("boundinertia", 0))
         self.inertiafromgeom = comp.get("inertiafromgeom", "auto")
+        self.balanceinertia = comp.get("balanceinertia", "false") == "true"
         if comp.get("coordinate", "local") != "local":
             raise NotImplementedError("compiler coordinate='global'")
         for d in _merge_sections(root, "default"):
@@ -510,6 +511,9 @@ class _Compiler:
                     I["diag"], I["quat"] = w, _quat_mul(I["quat"], q)
                 else:
                     I["diag"] = _floats(at["diaginertia"], 3)
+                d = I["diag"]
+                if self.balanceinertia and (d[0] + d[1] < d[2] or d[0] + d[2] < d[1] or d[1] + d[2] < d[0]):
+                    I["diag"] = np.full(3, d.mean())  # MuJoCo: triangle inequality violated -> all three set to the mean
                 body["inertial"] = I
             elif c.tag in ("joint", "freejoint"):
                 body["joints"].append(self._joint(c, childclass))
@@ -1104,10 +1108,22 @@ def recompile_options(m: MjModel) -> MjModel:
     return m
 
 
-def compile_mjcf(path: str) -> MjModel:
+def load_mjcf_tree(path) -> ET.Element:
+    """MJCF element tree with `<include>`s resolved; a URDF is converted first (ambersim_amd/urdf.py)."""
     p = Path(path)
+    if p.suffix.lower() == ".urdf":  # mujoco.MjModel.from_xml_path also accepts URDF (reference conversion_utils.py:26)
+        from ambersim_amd.urdf import urdf_to_mjcf
+        return urdf_to_mjcf(p)
     root = ET.parse(p).getroot()
     if root.tag != "mujoco":
         raise ValueError("not an MJCF file")
     _resolve_includes(root, p.parent)
-    return _Compiler(root, p.parent).compile()
+    return root
+
+
+def compile_mjcf_tree(root: ET.Element, model_dir) -> MjModel:
+    return _Compiler(root, Path(model_dir)).compile()
+
+
+def compile_mjcf(path: str) -> MjModel:
+    return compile_mjcf_tree(load_mjcf_tree(path), Path(path).parent)

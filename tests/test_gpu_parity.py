@@ -221,6 +221,33 @@ def test_options_vs_oracle(cases, flags, solver):
     assert rel(xs[:, 1], ref[:, 1]) < TOL and rel(xs[:, 3], ref[:, 3]) < 1e-4
 
 
+def test_urdf_loaded_models_vs_oracle(dev):
+    """SURVEY.md §8f rank 2: models that come in through the URDF branch (limits, a mimic equality, damping, slide joints;
+    fused and floating-base variants) step like the oracle.  Contact is disabled: box/capsule pairs between non-adjacent
+    links are outside the supported collision table, as for the Barrett hand."""
+    from ambersim_amd import mjx
+    from ambersim_amd.mjcf import DisableBit, recompile_options
+    from ambersim_amd.utils.io_utils import load_mj_model_from_file
+    from oracle.oracle import Oracle
+    rng = np.random.default_rng(5)
+    for force_float in (False, True):
+        mj = load_mj_model_from_file(os.path.join(GOLDEN, "arm3.urdf"), force_float=False)
+        if force_float:
+            mj = load_mj_model_from_file(os.path.join(GOLDEN, "arm3_unfused.xml"), force_float=True)
+        mj = recompile_options(mj.replace(opt=mj.opt.replace(disableflags=int(DisableBit.CONTACT), iterations=4, ls_iterations=8)))
+        model = mjx.put_model(mj, dev)
+        nenv, N = 32, 20
+        q0 = np.tile(mj.qpos0, (nenv, 1))
+        q0[:, -4:] += np.array([0.3, -0.4, 0.01, 0.012]) + 0.05 * rng.standard_normal((nenv, 4)) * np.array([1, 1, 0.1, 0.1])
+        x0 = np.concatenate([q0, 0.2 * rng.standard_normal((nenv, mj.nv))], axis=1).astype(np.float32)
+        us = (rng.uniform(-1, 1, size=(nenv, N, 3)) * np.array([8.0, 4.0, 1.0])).astype(np.float32)
+        xs = gpu_rollout(model, x0, us)
+        ref = Oracle(mj, np.float64).rollout(x0, us)
+        assert np.isfinite(xs).all()
+        assert rel(xs[:, 1], ref[:, 1]) < TOL, force_float
+        assert rel(xs[:, N], ref[:, N]) < 5e-5, force_float  # 20 steps of fp32 vs fp64
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Callers: the reference's own tests, restated (SURVEY.md §4)
 # ---------------------------------------------------------------------------------------------------------------------
