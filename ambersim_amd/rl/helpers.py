@@ -1,0 +1,89 @@
+"""PPO network plumbing (counterpart of reference ambersim/rl/helpers.py:12-83, which wraps brax's PPONetworks)."""
+import math
+from dataclasses import dataclass
+from typing import Callable, Optional
+
+import torch
+from torch import nn
+
+
+class NormalTanhDistribution:
+    """tanh-squashed diagonal Gaussian, the action distribution brax's PPO uses: the policy emits (loc, raw scale),
+    scale = softplus(raw) + min_std, action = tanh(sample)."""
+
+    def __init__(self, event_size: int, min_std: float = 0.001):
+        self.event_size = event_size
+        self.param_size = 2 * event_size
+        self.min_std = min_std
+
+    def _split(self, params):
+        loc, raw = params[..., : self.event_size], params[..., self.event_size:]
+        return loc, torch.nn.functional.softplus(raw) + self.min_std
+
+    def sample_raw(self, params, generator=None):
+        loc, scale = self._split(params)
+        return loc + scale * torch.randn(loc.shape, generator=generator, device=loc.device, dtype=loc.dtype)
+
+    def mode(self, params):
+        return torch.tanh(self._split(params)[0])
+
+    @staticmethod
+    def postprocess(raw_action):
+        return torch.tanh(raw_action)
+
+    def log_prob(self, params, raw_action):
+        loc, scale = self._split(params)
+        z = (raw_action - loc) / scale
+        log_normal = -0.5 * z * z - torch.log(scale) - 0.5 * math.log(2 * math.pi)
+        log_det = 2.0 * (math.log(2.0) - raw_action - torch.nn.functional.softplus(-2.0 * raw_action))  # log d tanh(x)/dx
+        return (log_normal - log_det).sum(-1)
+
+    def entropy(self, params, generator=None):
+        loc, scale = self._split(params)
+        raw = loc + scale * torch.randn(loc.shape, generator=generator, device=loc.device, dtype=loc.dtype)
+        log_det = 2.0 * (math.log(2.0) - raw - torch.nn.functional.softplus(-2.0 * raw))
+        return (0.5 + 0.5 * math.log(2 * math.pi) + torch.log(scale) + log_det).sum(-1)
+
+
+@dataclass
+class PPONetworks:
+    policy_network: nn.Module
+    value_network: nn.Module
+    parametric_action_distribution: NormalTanhDistribution
+    preprocess_observations_fn: Callable
+
+
+def identity_observation_preprocessor(obs, params):
+    return obs
+
+
+@dataclass
+class PPONetworksWrapper:
+    """Lightweight holder of custom policy/value architectures (reference `BraxPPONetworksWrapper`, helpers.py:12-22):
+    `make_ppo_networks` checks the output sizes against the action distribution and the scalar value, like :45-70."""
+
+    policy_network: nn.Module
+    value_network: nn.Module
+    action_distribution: Callable[..., NormalTanhDistribution] = NormalTanhDistribution
+
+    def make_ppo_networks(self, observation_size: int, action_size: int,
+                          preprocess_observations_fn: Callable = identity_observation_preprocessor) -> PPONetworks:
+        action_dist = self.action_distribution(event_size=action_size)
+        dummy_observation = torch.zeros((1, observation_size), device=next(iter(self.policy_network.parameters())).device
+                                        if any(True for _ in self.policy_network.parameters()) else None)
+        with torch.no_grad():
+            policy_output = self.policy_network(dummy_observation)
+            value_output = self.value_network(dummy_observation)
+        assert policy_output.shape[-1] == action_dist.param_size, (
+            f"policy network output size {policy_output.shape[-1]} does not match action distribution size {action_dist.param_size}")
+        assert value_output.shape[-1] == 1, f"value network output size {tuple(value_output.shape)} does not match expected size 1"
+        return PPONetworks(self.policy_network, self.value_network, action_dist, preprocess_observations_fn)
+
+
+def make_ppo_networks(observation_size: int, action_size: int, policy_hidden_layer_sizes=(32,) * 4, value_hidden_layer_sizes=(256,) * 5,
+                      preprocess_observations_fn: Callable = identity_observation_preprocessor, device=None) -> PPONetworks:
+    """brax's default factory shape (swish MLPs in brax; the reference's own MLP uses relu and is what is built here)."""
+    from ambersim_amd.learning.architectures import MLP
+    policy = MLP(tuple(policy_hidden_layer_sizes) + (2 * action_size,)).to(device)
+    value = MLP(tuple(value_hidden_layer_sizes) + (1,)).to(device)
+    return PPONetworksWrapper(policy, value).make_ppo_networks(observation_size, action_size, preprocess_observations_fn)

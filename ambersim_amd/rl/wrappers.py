@@ -1,0 +1,64 @@
+"""Episode bookkeeping for natively batched envs: what brax's EpisodeWrapper + AutoResetWrapper do around the
+reference's env inside `ppo.train` (reference examples/rl/pendulum/ex_swingup.py:25-43 passes `episode_length`)."""
+from typing import Optional
+
+import torch
+
+from ambersim_amd.rl.base import MjxEnv, State
+
+
+def _blend(mask: torch.Tensor, new, old):
+    if new is None or old is None or not torch.is_tensor(new):
+        return old
+    m = mask.view((-1,) + (1,) * (new.dim() - 1)).to(torch.bool)
+    return torch.where(m, new, old)
+
+
+class EpisodeAutoReset:
+    """Truncates episodes at `episode_length` control steps and resets finished envs in place.
+
+    `info["truncation"]` marks envs cut by the time limit (their value target bootstraps), `info["steps"]` counts
+    control steps, `done` is the env's own termination OR the truncation.  A finished env restarts from the state it
+    was first reset to, as brax's AutoResetWrapper does (`first_pipeline_state`, `first_obs`)."""
+
+    def __init__(self, env: MjxEnv, episode_length: int, action_repeat: int = 1):
+        self.env, self.episode_length, self.action_repeat = env, int(episode_length), int(action_repeat)
+
+    def __getattr__(self, name):
+        return getattr(self.env, name)
+
+    def reset(self, rng: torch.Generator) -> State:
+        s = self.env.reset(rng)
+        n, dev = s.reward.shape[0], s.reward.device
+        s.info["steps"] = torch.zeros(n, device=dev)
+        s.info["truncation"] = torch.zeros(n, device=dev)
+        s.info["first_pipeline_state"] = s.pipeline_state
+        s.info["first_obs"] = s.obs
+        s.info["episode_return"] = torch.zeros(n, device=dev)
+        s.info["last_episode_return"] = torch.zeros(n, device=dev)
+        s.info["episodes"] = torch.zeros(n, device=dev)
+        return s
+
+    def step(self, state: State, action: torch.Tensor) -> State:
+        info = state.info
+        total = torch.zeros_like(state.reward)
+        s = state
+        for _ in range(self.action_repeat):
+            s = self.env.step(s, action)
+            total = total + s.reward
+        steps = info["steps"] + self.action_repeat
+        trunc = (steps >= self.episode_length).to(s.reward.dtype)
+        done = torch.maximum(s.done, trunc)
+        ret = info["episode_return"] + total
+        info["last_episode_return"] = torch.where(done > 0, ret, info["last_episode_return"])
+        info["episodes"] = info["episodes"] + done
+        info["episode_return"] = torch.where(done > 0, torch.zeros_like(ret), ret)
+        info["truncation"] = trunc * (1 - s.done)
+        info["steps"] = torch.where(done > 0, torch.zeros_like(steps), steps)
+        # auto reset: finished envs continue from their first state; the transition keeps this step's reward and done
+        first, cur = info["first_pipeline_state"], s.pipeline_state
+        fields = {f: _blend(done, getattr(first, f), getattr(cur, f)) for f in cur.__slots__}
+        data = cur.replace(**{k: v for k, v in fields.items() if v is not None})
+        info["terminal_obs"] = s.obs  # observation before the reset, for bootstrapping truncated episodes
+        obs = _blend(done, info["first_obs"], s.obs)
+        return s.replace(pipeline_state=data, obs=obs, reward=total, done=done)

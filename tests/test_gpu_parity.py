@@ -354,3 +354,31 @@ def test_argument_validation(cases):
         mjx.rollout(model, torch.tensor(x0[:3]), torch.tensor(us))
     with pytest.raises(NotImplementedError):
         model.replace(opt=model.opt.replace(integrator=1))
+
+
+def test_episode_wrapper_and_ppo_improves_pendulum_reward(dev):
+    """the torch PPO counterpart drives MjxEnv.step (amx_step); a short run must raise the
+    evaluation return of the swing-up env.  Also pins the episode wrapper: time-limit truncation and auto reset."""
+    import functools
+    from ambersim_amd.rl import ppo
+    from ambersim_amd.rl.helpers import make_ppo_networks
+    from ambersim_amd.rl.pendulum.swingup import PendulumSwingupEnv
+    from ambersim_amd.rl.wrappers import EpisodeAutoReset
+    env = PendulumSwingupEnv(num_envs=8, device=dev)
+    w = EpisodeAutoReset(env, episode_length=5)
+    s = w.reset(torch.Generator(device=dev).manual_seed(0))
+    q0 = s.pipeline_state.qpos.clone()
+    for k in range(5):
+        s = w.step(s, torch.zeros(8, 1, device=dev))
+        assert s.done.sum().item() == (8 if k == 4 else 0)
+    assert torch.equal(s.pipeline_state.qpos, q0) and s.info["truncation"].sum().item() == 8 and s.info["steps"].sum().item() == 0
+    assert torch.allclose(s.obs, env.compute_obs(s.pipeline_state, {}))
+    env = PendulumSwingupEnv(num_envs=256, device=dev)
+    eval_env = PendulumSwingupEnv(num_envs=64, device=dev)
+    res = ppo.train(environment=env, eval_env=eval_env, num_timesteps=12 * 256 * 10 * 8, num_evals=4, reward_scaling=0.1, episode_length=200,
+                    normalize_observations=True, unroll_length=10, num_minibatches=8, num_updates_per_batch=4, discounting=0.97,
+                    learning_rate=3e-4, entropy_cost=0, num_envs=256, batch_size=256, seed=0,
+                    network_factory=functools.partial(make_ppo_networks, policy_hidden_layer_sizes=(64,) * 3))
+    rewards = [m["eval/episode_reward"] for _, m in res.metrics]
+    assert len(rewards) == 4 and all(math.isfinite(r) for r in rewards)
+    assert rewards[-1] > rewards[0] + 50.0, rewards
