@@ -382,3 +382,38 @@ def test_episode_wrapper_and_ppo_improves_pendulum_reward(dev):
     rewards = [m["eval/episode_reward"] for _, m in res.metrics]
     assert len(rewards) == 4 and all(math.isfinite(r) for r in rewards)
     assert rewards[-1] > rewards[0] + 50.0, rewards
+
+
+def test_random_models_vs_oracle(dev):
+    """Fuzz parity: 40 seeded random trees (tests/fuzz_models.py: free/ball/hinge/slide joints, several roots, limits,
+    springs, armature, motors and position servos, a polynomial joint equality, sphere/capsule contacts, Newton and CG with
+    random iteration counts) - every lane-group width and most index paths.  One step must agree with the fp64 oracle
+    to north_star's 1e-5, or to 3x the distance of the fp32 CPU oracle from it where fp32 itself cannot do better
+    (ill-conditioned draws); five steps to 5e-5 or 5x that floor.  Draws whose fp64 trajectory blows up are skipped."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from fuzz_models import random_inputs, random_model
+    from ambersim_amd import mjx
+    from oracle.oracle import Oracle
+    tested, widths, worst = 0, set(), 0.0
+    for seed in range(40):
+        mj = random_model(seed)
+        if mj is None:
+            continue
+        x0, us = random_inputs(mj, seed, 8, 5)
+        x0, us = x0.astype(np.float32), us.astype(np.float32)
+        ref = Oracle(mj, np.float64).rollout(x0, us)
+        ref32 = Oracle(mj, np.float32).rollout(x0, us)
+        if not (np.isfinite(ref).all() and np.isfinite(ref32).all()) or np.abs(ref).max() > 100:
+            continue
+        model = mjx.put_model(mj, dev)
+        widths.add(model._h.query("lanes_per_env"))
+        xs = gpu_rollout(model, x0, us)
+        assert np.isfinite(xs).all(), seed
+        e1, f1 = rel(xs[:, 1], ref[:, 1]), rel(ref32[:, 1], ref[:, 1])
+        e5, f5 = rel(xs[:, 5], ref[:, 5]), rel(ref32[:, 5], ref[:, 5])
+        assert e1 <= max(TOL, 3 * f1), (seed, e1, f1)
+        assert e5 <= max(5e-5, 5 * f5), (seed, e5, f5)
+        tested += 1
+        worst = max(worst, e1)
+    assert tested >= 30 and widths == {16, 32, 64}, (tested, widths)  # all three lane-group widths were exercised
