@@ -54,3 +54,17 @@ def gather_trajectories(xs_local: torch.Tensor, nenv_total: int | None = None) -
     out = torch.empty((world * nmax,) + tuple(xs_local.shape[1:]), dtype=xs_local.dtype, device=xs_local.device)
     dist.all_gather_into_tensor(out, pad)
     return torch.cat([out[r * nmax: r * nmax + sizes[r]] for r in range(world)], dim=0)
+
+
+def gather_trajectories_async(xs_local: torch.Tensor):
+    """Equal-block all-gather started asynchronously: returns (gathered tensor, work handle).  The collective is ordered
+    after the kernels already queued on the current stream (the rollout that produced `xs_local`) and runs on the
+    communication stream, so the next rollout overlaps with it; `work.wait()` orders the current stream after it.
+    Every rank must pass the same block shape (bench.py's weak-scaling layout)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return xs_local, None
+    world = dist.get_world_size()
+    xs_local = xs_local.contiguous()
+    out = torch.empty((world * xs_local.shape[0],) + tuple(xs_local.shape[1:]), dtype=xs_local.dtype, device=xs_local.device)
+    work = dist.all_gather_into_tensor(out, xs_local, async_op=True)
+    return out, work

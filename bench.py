@@ -4,7 +4,7 @@
 One "step" = one amx_rollout launch over one batch: NENV envs x HORIZON physics steps of the
 build-authored quadruped (4096 envs, random ctrl, 1000-step rollout), inputs
 resident in HBM.  With --gpus N every rank runs its own NENV envs (weak scaling, no collective in the
-data path) and the returned trajectories are all-gathered over RCCL once per step.
+data path) and the returned trajectories are all-gathered over RCCL once per step, overlapped with the next rollout.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
@@ -84,12 +84,13 @@ def main():
     ap.add_argument("--model", default="models/quadruped/quadruped.xml")
     ap.add_argument("--gather", choices=["traj", "none"], default="traj", help="N>1: all-gather returned trajectories")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="N>1: wait for each all-gather before the next rollout")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from ambersim_amd import mjx
-    from ambersim_amd.dist import gather_trajectories, init_from_env
+    from ambersim_amd.dist import gather_trajectories, gather_trajectories_async, init_from_env
     from ambersim_amd.utils.io_utils import load_mj_model_from_file
 
     rank, world, local = init_from_env()
@@ -103,27 +104,39 @@ def main():
     x0, us = make_inputs(mj, args.nenv, args.horizon, 1 + 1000 * rank, 2 + 1000 * rank, dev)
     nx = mj.nq + mj.nv
 
-    def one_step():
-        xs = mjx.rollout(model, x0, us)
-        if world > 1 and args.gather == "traj":
-            xs = gather_trajectories(xs)
+    overlap = world > 1 and args.gather == "traj" and not args.no_overlap
+
+    def run_steps(nsteps, events=None):
+        """`nsteps` rollouts; with N > 1 each trajectory block is all-gathered.  The gather of step k runs on the
+        communication stream while rollout k+1 runs on the compute stream (at most two gathers in flight); all of them
+        are complete when this returns (the caller synchronises)."""
+        pending, xs = [], None
+        for k in range(nsteps):
+            if events is not None:
+                events[k][0].record()  # HIP events on the launch stream (torch's current stream is the one handed to amx_rollout)
+            xs = mjx.rollout(model, x0, us)
+            if events is not None:
+                events[k][1].record()
+            if world > 1 and args.gather == "traj":
+                if overlap:
+                    pending.append(gather_trajectories_async(xs))
+                    if len(pending) > 2:
+                        pending.pop(0)[1].wait()
+                else:
+                    xs = gather_trajectories(xs)
+        for out, work in pending:
+            work.wait()
+            xs = out
         return xs
 
-    for _ in range(args.warmup):
-        one_step()
+    run_steps(args.warmup)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        # HIP events on the launch stream (torch's current stream is the one handed to amx_rollout)
-        ev[k][0].record()
-        xs = mjx.rollout(model, x0, us)
-        ev[k][1].record()
-        if world > 1 and args.gather == "traj":
-            xs = gather_trajectories(xs)
+    xs = run_steps(args.steps, ev)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -149,7 +162,7 @@ def main():
                                    f"{args.horizon}-step fused rollout, random ctrl ~U(ctrlrange), Newton {mj.opt.iterations} it / "
                                    f"{mj.opt.ls_iterations} ls, dt={mj.opt.timestep}",
                        "nenv_per_gpu": args.nenv, "horizon": args.horizon, "nq": mj.nq, "nv": mj.nv, "nu": mj.nu,
-                       "gather": args.gather if world > 1 else "none", "outputs_finite": finite},
+                       "gather": (args.gather + ("+overlapped" if overlap else "")) if world > 1 else "none", "outputs_finite": finite},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(args.nenv == 4096 and args.horizon == 1000 and args.model.endswith("quadruped.xml")),
                          "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_rocprofv3_pmc_amx_rollout.csv)",

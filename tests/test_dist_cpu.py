@@ -31,6 +31,12 @@ def _worker(rank, world, port, nenv_total, out_dir):
     xs_local = torch.arange(lo, hi, dtype=torch.float32).reshape(-1, 1, 1) * torch.ones((1, 4, 3))
     full = gather_trajectories(xs_local)
     np.save(os.path.join(out_dir, f"rank{rank}.npy"), full.numpy())
+    if nenv_total % world == 0:  # the overlapped path of bench.py: two equal-block gathers in flight, then waited
+        from ambersim_amd.dist import gather_trajectories_async
+        pend = [gather_trajectories_async(xs_local + k) for k in range(2)]
+        for k, (out, work) in enumerate(pend):
+            work.wait()
+            assert torch.equal(out, full + k)
     dist.barrier()
     dist.destroy_process_group()
 
