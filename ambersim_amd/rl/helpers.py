@@ -69,8 +69,9 @@ class PPONetworksWrapper:
     def make_ppo_networks(self, observation_size: int, action_size: int,
                           preprocess_observations_fn: Callable = identity_observation_preprocessor) -> PPONetworks:
         action_dist = self.action_distribution(event_size=action_size)
-        dummy_observation = torch.zeros((1, observation_size), device=next(iter(self.policy_network.parameters())).device
-                                        if any(True for _ in self.policy_network.parameters()) else None)
+        params = list(self.policy_network.parameters())
+        dev = params[0].device if params and not isinstance(params[0], nn.parameter.UninitializedParameter) else None
+        dummy_observation = torch.zeros((1, observation_size), device=dev)
         with torch.no_grad():
             policy_output = self.policy_network(dummy_observation)
             value_output = self.value_network(dummy_observation)

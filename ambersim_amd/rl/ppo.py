@@ -106,7 +106,8 @@ def train(environment, num_timesteps: int, episode_length: int, num_envs: int = 
     torch.manual_seed(seed)
     gen = torch.Generator(device=dev).manual_seed(seed)
     obs_size, act_size = environment.observation_size, environment.action_size
-    nets = network_factory(obs_size, act_size, device=dev)
+    nets = network_factory(obs_size, act_size)  # e.g. make_ppo_networks or PPONetworksWrapper(...).make_ppo_networks
+    nets.policy_network.to(dev); nets.value_network.to(dev)
     dist = nets.parametric_action_distribution
     norm = RunningStatistics(obs_size, dev) if normalize_observations else None
     nets.policy_network(torch.zeros((1, obs_size), device=dev)); nets.value_network(torch.zeros((1, obs_size), device=dev))  # materialise lazy layers

@@ -132,6 +132,87 @@ __device__ __noinline__ void spd_solve_gj(int M_off, int ldm, int n, int rhs_off
   if (gl < n) lds[x_off + gl * vstride] = b / d;
 }
 
+
+// ------------------------------------------------------------ hybrid: part of each pivot row through the crossbar, part through
+// v_readlane + exec-masked v_fmac with the SGPR as operand (two 32-lane groups per wave)
+#ifndef XNUM
+#define XNUM 1
+#define XDEN 2
+#endif
+template <int NC> DEV void masked_fmac(float *a, const float *lo, const float *hi, float nf) {
+  static_assert(NC >= 1 && NC <= 4, "chunk");
+  unsigned long long save;
+  float a0 = a[0], a1 = NC > 1 ? a[1] : 0.f, a2 = NC > 2 ? a[2] : 0.f, a3 = NC > 3 ? a[3] : 0.f;
+  const float l0 = lo[0], l1 = NC > 1 ? lo[1] : 0.f, l2 = NC > 2 ? lo[2] : 0.f, l3 = NC > 3 ? lo[3] : 0.f;
+  const float h0 = hi[0], h1 = NC > 1 ? hi[1] : 0.f, h2 = NC > 2 ? hi[2] : 0.f, h3 = NC > 3 ? hi[3] : 0.f;
+  asm volatile(
+      "s_nop 2\n\t"
+      "s_mov_b64 %[sv], exec\n\t"
+      "s_mov_b64 exec, 0xffffffff\n\t"
+      "v_fmac_f32 %[a0], %[l0], %[nf]\n\t"
+      "v_fmac_f32 %[a1], %[l1], %[nf]\n\t"
+      "v_fmac_f32 %[a2], %[l2], %[nf]\n\t"
+      "v_fmac_f32 %[a3], %[l3], %[nf]\n\t"
+      "s_not_b64 exec, exec\n\t"
+      "v_fmac_f32 %[a0], %[h0], %[nf]\n\t"
+      "v_fmac_f32 %[a1], %[h1], %[nf]\n\t"
+      "v_fmac_f32 %[a2], %[h2], %[nf]\n\t"
+      "v_fmac_f32 %[a3], %[h3], %[nf]\n\t"
+      "s_mov_b64 exec, %[sv]"
+      : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [sv] "=&s"(save)
+      : [l0] "s"(l0), [l1] "s"(l1), [l2] "s"(l2), [l3] "s"(l3), [h0] "s"(h0), [h1] "s"(h1), [h2] "s"(h2), [h3] "s"(h3), [nf] "v"(nf)
+      : "scc");
+  a[0] = a0; if (NC > 1) a[1] = a1; if (NC > 2) a[2] = a2; if (NC > 3) a[3] = a3;
+}
+template <int N, int J> struct GJH {
+  static DEV void run(float (&a)[N], float &b, int gl, int gb4) {
+    constexpr int nrl = ((N - J - 1) * (XDEN - XNUM)) / XDEN;  // columns J+1 .. J+nrl by readlane, the rest by crossbar
+    constexpr int ksplit = J + 1 + nrl;
+    float u[N];
+    const float piv = bperm_f(gb4 + 4 * J, a[J]);
+    const float bj = bperm_f(gb4 + 4 * J, b);
+#pragma unroll
+    for (int k = ksplit; k < N; ++k) u[k] = bperm_f(gb4 + 4 * J, a[k]);
+    float f = a[J] * __builtin_amdgcn_rcpf(fmaxf(piv, MINVAL));
+    f = gl == J ? 0.0f : f;
+    const float nf = -f;
+    b = __builtin_fmaf(nf, bj, b);
+#pragma unroll
+    for (int k0 = J + 1; k0 < ksplit; k0 += 4) {
+      float lo[4], hi[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const int k = k0 + i < ksplit ? k0 + i : ksplit - 1; lo[i] = readlane_f(a[k], J); hi[i] = readlane_f(a[k], J + 32); }
+      constexpr int dummy = 0;
+      const int nc = ksplit - k0;
+      if (nc >= 4) masked_fmac<4>(&a[k0], lo, hi, nf);
+      else if (nc == 3) masked_fmac<3>(&a[k0], lo, hi, nf);
+      else if (nc == 2) masked_fmac<2>(&a[k0], lo, hi, nf);
+      else masked_fmac<1>(&a[k0], lo, hi, nf);
+    }
+#pragma unroll
+    for (int k = ksplit; k < N; ++k) a[k] = __builtin_fmaf(nf, u[k], a[k]);
+    GJH<N, J + 1>::run(a, b, gl, gb4);
+  }
+};
+template <int N> struct GJH<N, N> { static DEV void run(float (&)[N], float &, int, int) {} };
+template <int N>
+__device__ __noinline__ void spd_solve_gjh(int M_off, int ldm, int n, int rhs_off, int x_off, int vstride, int gl, int gb4) {
+  float a[N];
+  const int li = gl < n ? gl : 0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const float v = lds[M_off + li * ldm + (k < n ? k : 0)];
+    a[k] = (gl < n && k < n) ? v : (k == gl ? 1.0f : 0.0f);
+  }
+  float b = lds[rhs_off + li * vstride];
+  b = gl < n ? b : 0.0f;
+  GJH<N, 0>::run(a, b, gl, gb4);
+  float d = 1.0f;
+#pragma unroll
+  for (int k = 0; k < N; ++k) d = (k == gl) ? a[k] : d;
+  if (gl < n) lds[x_off + gl * vstride] = b / d;
+}
+
 // each wave: 2 environments (32 lanes each); per env: M [n][ldm], rhs[n], x[n]
 template <int N, int MODE>
 __global__ void __launch_bounds__(256, 2) solve_bench(const float *Mg, const float *bg, float *xg, int n, int reps, unsigned long long *cyc) {
@@ -145,7 +226,8 @@ __global__ void __launch_bounds__(256, 2) solve_bench(const float *Mg, const flo
   const unsigned long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < reps; ++it) {
     if (MODE == 0) spd_solve_mfma<N, 2>(env0, env1, ldm, n, mine + n * ldm, mine + n * ldm + n, 1, lane);
-    else spd_solve_gj<N>(mine, ldm, n, mine + n * ldm, mine + n * ldm + n, 1, gl, 4 * (lane & 32));
+    else if (MODE == 1) spd_solve_gj<N>(mine, ldm, n, mine + n * ldm, mine + n * ldm + n, 1, gl, 4 * (lane & 32));
+    else spd_solve_gjh<N>(mine, ldm, n, mine + n * ldm, mine + n * ldm + n, 1, gl, 4 * (lane & 32));
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   const unsigned long long t1 = __builtin_readcyclecounter();
@@ -217,10 +299,13 @@ int main() {
   printf("permlane32_swap(vdst=l, vsrc=100+l): lane0 -> (%u,%u) lane31 -> (%u,%u) lane32 -> (%u,%u) lane63 -> (%u,%u)\n", hs[0], hs[1], hs[62], hs[63], hs[64], hs[65],
          hs[126], hs[127]);
   run_solve<18, 1>("crossbar Gauss-Jordan", 18, 1, 200);
+  run_solve<18, 2>("hybrid crossbar+readlane GJ", 18, 1, 200);
   run_solve<18, 0>("mfma LDL^T", 18, 1, 200);
   run_solve<18, 1>("crossbar Gauss-Jordan", 18, 512, 200);
+  run_solve<18, 2>("hybrid crossbar+readlane GJ", 18, 512, 200);
   run_solve<18, 0>("mfma LDL^T", 18, 512, 200);
   run_solve<30, 1>("crossbar Gauss-Jordan", 30, 512, 200);
+  run_solve<30, 2>("hybrid crossbar+readlane GJ", 30, 512, 200);
   run_solve<30, 0>("mfma LDL^T", 30, 512, 200);
   return 0;
 }
