@@ -222,7 +222,7 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
       for (int k = 0; k < PAIR_NCON[fn]; k++) dofmem[pairdof[d0 + a] & 255].push_back((4 * (ncon + k)) | (a << 8));
       for (int b = 0; b <= a; b++) {  // dof list ascending, so (dof_a, dof_b) is a lower-triangle entry of H
         const int di = pairdof[d0 + a] & 255, dj = pairdof[d0 + b] & 255;
-        for (int k = 0; k < PAIR_NCON[fn]; k++) hmembers[di * (di + 1) / 2 + dj].push_back(((4 * (ncon + k)) << 10) | (a << 18) | (b << 23));
+        for (int k = 0; k < PAIR_NCON[fn]; k++) hmembers[di * (di + 1) / 2 + dj].push_back(di | (dj << 5) | ((4 * (ncon + k)) << 10) | (a << 18) | (b << 23));
       }
     }
     for (int k = 0; k < PAIR_NCON[fn]; k++) {
@@ -233,7 +233,7 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
     ncon += PAIR_NCON[fn];
   }
   for (int t = 0; t < nv * (nv + 1) / 2; t++)
-    for (int w : hmembers[t]) hent.push_back(t | w);  // one term per (H entry, contact)
+    for (int w : hmembers[t]) hent.push_back(w);  // one term per (H entry, contact)
   m.ncon = ncon; m.njac = (int)jac_items.size(); m.nhent = (int)hent.size();
   if (ncon > 63) return fail(AMX_ECAPACITY, "%d contact slots exceed 63", ncon);
   // limit rows, equality rows
@@ -287,6 +287,8 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
     m.c_dofmemadr = add_ints(adr); m.c_dofmem = add_ints(flat);
   }
   m.ldc = maxchain | 1;
+  m.ldm = ((nv + 3) / 4) * 4;
+  if ((m.ldm / 4) % 2 == 0) m.ldm += 4;  // rows 16-byte aligned, ldm/4 odd: 8 lanes reading their rows as b128 cover all 32 banks
   m.c_qpos0 = im.reserve(nq);
   for (int k = 0; k < nq; k++) im.setf(m.c_qpos0 + k, d->qpos0[k]);
   m.c_vert = im.reserve(3 * d->nconvexvert);
@@ -302,9 +304,9 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
   m.e_com = take(3 * m.nroot); m.e_actf = take(nu);
   const int ntri = nv * (nv + 1) / 2;
   // joint anchors/axes (kinematics -> cdof) are dead before H is first written: they share its space
-  m.e_M = take(ntri);
-  off = (off + 3) & ~3;  // H doubles as the solver's 16-byte-aligned pivot-row scratch (spd_solve_rows)
-  m.e_H = take(std::max(std::max(ntri, JNT_E * nj), nv + 8)); m.e_jnt = m.e_H; m.e_Lb = d->solver == 1 ? take(ntri) : m.e_H;
+  off = (off + 3) & ~3;  // M and H are full symmetric [nv][ldm] with 16-byte aligned rows (row loads and M*v use ds_read_b128)
+  m.e_M = take(nv * m.ldm);
+  m.e_H = take(std::max(std::max(nv * m.ldm, JNT_E * nj), nv + 8)); m.e_jnt = m.e_H; m.e_Lb = d->solver == 1 ? take(ntri) : m.e_H;
   m.e_row = take(ROW_E * m.nefc);
   // collision geom poses (com_pos -> collision) are dead before the contact rows are written: they share their space
   m.e_J = take(std::max(4 * m.ncon * m.ldc, GEO_E * m.ngc)); m.e_geom = m.e_J;

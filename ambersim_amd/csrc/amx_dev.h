@@ -30,7 +30,7 @@ enum { BODY_S = 25, JNT_S = 13, DOF_S = 9, ACT_S = 13, GEOM_S = 13, PAIR_S = 29,
 struct DevModel {
   const float *image;  // HBM copy of the constant image (ints stored bit-cast), nconst floats
   int nconst;
-  int nq, nv, nu, nb, njnt, ngc, npair, ncon, neq, nlim, nefc, nlevel, nM, nroot, ldc /*contact-row stride: longest pair dof list, odd*/, nchol, njac, nhent;
+  int nq, nv, nu, nb, njnt, ngc, npair, ncon, neq, nlim, nefc, nlevel, nM, nroot, ldc /*contact-row stride: longest pair dof list, odd*/, ldm /*row stride of M and H: >= nv, ldm/4 odd*/, nchol, njac, nhent;
   int iterations, ls_iterations, solver, disableflags;
   int G;    // lanes per environment: 16, 32 or 64
   int wpb;  // wavefronts per workgroup (1..AMX_WAVES_PER_BLOCK), chosen to maximise resident waves per CU
@@ -38,14 +38,14 @@ struct DevModel {
   // bases inside the constant image (float offsets)
   int c_body, c_jnt, c_dof, c_act, c_geom, c_pair, c_lim, c_eq;
   int c_qpos0 /*[nq]*/, c_child, c_M /*packed i|j<<8*/, c_dofact, c_pairdof /*packed dof|sign<<8*/, c_jac /*packed contact|slot<<6|dof<<11|chain sign<<16|pair<<18*/,
-      c_hent /*[nhent] terms: packed H entry|first contact row<<10|slot_i<<18|slot_j<<23*/, c_dofmemadr /*[nv+1]*/, c_dofmem /*terms: packed first contact row|slot<<8*/, c_conpair /*[ncon]*/, c_vert, c_rootbody;
+      c_hent /*[nhent] terms: packed dof_i|dof_j<<5|first contact row<<10|slot_i<<18|slot_j<<23 (dof_j <= dof_i)*/, c_dofmemadr /*[nv+1]*/, c_dofmem /*terms: packed first contact row|slot<<8*/, c_conpair /*[ncon]*/, c_vert, c_rootbody;
   // bases inside one environment slab (float offsets from the slab start)
   int e_qpos, e_qvel, e_ctrl;
   int e_body /* records [nb][BODY_E]: xpos 0-2 xquat 3-6 cinert 7-16 (then cfrc 7-12) crb 17-26 (then cvel 17-22 cacc 23-28) */;
   int e_jnt  /* records [njnt][JNT_E]: xanchor 0-2 xaxis 3-5 */;
   int e_dof  /* records [nv][DOF_E]: cdof 0-5 fcrb 6-11 (then Ma grad Mgrad search mv fcon) fsmooth 12 asmooth 13 qacc 14 warm 15 fbias 16 */;
   int e_com, e_actf;
-  int e_M, e_H, e_Lb /* packed lower-triangular nv(nv+1)/2 each; Lb only allocated for the CG solver */;
+  int e_M, e_H /* full symmetric [nv][ldm], 16-byte aligned rows */, e_Lb /* packed lower-triangular Cholesky factor, only allocated for the CG solver */;
   int e_row /* records [nefc][ROW_E]: Dact 0 frow 1 */;
   int e_J /* contact rows only, chain-compressed: [4*ncon][ldc] */;
   int e_con /* records [ncon][CON_E]: dist 0 pos 1-3 */, e_frame /* [npair][9] */, e_geom /* records [ngc][GEO_E]: pos 0-2 mat 3-11 */;

@@ -165,7 +165,7 @@ template <int G> DEV float gbcast(float x, int j, int gb4) {
 DEV bool wave_any(bool p) { return __ballot(p) != 0ull; }
 
 // ---- register-row dense Cholesky: lane i holds row i of the matrix at lds[A_off] (lower part).
-// Matrices are packed lower-triangular (row i at TRI(i)).  Solves A x = rhs.  L is written to lds[L_off] (may equal A_off: each lane overwrites only
+// A is full symmetric [n][ld]; the factor is packed lower-triangular (row i at TRI(i)).  Solves A x = rhs.  L is written to lds[L_off] (may equal A_off: each lane overwrites only
 // its own row after reading it); the two substitutions re-read it masked (strict lower rows, then
 // strict lower columns), so every lane runs the same 3-instruction update per pivot.
 // `factor == false` reuses the factor already stored at L_off (CG preconditioner).
@@ -174,13 +174,13 @@ DEV bool wave_any(bool p) { return __ballot(p) != 0ull; }
 #define TRI(i) (((i) * ((i) + 1)) >> 1)  // offset of row i in packed lower-triangular storage
 
 template <int N, int G>
-__device__ __noinline__ void chol_solve_rows(int A_off, int n, int L_off, int rhs_off, int x_off, int vstride, bool factor, int gl, int gb4) {
+__device__ __noinline__ void chol_solve_rows(int A_off, int ld, int n, int L_off, int rhs_off, int x_off, int vstride, bool factor, int gl, int gb4) {
   float a[N];
   const int li = gl < n ? gl : 0, row = TRI(li);
   if (factor) {
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-      const float v = lds[A_off + row + (k <= li ? k : li)];
+      const float v = lds[A_off + li * ld + (k <= li ? k : li)];  // A: full symmetric [n][ld]; L: packed lower-triangular
       a[k] = (gl < n && k <= gl) ? v : (k == gl ? 1.0f : 0.0f);
     }
 #pragma unroll
@@ -339,14 +339,21 @@ template <int N, int G> struct GJ<N, G, N> { static DEV void run(float (&)[N], f
 // `sbuf`: LDS float offset (multiple of 4) of N+4 floats of scratch private to the group; it may alias the matrix,
 // whose rows are all in registers before the first pivot stores.
 template <int N, int G>
-__device__ __noinline__ void spd_solve_rows(int A_off, int n, int rhs_off, int x_off, int vstride, int gl, int gb4, int sbuf) {
+__device__ __noinline__ void spd_solve_rows(int A_off, int ld, int n, int rhs_off, int x_off, int vstride, int gl, int gb4, int sbuf) {
   float a[N];
-  const int li = gl < n ? gl : 0, row = A_off + TRI(li), last = A_off + TRI(n) - 1;
+  const int li = gl < n ? gl : 0;
+  // row li of the full symmetric matrix: 16-byte aligned, ld >= ceil4(n) floats long, so whole b128 chunks are in bounds
+  const float4 *rowp = reinterpret_cast<const float4 *>(lds + A_off + li * ld);
 #pragma unroll
-  for (int k = 0; k < N; ++k) {  // full symmetric row from packed lower-triangular storage (branch-free addresses)
-    const int addr = k <= li ? row + k : A_off + TRI(k) + li;
-    const float v = lds[addr < last ? addr : last];
-    a[k] = (gl < n && k < n) ? v : (k == gl ? 1.0f : 0.0f);
+  for (int c = 0; c < (N + 3) / 4; ++c) {
+    float4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (4 * c < ld) v = rowp[4 * c < ld ? c : 0];
+    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = 4 * c + q;
+      if (k < N) a[k] = (gl < n && k < n) ? e[q] : (k == gl ? 1.0f : 0.0f);
+    }
   }
   float b = lds[rhs_off + li * vstride];
   b = gl < n ? b : 0.0f;
@@ -360,12 +367,12 @@ __device__ __noinline__ void spd_solve_rows(int A_off, int n, int rhs_off, int x
 }
 
 template <int G>
-__device__ __noinline__ void spd_solve(int nchol, int A_off, int n, int rhs_off, int x_off, int gl, int gb4, int sbuf) {
+__device__ __noinline__ void spd_solve(int nchol, int A_off, int ld, int n, int rhs_off, int x_off, int gl, int gb4, int sbuf) {
   const int vstride = DOF_E;
   // one instantiation per even size (a pivot costs a crossbar round trip, so padding rows are not free);
   // a group of G lanes holds at most G rows
-#define AMX_SPD_CASE(NN) else if (nchol <= NN && NN <= G) spd_solve_rows<(NN <= G ? NN : 4), G>(A_off, n, rhs_off, x_off, vstride, gl, gb4, sbuf);
-  if (nchol <= 4) spd_solve_rows<4, G>(A_off, n, rhs_off, x_off, vstride, gl, gb4, sbuf);
+#define AMX_SPD_CASE(NN) else if (nchol <= NN && NN <= G) spd_solve_rows<(NN <= G ? NN : 4), G>(A_off, ld, n, rhs_off, x_off, vstride, gl, gb4, sbuf);
+  if (nchol <= 4) spd_solve_rows<4, G>(A_off, ld, n, rhs_off, x_off, vstride, gl, gb4, sbuf);
   AMX_SPD_CASE(6) AMX_SPD_CASE(8) AMX_SPD_CASE(10) AMX_SPD_CASE(12) AMX_SPD_CASE(14) AMX_SPD_CASE(16) AMX_SPD_CASE(18)
   AMX_SPD_CASE(20) AMX_SPD_CASE(22) AMX_SPD_CASE(24) AMX_SPD_CASE(26) AMX_SPD_CASE(28) AMX_SPD_CASE(30) AMX_SPD_CASE(32)
 #undef AMX_SPD_CASE
@@ -373,16 +380,16 @@ __device__ __noinline__ void spd_solve(int nchol, int A_off, int n, int rhs_off,
 
 // one out-of-line dispatcher so the call sites stay small (CG preconditioner only)
 template <int G>
-__device__ __noinline__ void chol_solve(int nchol, int A_off, int n, int L_off, int rhs_off, int x_off, bool factor, int gl, int gb4) {
+__device__ __noinline__ void chol_solve(int nchol, int A_off, int ld, int n, int L_off, int rhs_off, int x_off, bool factor, int gl, int gb4) {
   const int vstride = DOF_E;
-  if (nchol <= 4) chol_solve_rows<4, G>(A_off, n, L_off, rhs_off, x_off, vstride, factor, gl, gb4);
-  else if (nchol <= 8) chol_solve_rows<8, G>(A_off, n, L_off, rhs_off, x_off, vstride, factor, gl, gb4);
-  else if (nchol <= 12) chol_solve_rows<12, G>(A_off, n, L_off, rhs_off, x_off, vstride, factor, gl, gb4);
-  else if (nchol <= 16) chol_solve_rows<(G >= 16 ? 16 : 12), G>(A_off, n, L_off, rhs_off, x_off, vstride, factor, gl, gb4);
-  else if (nchol <= 20) chol_solve_rows<(G >= 32 ? 20 : 12), G>(A_off, n, L_off, rhs_off, x_off, vstride, factor, gl, gb4);
-  else if (nchol <= 24) chol_solve_rows<(G >= 32 ? 24 : 12), G>(A_off, n, L_off, rhs_off, x_off, vstride, factor, gl, gb4);
-  else if (nchol <= 28) chol_solve_rows<(G >= 32 ? 28 : 12), G>(A_off, n, L_off, rhs_off, x_off, vstride, factor, gl, gb4);
-  else chol_solve_rows<(G >= 32 ? 32 : 12), G>(A_off, n, L_off, rhs_off, x_off, vstride, factor, gl, gb4);
+  if (nchol <= 4) chol_solve_rows<4, G>(A_off, ld, n, L_off, rhs_off, x_off, vstride, factor, gl, gb4);
+  else if (nchol <= 8) chol_solve_rows<8, G>(A_off, ld, n, L_off, rhs_off, x_off, vstride, factor, gl, gb4);
+  else if (nchol <= 12) chol_solve_rows<12, G>(A_off, ld, n, L_off, rhs_off, x_off, vstride, factor, gl, gb4);
+  else if (nchol <= 16) chol_solve_rows<(G >= 16 ? 16 : 12), G>(A_off, ld, n, L_off, rhs_off, x_off, vstride, factor, gl, gb4);
+  else if (nchol <= 20) chol_solve_rows<(G >= 32 ? 20 : 12), G>(A_off, ld, n, L_off, rhs_off, x_off, vstride, factor, gl, gb4);
+  else if (nchol <= 24) chol_solve_rows<(G >= 32 ? 24 : 12), G>(A_off, ld, n, L_off, rhs_off, x_off, vstride, factor, gl, gb4);
+  else if (nchol <= 28) chol_solve_rows<(G >= 32 ? 28 : 12), G>(A_off, ld, n, L_off, rhs_off, x_off, vstride, factor, gl, gb4);
+  else chol_solve_rows<(G >= 32 ? 32 : 12), G>(A_off, ld, n, L_off, rhs_off, x_off, vstride, factor, gl, gb4);
 }
 
 // impedance of one constraint row [A9.6]; k and b are folded on the host, rec points at {k,b,dmin,dmax,width,mid,power,ca,cb}
@@ -669,8 +676,8 @@ struct Env {
       st_dsv(D_FCRB, gl, inert_mul(I, ld_dsv(D_CDOF, gl)));
     }
     WSYNC();
-    const int Mo = eb + m.e_M;
-    struct MEnt { int at; float v; };
+    const int Mo = eb + m.e_M, ldm = m.ldm;
+    struct MEnt { int at, at2; float v; };
     item_loop2<G>(m.nM, gl,
       [&](int e) {
         const int pk = CI(m.c_M + e), i = pk & 255, j = pk >> 8;
@@ -678,9 +685,9 @@ struct Env {
         const float arm = CF(m.c_dof + i * DOF_S + 4);
         float v = (c.v[0] * f.v[0] + c.v[1] * f.v[1]) + (c.v[2] * f.v[2] + c.v[3] * f.v[3]) + (c.v[4] * f.v[4] + c.v[5] * f.v[5]);
         if (i == j) v += arm;
-        return MEnt{Mo + TRI(i) + j, v};  // j is an ancestor of i: j <= i
+        return MEnt{Mo + i * ldm + j, Mo + j * ldm + i, v};  // j is an ancestor of i: j <= i; both triangles are stored
       },
-      [&](int, const MEnt &r) { lds[r.at] = r.v; });
+      [&](int, const MEnt &r) { lds[r.at] = r.v; lds[r.at2] = r.v; });
     WSYNC();
   }
 
@@ -1005,18 +1012,21 @@ struct Env {
   }
 
   // ------------------------------------------------------------------ A9.13 solver
-  DEV float mul_M_row(int vf) const {  // (M v)[gl], v = dof field vf; M packed lower-triangular
-    const int nv = m.nv, i = gl < nv ? gl : 0, Mo = eb + m.e_M, tri_i = TRI(i), vo = dofoff(vf);
-    float acc = 0;
-    int tri_j = 0;  // TRI(j), kept incrementally in a scalar register
-#pragma unroll 6
-    for (int j = 0; j < nv; ++j) {
-      tri_j += j;
-      // M(i,j) lives at TRI(max) + min: two value selects, no branches, no multiply
-      const int thi = j <= i ? tri_i : tri_j, lo = j <= i ? j : i;
-      acc += lds[Mo + thi + lo] * lds[vo + j * DOF_E];
+  // (M v)[gl], v = dof field vf.  v is first staged contiguously in the (idle) H buffer so that both the lane's M row and
+  // v stream in as ds_read_b128 (v: one address per group = broadcast); 2 * ldm/4 wide loads replace 2 * nv scalar ones.
+  DEV float mul_M_row(int vf) const {
+    const int nv = m.nv, ldm = m.ldm, i = gl < nv ? gl : 0, Vo = eb + m.e_H;
+    if (gl < ldm) lds[Vo + gl] = gl < nv ? dof(vf, gl) : 0.0f;
+    WSYNC();
+    const float4 *mr = reinterpret_cast<const float4 *>(lds + eb + m.e_M + i * ldm), *vv = reinterpret_cast<const float4 *>(lds + Vo);
+    float acc0 = 0, acc1 = 0;
+#pragma unroll 5
+    for (int c = 0; c < (ldm >> 2); ++c) {
+      const float4 a = mr[c], v = vv[c];
+      acc0 = __builtin_fmaf(a.x, v.x, __builtin_fmaf(a.y, v.y, acc0));
+      acc1 = __builtin_fmaf(a.z, v.z, __builtin_fmaf(a.w, v.w, acc1));
     }
-    return acc;
+    return acc0 + acc1;
   }
   DEV float row_dot(int vf) const {  // J[gl,:] . v over the row's static support
     const int r = gl, vo = dofoff(vf);
@@ -1088,19 +1098,19 @@ struct Env {
     WSYNC();
   }
   DEV void newton_direction() {  // Mgrad = (M + J' D_active J)^-1 grad, H packed lower-triangular
-    const int nv = m.nv, Mo = eb + m.e_M, Ho = eb + m.e_H, Jo = eb + m.e_J, ldc = m.ldc;
-    lds_copy<G>(Ho, Mo, TRI(nv), gl);
+    const int nv = m.nv, Mo = eb + m.e_M, Ho = eb + m.e_H, Jo = eb + m.e_J, ldc = m.ldc, ldm = m.ldm;
+    lds_copy<G>(Ho, Mo, nv * ldm, gl);
     WSYNC();
     PROF(19);
     const int row0 = m.neq + m.nlim;
     if (gl < row0) {  // equality + limit rows: a handful of entries each, from registers
       const float d = row(0, gl);
       if (d != 0.0f) {
-        atomicAdd(&lds[Ho + TRI(rd1) + rd1], d * rJ1 * rJ1);
+        atomicAdd(&lds[Ho + rd1 * ldm + rd1], d * rJ1 * rJ1);
         if (rd2 >= 0) {
-          atomicAdd(&lds[Ho + TRI(rd2) + rd2], d * rJ2 * rJ2);
-          const int hi = rd1 > rd2 ? rd1 : rd2, lo = rd1 > rd2 ? rd2 : rd1;
-          atomicAdd(&lds[Ho + TRI(hi) + lo], d * rJ1 * rJ2);
+          atomicAdd(&lds[Ho + rd2 * ldm + rd2], d * rJ2 * rJ2);
+          atomicAdd(&lds[Ho + rd1 * ldm + rd2], d * rJ1 * rJ2);
+          atomicAdd(&lds[Ho + rd2 * ldm + rd1], d * rJ1 * rJ2);
         }
       }
     }
@@ -1108,20 +1118,20 @@ struct Env {
     PROF(20);
     // contact rows: one lane per term (H entry, contact): the twelve operands of the contact's four pyramid rows are
     // fetched back to back, then reduced and added to the entry (ds_add_f32; entries are shared between contacts)
-    struct HEnt { int at; float v; };
+    struct HEnt { int at, at2; float v; };
     item_loop2<G>(m.nhent, gl,
       [&](int t) {
-        const int pk = CI(m.c_hent + t), ent = pk & 1023, cr0 = (pk >> 10) & 255, sa = (pk >> 18) & 31, sb = pk >> 23;
+        const int pk = CI(m.c_hent + t), di = pk & 31, dj = (pk >> 5) & 31, cr0 = (pk >> 10) & 255, sa = (pk >> 18) & 31, sb = pk >> 23;
         const int Jr = Jo + cr0 * ldc, Dr = eb + m.e_row + (row0 + cr0) * ROW_E;
         float d[4], ja[4], jb[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { d[k] = lds[Dr + k * ROW_E]; ja[k] = lds[Jr + k * ldc + sa]; jb[k] = lds[Jr + k * ldc + sb]; }
-        return HEnt{Ho + ent, (d[0] * ja[0] * jb[0] + d[1] * ja[1] * jb[1]) + (d[2] * ja[2] * jb[2] + d[3] * ja[3] * jb[3])};
+        return HEnt{Ho + di * ldm + dj, Ho + dj * ldm + di, (d[0] * ja[0] * jb[0] + d[1] * ja[1] * jb[1]) + (d[2] * ja[2] * jb[2] + d[3] * ja[3] * jb[3])};
       },
-      [&](int, const HEnt &r) { if (r.v != 0.0f) atomicAdd(&lds[r.at], r.v); });
+      [&](int, const HEnt &r) { if (r.v != 0.0f) { atomicAdd(&lds[r.at], r.v); if (r.at2 != r.at) atomicAdd(&lds[r.at2], r.v); } });
     WSYNC();
     PROF(14);
-    spd_solve<G>(m.nchol, Ho, nv, dofoff(D_GRAD), dofoff(D_MGRAD), gl, gb4, Ho);
+    spd_solve<G>(m.nchol, Ho, ldm, nv, dofoff(D_GRAD), dofoff(D_MGRAD), gl, gb4, Ho);
   }
 
   DEV LSPoint ls_point(float alpha, bool valid, bool iseq, float g0, float g1, float g2) const {
@@ -1222,7 +1232,7 @@ struct Env {
     constraint_force_and_grad();
     PROF(10);
     if (m.solver == 2) newton_direction();
-    else chol_solve<G>(m.nchol, eb + m.e_M, nv, eb + m.e_Lb, dofoff(D_GRAD), dofoff(D_MGRAD), false, gl, gb4);
+    else chol_solve<G>(m.nchol, eb + m.e_M, m.ldm, nv, eb + m.e_Lb, dofoff(D_GRAD), dofoff(D_MGRAD), false, gl, gb4);
     if (gl < nv) dof(D_SEARCH, gl) = -dof(D_MGRAD, gl);
     WSYNC();
     PROF(11);
@@ -1260,7 +1270,7 @@ struct Env {
           if (gl < nv) dof(D_SEARCH, gl) = -dof(D_MGRAD, gl);
         }
       } else {
-        chol_solve<G>(m.nchol, eb + m.e_M, nv, eb + m.e_Lb, dofoff(D_GRAD), dofoff(D_MGRAD), false, gl, gb4);
+        chol_solve<G>(m.nchol, eb + m.e_M, m.ldm, nv, eb + m.e_Lb, dofoff(D_GRAD), dofoff(D_MGRAD), false, gl, gb4);
         float num = gl < nv ? dof(D_GRAD, gl) * (dof(D_MGRAD, gl) - lds[eb + m.e_H + gl]) : 0.0f;
         num = gsum<G>(num);
         const float beta = fmaxf(0.0f, num / fmaxf(MINVAL, pg));
@@ -1290,8 +1300,8 @@ struct Env {
     PROF(7);
     // qacc_smooth = M^-1 qfrc_smooth.  Newton never reuses the factor: one-shot Gauss-Jordan solve;
     // CG keeps a Cholesky factor in Lb as its preconditioner.
-    if (m.solver == 2) spd_solve<G>(m.nchol, eb + m.e_M, nv, dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), gl, gb4, eb + m.e_H);
-    else chol_solve<G>(m.nchol, eb + m.e_M, nv, eb + m.e_Lb, dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), true, gl, gb4);
+    if (m.solver == 2) spd_solve<G>(m.nchol, eb + m.e_M, m.ldm, nv, dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), gl, gb4, eb + m.e_H);
+    else chol_solve<G>(m.nchol, eb + m.e_M, m.ldm, nv, eb + m.e_Lb, dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), true, gl, gb4);
     PROF(8);
     if (m.nefc == 0) {
       if (gl < nv) { dof(D_QACC, gl) = dof(D_ASMOOTH, gl); dof(D_FCON, gl) = 0; }
@@ -1309,12 +1319,10 @@ struct Env {
     const int nv = m.nv, Mo = eb + m.e_M, Ho = eb + m.e_H;
     const int qp = eb + m.e_qpos, qv = eb + m.e_qvel;
     if (!(m.disableflags & DIS_EULERDAMP)) {
-      lds_copy<G>(Ho, Mo, TRI(nv), gl);
-      if (gl < nv) dof(D_SEARCH, gl) = dof(D_FSMOOTH, gl) + dof(D_FCON, gl);
+      // M + dt*diag(damping) in place: this is the last reader of M in the step and the crb pass rewrites it
+      if (gl < nv) { dof(D_SEARCH, gl) = dof(D_FSMOOTH, gl) + dof(D_FCON, gl); lds[Mo + gl * m.ldm + gl] += m.dt * CF(m.c_dof + gl * DOF_S + 5); }
       WSYNC();
-      if (gl < nv) lds[Ho + TRI(gl) + gl] += m.dt * CF(m.c_dof + gl * DOF_S + 5);
-      WSYNC();
-      spd_solve<G>(m.nchol, Ho, nv, dofoff(D_SEARCH), dofoff(D_MV), gl, gb4, Ho);
+      spd_solve<G>(m.nchol, Mo, m.ldm, nv, dofoff(D_SEARCH), dofoff(D_MV), gl, gb4, Ho);
     } else {
       if (gl < nv) dof(D_MV, gl) = dof(D_QACC, gl);
       WSYNC();
@@ -1490,7 +1498,7 @@ amx_forward_kernel(const DevModel m_in, int nenv, const float *__restrict__ qpos
   if (o.qM)
     for (int k = gl; k < nv * nv; k += G) {
       const int r = k / nv, c = k % nv, hi = r > c ? r : c, lo = r > c ? c : r;
-      o.qM[(size_t)e * nv * nv + k] = lds[eb + m.e_M + TRI(hi) + lo];
+      o.qM[(size_t)e * nv * nv + k] = lds[eb + m.e_M + hi * m.ldm + lo];
     }
   if (o.xpos)
     for (int k = gl; k < m.nb * 3; k += G) o.xpos[(size_t)e * m.nb * 3 + k] = env.body(k % 3, k / 3);
