@@ -57,6 +57,7 @@ struct Image {
   void i(int x) { float t; memcpy(&t, &x, 4); v.push_back(t); }
   int reserve(int n) { int o = size(); v.resize(v.size() + (n > 0 ? n : 1), 0.f); return o; }
   void seti(int off, int x) { memcpy(&v[off], &x, 4); }
+  int geti(int off) const { int x; memcpy(&x, &v[off], 4); return x; }
   void setf(int off, double x) { v[off] = (float)x; }
 };
 const int PAIR_NCON[6] = {1, 2, 4, 1, 1, 1};
@@ -280,6 +281,14 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
   m.nM = (int)Mlist.size(); m.c_M = add_ints(Mlist);
   m.c_dofact = add_ints(dofact); m.c_pairdof = add_ints(pairdof); m.c_jac = add_ints(jac_items); m.c_hent = add_ints(hent);
   m.c_conpair = add_ints(con_pair); m.c_rootbody = add_ints(roots);
+  {
+    std::vector<int> slotmap((size_t)32 * std::max(ncon, 1), -1);
+    for (int c = 0; c < ncon; c++) {
+      const int o = m.c_pair + con_pair[c] * PAIR_S, d0 = im.geti(o + 9), dn = im.geti(o + 10);
+      for (int t = 0; t < dn; t++) slotmap[(size_t)32 * c + (pairdof[d0 + t] & 255)] = t;
+    }
+    m.c_slot = add_ints(slotmap);
+  }
   {
     std::vector<int> adr(nv + 1, 0), flat;
     for (int i = 0; i < nv; i++) { adr[i] = (int)flat.size(); flat.insert(flat.end(), dofmem[i].begin(), dofmem[i].end()); }

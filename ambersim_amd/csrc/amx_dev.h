@@ -38,7 +38,7 @@ struct DevModel {
   // bases inside the constant image (float offsets)
   int c_body, c_jnt, c_dof, c_act, c_geom, c_pair, c_lim, c_eq;
   int c_qpos0 /*[nq]*/, c_child, c_M /*packed i|j<<8*/, c_dofact, c_pairdof /*packed dof|sign<<8*/, c_jac /*packed contact|slot<<6|dof<<11|chain sign<<16|pair<<18*/,
-      c_hent /*[nhent] terms: packed dof_i|dof_j<<5|first contact row<<10|slot_i<<18|slot_j<<23 (dof_j <= dof_i)*/, c_dofmemadr /*[nv+1]*/, c_dofmem /*terms: packed first contact row|slot<<8*/, c_conpair /*[ncon]*/, c_vert, c_rootbody;
+      c_hent /*[nhent] terms: packed dof_i|dof_j<<5|first contact row<<10|slot_i<<18|slot_j<<23 (dof_j <= dof_i)*/, c_dofmemadr /*[nv+1]*/, c_dofmem /*terms: packed first contact row|slot<<8*/, c_conpair /*[ncon]*/, c_vert, c_rootbody, c_slot /*[ncon][32]: position of dof j in the contact's dof chain, -1 if absent*/;
   // bases inside one environment slab (float offsets from the slab start)
   int e_qpos, e_qvel, e_ctrl;
   int e_body /* records [nb][BODY_E]: xpos 0-2 xquat 3-6 cinert 7-16 (then cfrc 7-12) crb 17-26 (then cvel 17-22 cacc 23-28) */;

@@ -286,60 +286,78 @@ template <int N, int G, int J> DEV void gj_pivot(float (&a)[N], float &b, int gl
 #pragma unroll
   for (int k = J + 1; k < ksplit; ++k) a[k] = __builtin_fmaf(-f, u[k], a[k]);
 }
-// Pivot-row broadcast through LDS memory (groups narrower than a wave): the pivot lane of every group stores its
-// remaining row and right-hand side as 16-byte chunks into the group's scratch row, and every lane reads the chunks
-// back (same address within a group: a broadcast read).  A pivot row of n values costs ceil(n/4) ds_read_b128
-// instead of n ds_bpermute_b32 - the crossbar is shared by the whole CU and was the limiter (see profiles/).
-// LDS operations of one wave execute in order, so no barrier is needed between the store and the loads or between
-// pivots.  Chunk c holds columns 4c..4c+3; column N is the right-hand side.
-#ifndef AMX_GJ_LDS
-#define AMX_GJ_LDS 0
-#endif
-#ifndef AMX_GJ_LDS_MAXN
-#define AMX_GJ_LDS_MAXN 24
-#endif
-template <int N, int G, int J> DEV void gj_pivot_lds(float (&a)[N], float &b, int gl, int sbuf) {
-  constexpr int NC = (N + 4) / 4, C0 = J / 4;  // chunks [C0, NC) cover columns J..N
-  float4 *row = reinterpret_cast<float4 *>(lds + sbuf);
-  if (gl == J) {
-#pragma unroll
-    for (int c = C0; c < NC; ++c) {
-      float4 v;
-      v.x = 4 * c < N ? a[4 * c < N ? 4 * c : 0] : (4 * c == N ? b : 0.0f);
-      v.y = 4 * c + 1 < N ? a[4 * c + 1 < N ? 4 * c + 1 : 0] : (4 * c + 1 == N ? b : 0.0f);
-      v.z = 4 * c + 2 < N ? a[4 * c + 2 < N ? 4 * c + 2 : 0] : (4 * c + 2 == N ? b : 0.0f);
-      v.w = 4 * c + 3 < N ? a[4 * c + 3 < N ? 4 * c + 3 : 0] : (4 * c + 3 == N ? b : 0.0f);
-      row[c] = v;
-    }
-  }
-  // cross-lane hand-off: keeps the compiler from hoisting the other lanes' loads above the store
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  float u[4 * NC];
-#pragma unroll
-  for (int c = C0; c < NC; ++c) {
-    const float4 v = row[c];
-    u[4 * c] = v.x; u[4 * c + 1] = v.y; u[4 * c + 2] = v.z; u[4 * c + 3] = v.w;
-  }
-  float f = a[J] * __builtin_amdgcn_rcpf(fmaxf(u[J], MINVAL));
-  f = gl == J ? 0.0f : f;  // the pivot row itself is left alone
-  b = __builtin_fmaf(-f, u[N], b);
-#pragma unroll
-  for (int k = J + 1; k < N; ++k) a[k] = __builtin_fmaf(-f, u[k], a[k]);
-}
 template <int N, int G, int J> struct GJ {
-  static DEV void run(float (&a)[N], float &b, int gl, int gb4, int sbuf) {
-    if (AMX_GJ_LDS && G < 64 && N <= AMX_GJ_LDS_MAXN) gj_pivot_lds<N, G, J>(a, b, gl, sbuf);
-    else gj_pivot<N, G, J>(a, b, gl, gb4);
-    GJ<N, G, J + 1>::run(a, b, gl, gb4, sbuf);
+  static DEV void run(float (&a)[N], float &b, int gl, int gb4) {
+    gj_pivot<N, G, J>(a, b, gl, gb4);
+    GJ<N, G, J + 1>::run(a, b, gl, gb4);
   }
 };
-template <int N, int G> struct GJ<N, G, N> { static DEV void run(float (&)[N], float &, int, int, int) {} };
+template <int N, int G> struct GJ<N, G, N> { static DEV void run(float (&)[N], float &, int, int) {} };
 
-// `sbuf`: LDS float offset (multiple of 4) of N+4 floats of scratch private to the group; it may alias the matrix,
-// whose rows are all in registers before the first pivot stores.
+typedef float v32f __attribute__((ext_vector_type(32)));
+
+// H = M + J' D J on the matrix cores, for one wave (G = 32: the wave's two environments are the two 32x32 blocks of
+// v_mfma_f32_32x32x1_2b_f32; G = 64: block 1 idles).  Lane (b, j) feeds block b with column j of one contact-Jacobian row
+// per instruction: A = D_r J_r[j], B = J_r[j], a rank-1 update of H_b.  The accumulator holds H_b[8q+4h+r][j] in register
+// 16b+4q+r of lane (h, j).  H is symmetric, so column j is row j: one v_permlane32_swap per register pair hands lane
+// (b, j) the entries of row j of its own environment as ready-made 16-byte chunks (columns 8q..8q+3 and 8q+4..8q+7),
+// which are added to the chunk of M and stored as row j of the full matrix H.  Out of line: the 32 accumulator
+// registers stay out of the caller's and the solver's register budgets.
+//   crows: active contact rows (bit 4c+r), OR-ed over the environments of the wave; an inactive row has D = 0 anyway,
+//          the mask only skips contacts that are inactive everywhere.
+template <int G>
+__device__ __noinline__ void build_H_mfma(int M_off, int H_off, int ld, int n, unsigned long long crows, int ncon, int row_base, int J_base, int ldc,
+                                          int slot_base, int gl) {
+  const int j = gl & 31;
+  const bool lane_ok = G == 32 || gl < 32;
+  v32f C = {};
+  // one bit per contact that is active in some environment of the wave (wave-uniform scalar loop over the set bits)
+  unsigned long long cm = (crows | (crows >> 1) | (crows >> 2) | (crows >> 3)) & 0x1111111111111111ull;
+  while (cm != 0ull) {
+    const int c = __builtin_ctzll(cm) >> 2;
+    cm &= cm - 1ull;
+    const int slot = CI(slot_base + 32 * c + j);
+    const bool has = lane_ok && slot >= 0;
+    const int Jr = J_base + 4 * c * ldc + (has ? slot : 0), Dr = row_base + 4 * c * ROW_E;
+    float d[4], jv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { d[r] = lds[Dr + r * ROW_E]; jv[r] = lds[Jr + r * ldc]; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = has ? jv[r] : 0.0f;
+      C = __builtin_amdgcn_mfma_f32_32x32x1f32(d[r] * v, v, C, 0, 0, 0);
+    }
+  }
+  const bool writer = lane_ok && j < n;
+  const int jr = (writer ? j : 0) * ld;
+  const float4 *mrow = reinterpret_cast<const float4 *>(lds + M_off + jr);
+  float4 *hrow = reinterpret_cast<float4 *>(lds + H_off + jr);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (8 * q >= ld) break;  // wave-uniform: no such columns
+    unsigned lo[4], hi[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      // new vdst: own lower half + the other register's lower half in the upper lanes = rows 8q+r of the lane's block;
+      // new vsrc: rows 8q+4+r
+      auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(C[4 * q + r]), __float_as_uint(C[16 + 4 * q + r]), false, false);
+      lo[r] = sw[0]; hi[r] = sw[1];
+    }
+    float4 m0 = mrow[2 * q];
+    m0.x += __uint_as_float(lo[0]); m0.y += __uint_as_float(lo[1]); m0.z += __uint_as_float(lo[2]); m0.w += __uint_as_float(lo[3]);
+    if (writer) hrow[2 * q] = m0;
+    if (8 * q + 4 < ld) {
+      float4 m1 = mrow[2 * q + 1];
+      m1.x += __uint_as_float(hi[0]); m1.y += __uint_as_float(hi[1]); m1.z += __uint_as_float(hi[2]); m1.w += __uint_as_float(hi[3]);
+      if (writer) hrow[2 * q + 1] = m1;
+    }
+    __builtin_amdgcn_sched_barrier(0);  // one register quad at a time: keeps this function inside the caller-saved registers
+  }
+  WSYNC();
+}
+
 template <int N, int G>
-__device__ __noinline__ void spd_solve_rows(int A_off, int ld, int n, int rhs_off, int x_off, int vstride, int gl, int gb4, int sbuf) {
+__device__ __noinline__ void spd_solve_rows(int A_off, int ld, int n, int rhs_off, int x_off, int vstride, int gl, int gb4) {
   float a[N];
   const int li = gl < n ? gl : 0;
   // row li of the full symmetric matrix: 16-byte aligned, ld >= ceil4(n) floats long, so whole b128 chunks are in bounds
@@ -357,7 +375,7 @@ __device__ __noinline__ void spd_solve_rows(int A_off, int ld, int n, int rhs_of
   }
   float b = lds[rhs_off + li * vstride];
   b = gl < n ? b : 0.0f;
-  GJ<N, G, 0>::run(a, b, gl, gb4, sbuf);
+  GJ<N, G, 0>::run(a, b, gl, gb4);
   // the matrix is now diagonal: x_i = b_i / a_ii.  a[gl] is a runtime register index, so select it.
   float d = 1.0f;
 #pragma unroll
@@ -367,12 +385,12 @@ __device__ __noinline__ void spd_solve_rows(int A_off, int ld, int n, int rhs_of
 }
 
 template <int G>
-__device__ __noinline__ void spd_solve(int nchol, int A_off, int ld, int n, int rhs_off, int x_off, int gl, int gb4, int sbuf) {
+__device__ __noinline__ void spd_solve(int nchol, int A_off, int ld, int n, int rhs_off, int x_off, int gl, int gb4) {
   const int vstride = DOF_E;
   // one instantiation per even size (a pivot costs a crossbar round trip, so padding rows are not free);
   // a group of G lanes holds at most G rows
-#define AMX_SPD_CASE(NN) else if (nchol <= NN && NN <= G) spd_solve_rows<(NN <= G ? NN : 4), G>(A_off, ld, n, rhs_off, x_off, vstride, gl, gb4, sbuf);
-  if (nchol <= 4) spd_solve_rows<4, G>(A_off, ld, n, rhs_off, x_off, vstride, gl, gb4, sbuf);
+#define AMX_SPD_CASE(NN) else if (nchol <= NN && NN <= G) spd_solve_rows<(NN <= G ? NN : 4), G>(A_off, ld, n, rhs_off, x_off, vstride, gl, gb4);
+  if (nchol <= 4) spd_solve_rows<4, G>(A_off, ld, n, rhs_off, x_off, vstride, gl, gb4);
   AMX_SPD_CASE(6) AMX_SPD_CASE(8) AMX_SPD_CASE(10) AMX_SPD_CASE(12) AMX_SPD_CASE(14) AMX_SPD_CASE(16) AMX_SPD_CASE(18)
   AMX_SPD_CASE(20) AMX_SPD_CASE(22) AMX_SPD_CASE(24) AMX_SPD_CASE(26) AMX_SPD_CASE(28) AMX_SPD_CASE(30) AMX_SPD_CASE(32)
 #undef AMX_SPD_CASE
@@ -429,14 +447,17 @@ template <int G, class F, class C> DEV void item_loop2(int n, int gl, F fetch, C
     if (tb < n) commit(tb, vb);
   }
 }
-// lds[dst + e] = lds[src + e], e < n, four loads in flight per lane
+// lds[dst + e] = lds[src + e], e < n; dst, src and n are multiples of 4 floats: 16-byte moves, four in flight per lane
 template <int G> DEV void lds_copy(int dst, int src, int n, int gl) {
-  for (int e0 = 0; e0 < n; e0 += 4 * G) {
-    float v[4];
+  const float4 *s = reinterpret_cast<const float4 *>(lds + src);
+  float4 *d = reinterpret_cast<float4 *>(lds + dst);
+  const int n4 = n >> 2;
+  for (int e0 = 0; e0 < n4; e0 += 4 * G) {
+    float4 v[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { const int e = e0 + k * G + gl; v[k] = lds[src + (e < n ? e : n - 1)]; }
+    for (int k = 0; k < 4; ++k) { const int e = e0 + k * G + gl; v[k] = s[e < n4 ? e : n4 - 1]; }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { const int e = e0 + k * G + gl; if (e < n) lds[dst + e] = v[k]; }
+    for (int k = 0; k < 4; ++k) { const int e = e0 + k * G + gl; if (e < n4) d[e] = v[k]; }
   }
 }
 
@@ -456,6 +477,7 @@ struct Env {
   int rchain[4], rdn, rcr;  // contact row `gl`: its pair's dof list (<=16 dofs, one byte each), its length, its contact-row index
   float rJ1, rJ2;  // equality / limit row `gl`: Jacobian entries on dofs rd1, rd2 (contact rows live in LDS, chain-compressed)
   int rd1, rd2;
+  bool ract;  // row role: the row is active at the current iterate (set by constraint_force_and_grad)
   PROF_DECL
 
   DEV Env(const DevModel &m_, int eb_, int gl_, int gb4_) : m(m_), eb(eb_), gl(gl_), gb4(gb4_) {
@@ -466,6 +488,7 @@ struct Env {
     const int dr = m.c_dof + (lane < m.nv ? lane : 0) * DOF_S;
     d_body = CI(dr); d_jnt = CI(dr + 1); d_kind = CI(dr + 2); d_axis = CI(dr + 3); d_root = CI(dr + 8);
     rD = rAref = rJaref = rJv = rJ1 = rJ2 = 0.0f;
+    ract = false;
     rd1 = 0; rd2 = -1;
     if (lane < m.neq) { const int er = m.c_eq + lane * EQ_S; rd1 = CI(er + 1); rd2 = CI(er + 3); }
     else if (lane < m.neq + m.nlim) rd1 = CI(m.c_lim + (lane - m.neq) * LIM_S + 1);
@@ -1070,6 +1093,7 @@ struct Env {
   DEV void constraint_force_and_grad() {
     const int Jo = eb + m.e_J, ldc = m.ldc, row0 = m.neq + m.nlim;
     const bool act = gl < m.nefc && (rJaref < 0 || gl < m.neq) && rD > 0;
+    ract = act;
     const float f = act ? -rD * rJaref : 0.0f;
     if (gl < m.nefc) { row(0, gl) = act ? rD : 0.0f; row(1, gl) = f; }
     WSYNC();
@@ -1097,41 +1121,57 @@ struct Env {
     if (gl < m.nv) dof(D_GRAD, gl) = dof(D_MA, gl) - dof(D_FSMOOTH, gl) - dof(D_FCON, gl);
     WSYNC();
   }
-  DEV void newton_direction() {  // Mgrad = (M + J' D_active J)^-1 grad, H packed lower-triangular
+  // Mgrad = (M + J' D_active J)^-1 grad, H a full symmetric matrix in LDS.
+  // G >= 32: the contact rows' J'DJ comes from the matrix cores and lands in H together with M (build_H_mfma); equality and
+  // limit rows, rarely active and one or two entries each, are added with LDS atomics only when one of them is active.
+  // G = 16 (four environments per wave do not map onto the two MFMA blocks): copy of M + atomics for every row kind.
+  DEV void newton_direction() {
     const int nv = m.nv, Mo = eb + m.e_M, Ho = eb + m.e_H, Jo = eb + m.e_J, ldc = m.ldc, ldm = m.ldm;
-    lds_copy<G>(Ho, Mo, nv * ldm, gl);
-    WSYNC();
-    PROF(19);
     const int row0 = m.neq + m.nlim;
-    if (gl < row0) {  // equality + limit rows: a handful of entries each, from registers
-      const float d = row(0, gl);
-      if (d != 0.0f) {
-        atomicAdd(&lds[Ho + rd1 * ldm + rd1], d * rJ1 * rJ1);
-        if (rd2 >= 0) {
-          atomicAdd(&lds[Ho + rd2 * ldm + rd2], d * rJ2 * rJ2);
-          atomicAdd(&lds[Ho + rd1 * ldm + rd2], d * rJ1 * rJ2);
-          atomicAdd(&lds[Ho + rd2 * ldm + rd1], d * rJ1 * rJ2);
+    bool scalar_rows = true;  // wave-uniform: some equality / limit row is active
+    if (G >= 32) {
+      const unsigned long long act = __ballot(ract);
+      const unsigned long long rows = G == 32 ? ((act | (act >> 32)) & 0xFFFFFFFFull) : act;  // row active in any environment of the wave
+      scalar_rows = (rows & ((1ull << row0) - 1ull)) != 0ull;
+      build_H_mfma<G>(Mo, Ho, ldm, nv, row0 < 64 ? rows >> row0 : 0ull, m.ncon, eb + m.e_row + row0 * ROW_E, Jo, ldc, m.c_slot, gl);
+    } else {
+      lds_copy<G>(Ho, Mo, nv * ldm, gl);
+      WSYNC();
+    }
+    PROF(19);
+    if (scalar_rows) {
+      if (gl < row0) {  // equality + limit rows: a handful of entries each, from registers
+        const float d = row(0, gl);
+        if (d != 0.0f) {
+          atomicAdd(&lds[Ho + rd1 * ldm + rd1], d * rJ1 * rJ1);
+          if (rd2 >= 0) {
+            atomicAdd(&lds[Ho + rd2 * ldm + rd2], d * rJ2 * rJ2);
+            atomicAdd(&lds[Ho + rd1 * ldm + rd2], d * rJ1 * rJ2);
+            atomicAdd(&lds[Ho + rd2 * ldm + rd1], d * rJ1 * rJ2);
+          }
         }
       }
+      WSYNC();
     }
-    WSYNC();
     PROF(20);
-    // contact rows: one lane per term (H entry, contact): the twelve operands of the contact's four pyramid rows are
-    // fetched back to back, then reduced and added to the entry (ds_add_f32; entries are shared between contacts)
-    struct HEnt { int at, at2; float v; };
-    item_loop2<G>(m.nhent, gl,
-      [&](int t) {
-        const int pk = CI(m.c_hent + t), di = pk & 31, dj = (pk >> 5) & 31, cr0 = (pk >> 10) & 255, sa = (pk >> 18) & 31, sb = pk >> 23;
-        const int Jr = Jo + cr0 * ldc, Dr = eb + m.e_row + (row0 + cr0) * ROW_E;
-        float d[4], ja[4], jb[4];
+    if (G < 32) {
+      // contact rows: one lane per term (H entry, contact): the twelve operands of the contact's four pyramid rows are
+      // fetched back to back, then reduced and added to the entry (ds_add_f32; entries are shared between contacts)
+      struct HEnt { int at, at2; float v; };
+      item_loop2<G>(m.nhent, gl,
+        [&](int t) {
+          const int pk = CI(m.c_hent + t), di = pk & 31, dj = (pk >> 5) & 31, cr0 = (pk >> 10) & 255, sa = (pk >> 18) & 31, sb = pk >> 23;
+          const int Jr = Jo + cr0 * ldc, Dr = eb + m.e_row + (row0 + cr0) * ROW_E;
+          float d[4], ja[4], jb[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { d[k] = lds[Dr + k * ROW_E]; ja[k] = lds[Jr + k * ldc + sa]; jb[k] = lds[Jr + k * ldc + sb]; }
-        return HEnt{Ho + di * ldm + dj, Ho + dj * ldm + di, (d[0] * ja[0] * jb[0] + d[1] * ja[1] * jb[1]) + (d[2] * ja[2] * jb[2] + d[3] * ja[3] * jb[3])};
-      },
-      [&](int, const HEnt &r) { if (r.v != 0.0f) { atomicAdd(&lds[r.at], r.v); if (r.at2 != r.at) atomicAdd(&lds[r.at2], r.v); } });
-    WSYNC();
+          for (int k = 0; k < 4; ++k) { d[k] = lds[Dr + k * ROW_E]; ja[k] = lds[Jr + k * ldc + sa]; jb[k] = lds[Jr + k * ldc + sb]; }
+          return HEnt{Ho + di * ldm + dj, Ho + dj * ldm + di, (d[0] * ja[0] * jb[0] + d[1] * ja[1] * jb[1]) + (d[2] * ja[2] * jb[2] + d[3] * ja[3] * jb[3])};
+        },
+        [&](int, const HEnt &r) { if (r.v != 0.0f) { atomicAdd(&lds[r.at], r.v); if (r.at2 != r.at) atomicAdd(&lds[r.at2], r.v); } });
+      WSYNC();
+    }
     PROF(14);
-    spd_solve<G>(m.nchol, Ho, ldm, nv, dofoff(D_GRAD), dofoff(D_MGRAD), gl, gb4, Ho);
+    spd_solve<G>(m.nchol, Ho, ldm, nv, dofoff(D_GRAD), dofoff(D_MGRAD), gl, gb4);
   }
 
   DEV LSPoint ls_point(float alpha, bool valid, bool iseq, float g0, float g1, float g2) const {
@@ -1300,7 +1340,7 @@ struct Env {
     PROF(7);
     // qacc_smooth = M^-1 qfrc_smooth.  Newton never reuses the factor: one-shot Gauss-Jordan solve;
     // CG keeps a Cholesky factor in Lb as its preconditioner.
-    if (m.solver == 2) spd_solve<G>(m.nchol, eb + m.e_M, m.ldm, nv, dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), gl, gb4, eb + m.e_H);
+    if (m.solver == 2) spd_solve<G>(m.nchol, eb + m.e_M, m.ldm, nv, dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), gl, gb4);
     else chol_solve<G>(m.nchol, eb + m.e_M, m.ldm, nv, eb + m.e_Lb, dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), true, gl, gb4);
     PROF(8);
     if (m.nefc == 0) {
@@ -1322,7 +1362,7 @@ struct Env {
       // M + dt*diag(damping) in place: this is the last reader of M in the step and the crb pass rewrites it
       if (gl < nv) { dof(D_SEARCH, gl) = dof(D_FSMOOTH, gl) + dof(D_FCON, gl); lds[Mo + gl * m.ldm + gl] += m.dt * CF(m.c_dof + gl * DOF_S + 5); }
       WSYNC();
-      spd_solve<G>(m.nchol, Mo, m.ldm, nv, dofoff(D_SEARCH), dofoff(D_MV), gl, gb4, Ho);
+      spd_solve<G>(m.nchol, Mo, m.ldm, nv, dofoff(D_SEARCH), dofoff(D_MV), gl, gb4);
     } else {
       if (gl < nv) dof(D_MV, gl) = dof(D_QACC, gl);
       WSYNC();
