@@ -305,53 +305,83 @@ typedef float v32f __attribute__((ext_vector_type(32)));
 // registers stay out of the caller's and the solver's register budgets.
 //   crows: active contact rows (bit 4c+r), OR-ed over the environments of the wave; an inactive row has D = 0 anyway,
 //          the mask only skips contacts that are inactive everywhere.
+typedef float v16f __attribute__((ext_vector_type(16)));
 template <int G>
 __device__ __noinline__ void build_H_mfma(int M_off, int H_off, int ld, int n, unsigned long long crows, int ncon, int row_base, int J_base, int ldc,
                                           int slot_base, int gl) {
-  const int j = gl & 31;
-  const bool lane_ok = G == 32 || gl < 32;
-  v32f C = {};
+  const int j = gl & 31, h = gl >> 5;
   // one bit per contact that is active in some environment of the wave (wave-uniform scalar loop over the set bits)
   unsigned long long cm = (crows | (crows >> 1) | (crows >> 2) | (crows >> 3)) & 0x1111111111111111ull;
-  while (cm != 0ull) {
-    const int c = __builtin_ctzll(cm) >> 2;
-    cm &= cm - 1ull;
-    const int slot = CI(slot_base + 32 * c + j);
-    const bool has = lane_ok && slot >= 0;
-    const int Jr = J_base + 4 * c * ldc + (has ? slot : 0), Dr = row_base + 4 * c * ROW_E;
-    float d[4], jv[4];
+  unsigned lo[4][4], hi[4][4];  // after the swaps: lo[q][r] = H[j][8q+r], hi[q][r] = H[j][8q+4+r] of the lane's environment
+  if (G == 32) {
+    v32f C = {};
+    while (cm != 0ull) {
+      const int c = __builtin_ctzll(cm) >> 2;
+      cm &= cm - 1ull;
+      const int slot = CI(slot_base + 32 * c + j);
+      const bool has = slot >= 0;
+      const int Jr = J_base + 4 * c * ldc + (has ? slot : 0), Dr = row_base + 4 * c * ROW_E;
+      float d[4], jv[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { d[r] = lds[Dr + r * ROW_E]; jv[r] = lds[Jr + r * ldc]; }
+      for (int r = 0; r < 4; ++r) { d[r] = lds[Dr + r * ROW_E]; jv[r] = lds[Jr + r * ldc]; }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float v = has ? jv[r] : 0.0f;
-      C = __builtin_amdgcn_mfma_f32_32x32x1f32(d[r] * v, v, C, 0, 0, 0);
+      for (int r = 0; r < 4; ++r) {
+        const float v = has ? jv[r] : 0.0f;
+        C = __builtin_amdgcn_mfma_f32_32x32x1f32(d[r] * v, v, C, 0, 0, 0);
+      }
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        // new vdst: own lower half + the other register's lower half in the upper lanes = rows 8q+r of the lane's block;
+        // new vsrc: rows 8q+4+r
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(C[4 * q + r]), __float_as_uint(C[16 + 4 * q + r]), false, false);
+        lo[q][r] = sw[0]; hi[q][r] = sw[1];
+      }
+  } else {
+    // one environment per wave: the single-block K = 2 instruction takes two Jacobian rows at a time (lanes 32-63 feed the
+    // second), two instructions per contact
+    v16f C = {};
+    while (cm != 0ull) {
+      const int c = __builtin_ctzll(cm) >> 2;
+      cm &= cm - 1ull;
+      const int slot = CI(slot_base + 32 * c + j);
+      const bool has = slot >= 0;
+      const int Jr = J_base + (4 * c + h) * ldc + (has ? slot : 0), Dr = row_base + (4 * c + h) * ROW_E;
+      float d[2], jv[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) { d[s2] = lds[Dr + 2 * s2 * ROW_E]; jv[s2] = lds[Jr + 2 * s2 * ldc]; }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const float v = has ? jv[s2] : 0.0f;
+        C = __builtin_amdgcn_mfma_f32_32x32x2f32(d[s2] * v, v, C, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        // lanes 0-31 keep rows 8q+r and receive rows 8q+4+r from lanes 32-63
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(C[4 * q + r]), 0u, false, false);
+        lo[q][r] = sw[0]; hi[q][r] = sw[1];
+      }
   }
-  const bool writer = lane_ok && j < n;
+  const bool writer = (G == 32 || gl < 32) && j < n;
   const int jr = (writer ? j : 0) * ld;
   const float4 *mrow = reinterpret_cast<const float4 *>(lds + M_off + jr);
   float4 *hrow = reinterpret_cast<float4 *>(lds + H_off + jr);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     if (8 * q >= ld) break;  // wave-uniform: no such columns
-    unsigned lo[4], hi[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      // new vdst: own lower half + the other register's lower half in the upper lanes = rows 8q+r of the lane's block;
-      // new vsrc: rows 8q+4+r
-      auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(C[4 * q + r]), __float_as_uint(C[16 + 4 * q + r]), false, false);
-      lo[r] = sw[0]; hi[r] = sw[1];
-    }
     float4 m0 = mrow[2 * q];
-    m0.x += __uint_as_float(lo[0]); m0.y += __uint_as_float(lo[1]); m0.z += __uint_as_float(lo[2]); m0.w += __uint_as_float(lo[3]);
+    m0.x += __uint_as_float(lo[q][0]); m0.y += __uint_as_float(lo[q][1]); m0.z += __uint_as_float(lo[q][2]); m0.w += __uint_as_float(lo[q][3]);
     if (writer) hrow[2 * q] = m0;
     if (8 * q + 4 < ld) {
       float4 m1 = mrow[2 * q + 1];
-      m1.x += __uint_as_float(hi[0]); m1.y += __uint_as_float(hi[1]); m1.z += __uint_as_float(hi[2]); m1.w += __uint_as_float(hi[3]);
+      m1.x += __uint_as_float(hi[q][0]); m1.y += __uint_as_float(hi[q][1]); m1.z += __uint_as_float(hi[q][2]); m1.w += __uint_as_float(hi[q][3]);
       if (writer) hrow[2 * q + 1] = m1;
     }
-    __builtin_amdgcn_sched_barrier(0);  // one register quad at a time: keeps this function inside the caller-saved registers
   }
   WSYNC();
 }
