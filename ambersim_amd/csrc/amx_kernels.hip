@@ -307,12 +307,23 @@ typedef float v32f __attribute__((ext_vector_type(32)));
 //          the mask only skips contacts that are inactive everywhere.
 typedef float v16f __attribute__((ext_vector_type(16)));
 template <int G>
-__device__ __noinline__ void build_H_mfma(int M_off, int H_off, int ld, int n, unsigned long long crows, int ncon, int row_base, int J_base, int ldc,
-                                          int slot_base, int gl) {
+__device__ __noinline__ void build_H_mfma(int M_off, int H_off, int ld_, int n_, unsigned long long crows_, int ncon, int row_base, int J_base, int ldc_,
+                                          int slot_base_, int gl) {
+  // arguments of an out-of-line function arrive in vector registers; these are wave-uniform, and saying so keeps the
+  // loops and the chunk guards below on the scalar unit
+  const int ld = __builtin_amdgcn_readfirstlane(ld_), n = __builtin_amdgcn_readfirstlane(n_), ldc = __builtin_amdgcn_readfirstlane(ldc_);
+  const int slot_base = __builtin_amdgcn_readfirstlane(slot_base_);
+  const unsigned long long crows = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(crows_ >> 32)) << 32) |
+                                   (unsigned)__builtin_amdgcn_readfirstlane((int)crows_);
   const int j = gl & 31, h = gl >> 5;
   // one bit per contact that is active in some environment of the wave (wave-uniform scalar loop over the set bits)
   unsigned long long cm = (crows | (crows >> 1) | (crows >> 2) | (crows >> 3)) & 0x1111111111111111ull;
   unsigned lo[4][4], hi[4][4];  // after the swaps: lo[q][r] = H[j][8q+r], hi[q][r] = H[j][8q+4+r] of the lane's environment
+  const bool writer = (G == 32 || gl < 32) && j < n;
+  const int jr = (writer ? j : 0) * ld;
+  const float4 *mrow = reinterpret_cast<const float4 *>(lds + M_off + jr);
+  float4 *hrow = reinterpret_cast<float4 *>(lds + H_off + jr);
+  const int nch = ld >> 2;  // 16-byte chunks per row
   if (G == 32) {
     v32f C = {};
     while (cm != 0ull) {
@@ -367,20 +378,20 @@ __device__ __noinline__ void build_H_mfma(int M_off, int H_off, int ld, int n, u
         lo[q][r] = sw[0]; hi[q][r] = sw[1];
       }
   }
-  const bool writer = (G == 32 || gl < 32) && j < n;
-  const int jr = (writer ? j : 0) * ld;
-  const float4 *mrow = reinterpret_cast<const float4 *>(lds + M_off + jr);
-  float4 *hrow = reinterpret_cast<float4 *>(lds + H_off + jr);
+  // H row = M row + J'DJ row, two halves of four chunks: the four loads of a half are in flight together
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    if (8 * q >= ld) break;  // wave-uniform: no such columns
-    float4 m0 = mrow[2 * q];
-    m0.x += __uint_as_float(lo[q][0]); m0.y += __uint_as_float(lo[q][1]); m0.z += __uint_as_float(lo[q][2]); m0.w += __uint_as_float(lo[q][3]);
-    if (writer) hrow[2 * q] = m0;
-    if (8 * q + 4 < ld) {
-      float4 m1 = mrow[2 * q + 1];
-      m1.x += __uint_as_float(hi[q][0]); m1.y += __uint_as_float(hi[q][1]); m1.z += __uint_as_float(hi[q][2]); m1.w += __uint_as_float(hi[q][3]);
-      if (writer) hrow[2 * q + 1] = m1;
+  for (int half = 0; half < 2; ++half) {
+    if (4 * half >= nch) break;  // wave-uniform
+    float4 mc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int c = 4 * half + k; mc[k] = mrow[c < nch ? c : 0]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = 4 * half + k, q = c >> 1;
+      const unsigned *src = (c & 1) ? hi[q] : lo[q];
+      float4 v = mc[k];
+      v.x += __uint_as_float(src[0]); v.y += __uint_as_float(src[1]); v.z += __uint_as_float(src[2]); v.w += __uint_as_float(src[3]);
+      if (writer && c < nch) hrow[c] = v;
     }
   }
   WSYNC();
