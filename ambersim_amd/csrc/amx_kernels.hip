@@ -1173,7 +1173,7 @@ struct Env {
     if (G >= 32) {
       const unsigned long long act = __ballot(ract);
       const unsigned long long rows = G == 32 ? ((act | (act >> 32)) & 0xFFFFFFFFull) : act;  // row active in any environment of the wave
-      scalar_rows = (rows & ((1ull << row0) - 1ull)) != 0ull;
+      scalar_rows = (rows & (row0 >= 64 ? ~0ull : (1ull << row0) - 1ull)) != 0ull;
       build_H_mfma<G>(Mo, Ho, ldm, nv, row0 < 64 ? rows >> row0 : 0ull, m.ncon, eb + m.e_row + row0 * ROW_E, Jo, ldc, m.c_slot, gl);
     } else {
       lds_copy<G>(Ho, Mo, nv * ldm, gl);
