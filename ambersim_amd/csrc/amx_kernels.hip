@@ -235,56 +235,22 @@ __device__ __noinline__ void chol_solve_rows(int A_off, int ld, int n, int L_off
 // its own column-j entry by 1/pivot and updates its row and right-hand side.  No substitutions, no LDS
 // traffic besides the initial row load, and one cross-lane latency per pivot instead of two plus 2n
 // serial substitution steps for Cholesky.
-// Pivot-row broadcast for groups narrower than a wave uses BOTH cross-lane paths, because each is a separate pipe:
-// the LDS crossbar (ds_bpermute: one instruction serves every group of the wave, but the crossbar is shared by the
-// whole CU - 38 cycles per op with 8 waves/CU) and v_readlane under the group's exec mask (VALU, per SIMD, one pass per
-// group).  The columns of a pivot row are split between the two; profiles/r01_microbench_primitives.txt has the rates.
-// Measured on the quadruped (G = 32, 4096 envs): all crossbar 57.0 M env-steps/s, 3/4 54.0, 1/2 54.0, 1/4 53.3, all
-// readlane 52.7 - so the default sends the whole row through the crossbar; the split stays as a build-time knob.
-#ifndef AMX_XBAR_NUM
-#define AMX_XBAR_NUM 1  // AMX_XBAR_NUM/AMX_XBAR_DEN of each pivot row goes through the crossbar
-#define AMX_XBAR_DEN 1
-#endif
-template <int N, int OFF, int J> DEV void gj_readlane_cols(float (&a)[N], float f, int k_begin) {
-#pragma unroll
-  for (int k0 = J + 1; k0 < N; k0 += 8) {
-    float u[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) u[i] = readlane_f(a[k0 + i < N ? k0 + i : N - 1], J + OFF);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) if (k0 + i < N && k0 + i >= k_begin) a[k0 + i] = __builtin_fmaf(-f, u[i], a[k0 + i]);
-  }
-}
+// Pivot-row broadcast: v_readlane for one group per wave (G == 64), the LDS crossbar (ds_bpermute, one instruction serves
+// every group of the wave) for narrower groups.  A wave issues one ds_bpermute per ~24 cycles (tools/bperm_rate.hip), which
+// is what bounds an elimination; sending part of each row through v_readlane + exec-masked v_fmac instead was measured
+// three times in this round (branches, selects, one asm block per column quad) and always lost in the kernel, although
+// it wins 13 % in an isolated solve loop with 8 waves per CU (profiles/r01_mfma_probe.txt).
 template <int N, int G, int J> DEV void gj_pivot(float (&a)[N], float &b, int gl, int gb4) {
-  // columns [J+1, ksplit) through the crossbar, [ksplit, N) by masked readlane (all of them when G == 64)
-  constexpr int ksplit = G == 64 ? J + 1 : J + 1 + ((N - J - 1) * AMX_XBAR_NUM) / AMX_XBAR_DEN;
   float u[N];
   const float piv = gbcast<G>(a[J], J, gb4);
   const float bj = gbcast<G>(b, J, gb4);
 #pragma unroll
-  for (int k = J + 1; k < ksplit; ++k) u[k] = gbcast<G>(a[k], J, gb4);
+  for (int k = J + 1; k < N; ++k) u[k] = gbcast<G>(a[k], J, gb4);
   float f = a[J] * __builtin_amdgcn_rcpf(fmaxf(piv, MINVAL));
   f = gl == J ? 0.0f : f;  // the pivot row itself is left alone
   b = __builtin_fmaf(-f, bj, b);
-  if (ksplit < N) {
-    if (G == 64) {
 #pragma unroll
-      for (int k = ksplit; k < N; ++k) a[k] = __builtin_fmaf(-f, readlane_f(a[k], J), a[k]);
-    } else if (G == 32) {
-      if (gb4 == 0) {
-#pragma unroll
-        for (int k = ksplit; k < N; ++k) a[k] = __builtin_fmaf(-f, readlane_f(a[k], J), a[k]);
-      } else {
-#pragma unroll
-        for (int k = ksplit; k < N; ++k) a[k] = __builtin_fmaf(-f, readlane_f(a[k], J + 32), a[k]);
-      }
-    } else {
-#pragma unroll
-      for (int k = ksplit; k < N; ++k) a[k] = __builtin_fmaf(-f, gbcast<G>(a[k], J, gb4), a[k]);
-    }
-  }
-#pragma unroll
-  for (int k = J + 1; k < ksplit; ++k) a[k] = __builtin_fmaf(-f, u[k], a[k]);
+  for (int k = J + 1; k < N; ++k) a[k] = __builtin_fmaf(-f, u[k], a[k]);
 }
 template <int N, int G, int J> struct GJ {
   static DEV void run(float (&a)[N], float &b, int gl, int gb4) {
