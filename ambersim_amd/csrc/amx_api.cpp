@@ -279,6 +279,7 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
   std::vector<int> Mlist;
   for (int i = 0; i < nv; i++) for (int j = i; j >= 0; j = d->dof_parentid[j]) Mlist.push_back(i | (j << 8));
   m.nM = (int)Mlist.size(); m.c_M = add_ints(Mlist);
+  if (m.G >= 32) { hent.clear(); m.nhent = 0; }  // wide groups build the Hessian on the matrix cores; only 16-lane groups walk the term list
   m.c_dofact = add_ints(dofact); m.c_pairdof = add_ints(pairdof); m.c_jac = add_ints(jac_items); m.c_hent = add_ints(hent);
   m.c_conpair = add_ints(con_pair); m.c_rootbody = add_ints(roots);
   {

@@ -10,7 +10,7 @@
 #ifndef AMX_MIN_WAVES_PER_SIMD
 #define AMX_MIN_WAVES_PER_SIMD 2  // launch bound: 256 VGPRs.  4096 envs give at most 2 waves/SIMD at G=32 and LDS allows no more at G=64, and 168/128 spill
 #endif
-#define AMX_MAX_NV 32           // register-row Cholesky capacity (one matrix row per lane, <=32 columns)
+#define AMX_MAX_NV 32           // register-row solve capacity (one matrix row per lane, <=32 columns; one 32x32 MFMA block)
 
 // Record strides (floats) of the constant image.  All odd, so lane-per-record LDS reads are conflict free.
 // Record strides (floats) of the per-environment slab, also odd.

@@ -1,5 +1,5 @@
 // amx_kernels.hip — the hot path: batched forward dynamics + constraint solve + integration
-// for gfx950 (MI355X), one 64-lane wavefront per environment, per-environment state in LDS.
+// for gfx950 (MI355X): a 16/32/64-lane group of a wavefront per environment, per-environment state in LDS.
 //
 // Replaces mjx.forward / mjx.step under MjxEnv.pipeline_step (reference ambersim/rl/base.py:81-96)
 // and shoot (reference ambersim/trajopt/shooting.py:22-48).  Stage names follow SURVEY.md §8(a)
@@ -14,11 +14,13 @@
 //   * static lane roles inside a group: lane b owns body b, lane i owns dof i, lane r owns constraint row r, so
 //     per-row solver state (D, aref, Jaref, Jv) lives in registers and role constants are read from
 //     LDS records with odd strides (bank-conflict free), never through dependent HBM loads;
-//   * per-body / per-dof arrays are struct-of-arrays in LDS; dense matrices use an odd leading dimension;
+//   * per-body / per-dof / per-row data are odd-stride records in LDS; M and H are full symmetric with 16-byte rows
+//     (ds_read_b128), the contact Jacobian is chain-compressed;
 //   * tree scans run level by level; up-scans gather from a static child list instead of scattering;
-//   * the small dense factorisations (M, M+J'DJ, M+dt*damping) hold one matrix row per lane in
-//     registers; pivots travel by v_readlane (G = 64) or through the LDS crossbar (ds_bpermute, G < 64),
-//     which also moves half of the factorisation's instructions off the VALU;
+//   * the Newton Hessian M + J'DJ is accumulated on the matrix cores (v_mfma_f32_32x32x1_2b: the two blocks are the two
+//     environments of a G = 32 wave) and handed to the solver through v_permlane32_swap;
+//   * the small dense solves (M, M+J'DJ, M+dt*damping) are one-shot Gauss-Jordan eliminations with one matrix row per
+//     lane in registers; pivot rows travel by v_readlane (G = 64) or through the LDS crossbar (ds_bpermute, G < 64);
 //   * group reductions use DPP row operations (+ one ds_swizzle / bpermute step across rows), never LDS memory;
 //   * HBM traffic of a rollout is the control stream in and the state rows out, both coalesced.
 #include <hip/hip_runtime.h>
