@@ -417,3 +417,22 @@ def test_random_models_vs_oracle(dev):
         tested += 1
         worst = max(worst, e1)
     assert tested >= 30 and widths == {16, 32, 64}, (tested, widths)  # all three lane-group widths were exercised
+
+
+@pytest.mark.parametrize("force", ["32", "64"])
+def test_forced_lane_group_widths(cases, golden, force, dev):
+    """Every model also runs on a wider lane group than it needs (AMX_FORCE_G is read when the model is created): the
+    pendulum and the Barrett hand on 32 and 64 lanes, the quadruped on 64 - same one-step parity as on their native width.
+    Covers the matrix-core Hessian and both broadcast paths of the solver at sizes their native widths never see."""
+    from ambersim_amd import mjx
+    os.environ["AMX_FORCE_G"] = force
+    try:
+        for name in ("pendulum_ctrl", "bh280", "quadruped"):
+            mj, _, x0, us = cases[name]
+            model = mjx.put_model(mj, dev)
+            assert model._h.query("lanes_per_env") == max(int(force), cases[name][1]._h.query("lanes_per_env"))
+            xs = gpu_rollout(model, x0.astype(np.float32), us.astype(np.float32))
+            ref = golden[name + "_xs"]
+            assert rel(xs[:, 1], ref[:, 1]) < (TOL if name != "bh280" else 3e-5), (name, force)
+    finally:
+        del os.environ["AMX_FORCE_G"]
