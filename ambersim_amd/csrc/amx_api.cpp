@@ -475,7 +475,15 @@ extern "C" int amx_quadcost(int nenv, int nsteps, int nx, int nu, const float *x
                             const float *R, const float *xg, float *cost, void *stream) {
   if (!xs || !Q || !Qf || !xg || !cost || (nu > 0 && (!us || !R)) || nenv < 0 || nsteps < 0) return fail(AMX_EINVAL, "amx_quadcost: bad argument");
   if (nenv == 0) return AMX_OK;
-  hipLaunchKernelGGL(amx_quadcost_kernel, dim3(nenv), dim3(AMX_WAVE), 0, (hipStream_t)stream, nenv, nsteps, nx, nu, xs, us, Q, Qf, R, xg, cost);
+  // tiled matrix-core kernel when Q, R and four 32-row tiles fit in LDS; the entry-per-lane kernel otherwise
+  const int nbx = (nx + 31) / 32, nbu = (nu + 31) / 32, ldy = 32 * std::max(nbx, std::max(nbu, 1)) + 5;
+  const size_t lds_floats = (size_t)((nx + 3) & ~3) * 32 * nbx + (size_t)((nu + 3) & ~3) * 32 * nbu + 32 * nbx + (size_t)QC_WAVES * 32 * ldy;
+  if (nx >= 1 && nbx <= QC_MAXBLK && nbu <= QC_MAXBLK && lds_floats * sizeof(float) <= 64 * 1024) {
+    hipLaunchKernelGGL(amx_quadcost_mfma_kernel, dim3((nenv + QC_WAVES - 1) / QC_WAVES), dim3(AMX_WAVE * QC_WAVES), lds_floats * sizeof(float), (hipStream_t)stream,
+                       nenv, nsteps, nx, nu, xs, us, Q, Qf, R, xg, cost);
+  } else {
+    hipLaunchKernelGGL(amx_quadcost_kernel, dim3(nenv), dim3(AMX_WAVE), 0, (hipStream_t)stream, nenv, nsteps, nx, nu, xs, us, Q, Qf, R, xg, cost);
+  }
   HIP_TRY(hipGetLastError());
   return AMX_OK;
 }

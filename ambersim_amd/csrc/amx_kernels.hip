@@ -1558,7 +1558,8 @@ amx_forward_kernel(const DevModel m_in, int nenv, const float *__restrict__ qpos
   if (o.nefc && gl == 0) o.nefc[e] = nactive;
 }
 
-// Batched StaticGoalQuadraticCost.cost (reference ambersim/trajopt/cost.py:62-85): one wave per rollout.
+// Batched StaticGoalQuadraticCost.cost (reference ambersim/trajopt/cost.py:62-85), general sizes: one wave per rollout,
+// lanes over the matrix entries.  Used when nx or nu exceed the tiled kernel's limits.
 extern "C" __global__ void __launch_bounds__(AMX_WAVE) amx_quadcost_kernel(int nenv, int nsteps, int nx, int nu, const float *xs,
                                                                            const float *us, const float *Q, const float *Qf,
                                                                            const float *R, const float *xg, float *cost) {
@@ -1578,6 +1579,113 @@ extern "C" __global__ void __launch_bounds__(AMX_WAVE) amx_quadcost_kernel(int n
     for (int k = lane; k < nu * nu; k += AMX_WAVE) {
       const int i = k / nu, j = k - i * nu;
       acc += u[i] * R[k] * u[j];
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) cost[e] = 0.5f * acc;
+}
+
+// The same cost as a tiled product on the matrix cores: sum_t y_t' W y_t = sum over a [32 rows x n] tile Y of (Y W) o Y.
+// One wave per rollout, four rollouts per workgroup sharing one LDS copy of Q and R (zero-padded to whole 32-column
+// blocks and an even number of rows).  Per tile of 32 time steps: the rows stream in coalesced (they are contiguous in
+// HBM) minus the goal, v_mfma_f32_32x32x2 accumulates Y W over k pairs for each 32-column block, and the accumulator
+// (lane (h, j) holds rows 8q+4h+r of column j) is multiplied elementwise with Y and summed - no per-row bookkeeping,
+// because every row of the tile belongs to the same rollout.  The terminal row (Qf) is one row per rollout: lanes over
+// matrix entries.  HBM traffic is the trajectories, read once.
+#define QC_WAVES 4
+#define QC_MAXBLK 3  // column blocks of 32: nx <= 96
+#define QC_REGS (32 * 32 * QC_MAXBLK / AMX_WAVE)  // values per lane of one staged tile
+struct QuadTile {
+  // issue the global loads of a tile: rows*n contiguous floats, value q*64+lane in r[q]
+  static DEV void fetch(float (&r)[QC_REGS], const float *__restrict__ src, int total, int lane) {
+#pragma unroll
+    for (int q = 0; q < QC_REGS; ++q) {
+      if (q * AMX_WAVE >= total) break;  // wave-uniform
+      const int idx = q * AMX_WAVE + lane;
+      r[q] = src[idx < total ? idx : total - 1];
+    }
+  }
+  // registers -> LDS tile Y[32][ldy] minus the goal; the padding columns (>= n) are kept zero by the caller, a short tile
+  // zeroes its missing rows
+  static DEV void stage(const float (&r)[QC_REGS], int rows, int n, int Gl, int Yl, int ldy, int lane) {
+    if (rows < 32) {
+      for (int idx = rows * ldy + lane; idx < 32 * ldy; idx += AMX_WAVE) lds[Yl + idx] = 0.0f;
+    }
+    const int total = rows * n;
+    int row = 0, col = lane;
+    while (col >= n) { col -= n; ++row; }
+#pragma unroll
+    for (int q = 0; q < QC_REGS; ++q) {
+      if (q * AMX_WAVE >= total) break;  // wave-uniform
+      if (q * AMX_WAVE + lane < total) lds[Yl + row * ldy + col] = r[q] - (Gl >= 0 ? lds[Gl + col] : 0.0f);
+      col += AMX_WAVE;
+      while (col >= n) { col -= n; ++row; }
+    }
+    WSYNC();
+  }
+  // sum over the staged tile of y' W y
+  static DEV float compute(int n, int Wl, int ldw, int nblk, int Yl, int ldy, int lane) {
+    const int np4 = (n + 3) & ~3, i = lane & 31, h = lane >> 5;  // W and Y are zero-padded to a multiple of 4 in k
+    float acc = 0.0f;
+    for (int jb = 0; jb < nblk; ++jb) {
+      v16f C = {};
+      for (int k0 = 0; k0 < np4; k0 += 4) {  // two k pairs per trip: four operand loads in flight, two dependent MFMAs
+        const float a0 = lds[Yl + i * ldy + k0 + h], a1 = lds[Yl + i * ldy + k0 + 2 + h];                        // Y[row i][k]
+        const float b0 = lds[Wl + (k0 + h) * ldw + 32 * jb + i], b1 = lds[Wl + (k0 + 2 + h) * ldw + 32 * jb + i];  // W[k][32 jb + i]
+        C = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, C, 0, 0, 0);
+        C = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, C, 0, 0, 0);
+      }
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc = __builtin_fmaf(C[v], lds[Yl + (8 * (v >> 2) + 4 * h + (v & 3)) * ldy + 32 * jb + i], acc);
+    }
+    WSYNC();  // the tile buffer is rewritten by the next stage()
+    return acc;
+  }
+  // all tiles of one [nrows][n] trajectory block: the loads of tile t+1 are in flight while tile t is on the matrix cores
+  static DEV float block(const float *__restrict__ src, int nrows, int n, int Gl, int Wl, int ldw, int nblk, int Yl, int ldy, int lane) {
+    float r[QC_REGS], acc = 0.0f;
+    if (nrows <= 0) return 0.0f;
+    fetch(r, src, (nrows < 32 ? nrows : 32) * n, lane);
+    for (int t0 = 0; t0 < nrows; t0 += 32) {
+      const int rows = nrows - t0 < 32 ? nrows - t0 : 32;
+      stage(r, rows, n, Gl, Yl, ldy, lane);
+      const int t1 = t0 + 32;
+      if (t1 < nrows) fetch(r, src + (size_t)t1 * n, (nrows - t1 < 32 ? nrows - t1 : 32) * n, lane);
+      acc += compute(n, Wl, ldw, nblk, Yl, ldy, lane);
+    }
+    return acc;
+  }
+};
+extern "C" __global__ void __launch_bounds__(AMX_WAVE * QC_WAVES) amx_quadcost_mfma_kernel(int nenv, int nsteps, int nx, int nu, const float *__restrict__ xs,
+                                                                                          const float *__restrict__ us, const float *__restrict__ Q,
+                                                                                          const float *__restrict__ Qf, const float *__restrict__ R,
+                                                                                          const float *__restrict__ xg, float *__restrict__ cost) {
+  const int lane = threadIdx.x & (AMX_WAVE - 1), wave = threadIdx.x / AMX_WAVE, e = blockIdx.x * QC_WAVES + wave;
+  const int nbx = (nx + 31) >> 5, nbu = (nu + 31) >> 5, ldwx = 32 * nbx, ldwu = 32 * nbu, nxp = (nx + 3) & ~3, nup = (nu + 3) & ~3;
+  const int Ql = 0, Rl = Ql + nxp * ldwx, Gl = Rl + nup * ldwu, tiles = Gl + 32 * nbx;
+  const int ldy = 32 * (nbx > nbu ? nbx : nbu) + 5;  // odd, and k may run 3 past the last block: lane-per-row reads are conflict free
+  for (int k = threadIdx.x; k < nxp * ldwx; k += blockDim.x) { const int r = k / ldwx, c = k - r * ldwx; lds[Ql + k] = (r < nx && c < nx) ? Q[r * nx + c] : 0.0f; }
+  for (int k = threadIdx.x; k < nup * ldwu; k += blockDim.x) { const int r = k / ldwu, c = k - r * ldwu; lds[Rl + k] = (r < nu && c < nu) ? R[r * nu + c] : 0.0f; }
+  for (int k = threadIdx.x; k < 32 * nbx; k += blockDim.x) lds[Gl + k] = k < nx ? xg[k] : 0.0f;
+  __syncthreads();
+  if (e >= nenv) return;
+  const int Yl = tiles + wave * 32 * ldy;
+  float acc = 0.0f;
+  const float *x = xs + (size_t)e * (nsteps + 1) * nx;
+  for (int idx = lane; idx < 32 * ldy; idx += AMX_WAVE) lds[Yl + idx] = 0.0f;
+  WSYNC();
+  acc += QuadTile::block(x, nsteps, nx, Gl, Ql, ldwx, nbx, Yl, ldy, lane);
+  if (nu > 0) {
+    const float *u = us + (size_t)e * nsteps * nu;
+    for (int idx = lane; idx < 32 * ldy; idx += AMX_WAVE) lds[Yl + idx] = 0.0f;  // columns nu..nx still hold state data
+    WSYNC();
+    acc += QuadTile::block(u, nsteps, nu, -1, Rl, ldwu, nbu, Yl, ldy, lane);
+  }
+  {  // terminal row with Qf
+    const float *xN = x + (size_t)nsteps * nx;
+    for (int k = lane; k < nx * nx; k += AMX_WAVE) {
+      const int i = k / nx, j = k - i * nx;
+      acc = __builtin_fmaf((xN[i] - xg[i]) * Qf[k], xN[j] - xg[j], acc);
     }
   }
   acc = wave_sum(acc);

@@ -436,3 +436,20 @@ def test_forced_lane_group_widths(cases, golden, force, dev):
             assert rel(xs[:, 1], ref[:, 1]) < (TOL if name != "bh280" else 3e-5), (name, force)
     finally:
         del os.environ["AMX_FORCE_G"]
+
+
+@pytest.mark.parametrize("S,N,nx,nu", [(7, 1, 2, 1), (5, 33, 37, 12), (9, 64, 61, 24), (3, 100, 33, 0), (4, 40, 96, 32), (3, 20, 100, 5)])
+def test_quadcost_shapes_vs_einsum(dev, S, N, nx, nu):
+    """amx_quadcost against an fp64 einsum at the shapes of every configuration: tiles that end mid-way, several 32-column
+    blocks, a non-symmetric Q, a goal, no controls, and (nx = 100) the entry-per-lane kernel behind the same entry point."""
+    from ambersim_amd.trajopt.cost import StaticGoalQuadraticCost
+    g = torch.Generator().manual_seed(S + N)
+    xs = torch.randn((S, N + 1, nx), generator=g); us = torch.randn((S, N, nu), generator=g)
+    Q = torch.randn((nx, nx), generator=g); Qf = torch.randn((nx, nx), generator=g); R = torch.randn((nu, nu), generator=g)
+    xg = torch.randn(nx, generator=g)
+    val, _ = StaticGoalQuadraticCost(Q=Q, Qf=Qf, R=R, xg=xg).cost(xs.to(dev), us.to(dev), None)
+    xc = (xs - xg).double()
+    ref = 0.5 * (torch.einsum("sti,ij,stj->s", xc[:, :-1], Q.double(), xc[:, :-1]) + torch.einsum("si,ij,sj->s", xc[:, -1], Qf.double(), xc[:, -1])
+                 + torch.einsum("sti,ij,stj->s", us.double(), R.double(), us.double()))
+    scale = 0.5 * (torch.einsum("sti,ij,stj->s", xc[:, :-1].abs(), Q.double().abs(), xc[:, :-1].abs()) + 1.0)
+    assert ((val.cpu().double() - ref).abs() / scale).max() < 1e-6
