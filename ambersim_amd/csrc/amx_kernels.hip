@@ -550,59 +550,80 @@ struct Env {
   DEV int dofoff(int f) const { return eb + m.e_dof + f; }  // element i of dof field f lives at dofoff(f) + i*DOF_E
 
   // ------------------------------------------------------------------ A9.1 kinematics
+  // Three passes, so that the joint arithmetic (type switch, sin/cos, quaternion products) runs once per step and not once
+  // per tree level under a partial exec mask:
+  //   1. every body in parallel: its pose and its joints' anchors and axes in the PARENT's frame (a free joint gives the
+  //      world pose directly; its parent is the world);
+  //   2. level scan from depth 2 down: world pose = parent's world pose o local pose (one quaternion product, one
+  //      rotation); depth-1 bodies hang off the world, whose pose is the identity, and are already final;
+  //   3. every joint in parallel: anchor and axis taken to the world frame by the parent body's pose.
   DEV void kinematics() {
     const int b = gl;
     if (gl == 0) {
       body(0, 0) = 0; body(1, 0) = 0; body(2, 0) = 0;
       body(3, 0) = 1; body(4, 0) = 0; body(5, 0) = 0; body(6, 0) = 0;
     }
-    WSYNC();
-    const int br = m.c_body + (b < m.nb ? b : 0) * BODY_S;
-    const f3 bpos = mk3(CF(br + 7), CF(br + 8), CF(br + 9));
-    const f4 bquat = {CF(br + 10), CF(br + 11), CF(br + 12), CF(br + 13)};
-    for (int L = 1; L < m.nlevel; ++L) {
-      if (b_level == L) {
-        const int par = b_parent;
-        const f4 pq = ld_xquat(par);
-        f3 pos = ld_xpos(par) + qrot(pq, bpos);
-        f4 quat = qmul(pq, bquat);
-        for (int k = 0; k < b_jntnum; ++k) {
-          const int j = b_jntadr + k, jr = m.c_jnt + j * JNT_S;
-          const int t_ = CI(jr), qa = eb + m.e_qpos + CI(jr + 1);
-          const f3 jpos = mk3(CF(jr + 4), CF(jr + 5), CF(jr + 6)), jax = mk3(CF(jr + 7), CF(jr + 8), CF(jr + 9));
-          f3 anchor, axis;
-          if (t_ == JFREE) {
-            anchor = mk3(lds[qa], lds[qa + 1], lds[qa + 2]);
-            axis = mk3(0, 0, 1);
-            pos = anchor;
-            f4 q = {lds[qa + 3], lds[qa + 4], lds[qa + 5], lds[qa + 6]};
+    if (b > 0 && b < m.nb) {
+      const int br = m.c_body + b * BODY_S;
+      f3 pos = mk3(CF(br + 7), CF(br + 8), CF(br + 9));
+      f4 quat = {CF(br + 10), CF(br + 11), CF(br + 12), CF(br + 13)};
+      for (int k = 0; k < b_jntnum; ++k) {
+        const int j = b_jntadr + k, jr = m.c_jnt + j * JNT_S;
+        const int t_ = CI(jr), qa = eb + m.e_qpos + CI(jr + 1);
+        const f3 jpos = mk3(CF(jr + 4), CF(jr + 5), CF(jr + 6)), jax = mk3(CF(jr + 7), CF(jr + 8), CF(jr + 9));
+        f3 anchor, axis;
+        if (t_ == JFREE) {
+          anchor = mk3(lds[qa], lds[qa + 1], lds[qa + 2]);
+          axis = mk3(0, 0, 1);
+          pos = anchor;
+          f4 q = {lds[qa + 3], lds[qa + 4], lds[qa + 5], lds[qa + 6]};
+          q = qnormalize(q);
+          lds[qa + 3] = q.w; lds[qa + 4] = q.x; lds[qa + 5] = q.y; lds[qa + 6] = q.z;
+          quat = q;
+        } else {
+          anchor = qrot(quat, jpos) + pos;
+          axis = qrot(quat, jax);
+          if (t_ == JBALL) {
+            f4 q = {lds[qa], lds[qa + 1], lds[qa + 2], lds[qa + 3]};
             q = qnormalize(q);
-            lds[qa + 3] = q.w; lds[qa + 4] = q.x; lds[qa + 5] = q.y; lds[qa + 6] = q.z;
-            quat = q;
+            lds[qa] = q.w; lds[qa + 1] = q.x; lds[qa + 2] = q.y; lds[qa + 3] = q.z;
+            quat = qmul(quat, q);
+            pos = anchor - qrot(quat, jpos);
+          } else if (t_ == JHINGE) {
+            quat = qmul(quat, axisangle(jax, lds[qa] - CF(jr + 10)));
+            pos = anchor - qrot(quat, jpos);
           } else {
-            anchor = qrot(quat, jpos) + pos;
-            axis = qrot(quat, jax);
-            if (t_ == JBALL) {
-              f4 q = {lds[qa], lds[qa + 1], lds[qa + 2], lds[qa + 3]};
-              q = qnormalize(q);
-              lds[qa] = q.w; lds[qa + 1] = q.x; lds[qa + 2] = q.y; lds[qa + 3] = q.z;
-              quat = qmul(quat, q);
-              pos = anchor - qrot(quat, jpos);
-            } else if (t_ == JHINGE) {
-              quat = qmul(quat, axisangle(jax, lds[qa] - CF(jr + 10)));
-              pos = anchor - qrot(quat, jpos);
-            } else {
-              pos = pos + axis * (lds[qa] - CF(jr + 10));
-            }
+            pos = pos + axis * (lds[qa] - CF(jr + 10));
           }
-          jnt(0, j) = anchor.x; jnt(1, j) = anchor.y; jnt(2, j) = anchor.z;
-          jnt(3, j) = axis.x; jnt(4, j) = axis.y; jnt(5, j) = axis.z;
         }
+        jnt(0, j) = anchor.x; jnt(1, j) = anchor.y; jnt(2, j) = anchor.z;
+        jnt(3, j) = axis.x; jnt(4, j) = axis.y; jnt(5, j) = axis.z;
+      }
+      body(0, b) = pos.x; body(1, b) = pos.y; body(2, b) = pos.z;
+      body(3, b) = quat.w; body(4, b) = quat.x; body(5, b) = quat.y; body(6, b) = quat.z;
+    }
+    WSYNC();
+    for (int L = 2; L < m.nlevel; ++L) {
+      if (b_level == L) {
+        const f4 pq = ld_xquat(b_parent);
+        const f3 pos = ld_xpos(b_parent) + qrot(pq, ld_xpos(b));
+        const f4 quat = qmul(pq, ld_xquat(b));
         body(0, b) = pos.x; body(1, b) = pos.y; body(2, b) = pos.z;
         body(3, b) = quat.w; body(4, b) = quat.x; body(5, b) = quat.y; body(6, b) = quat.z;
       }
       WSYNC();
     }
+    if (gl < m.njnt) {
+      const int p = CI(m.c_body + CI(m.c_jnt + gl * JNT_S + 3) * BODY_S);  // parent of the joint's body
+      if (p > 0) {  // the world's frame is the identity
+        const f4 pq = ld_xquat(p);
+        const f3 anchor = ld_xpos(p) + qrot(pq, mk3(jnt(0, gl), jnt(1, gl), jnt(2, gl)));
+        const f3 axis = qrot(pq, mk3(jnt(3, gl), jnt(4, gl), jnt(5, gl)));
+        jnt(0, gl) = anchor.x; jnt(1, gl) = anchor.y; jnt(2, gl) = anchor.z;
+        jnt(3, gl) = axis.x; jnt(4, gl) = axis.y; jnt(5, gl) = axis.z;
+      }
+    }
+    WSYNC();
   }
 
   // ------------------------------------------------------------------ A9.2 com_pos: tree COM, cinert, cdof (+ collision geom poses)
