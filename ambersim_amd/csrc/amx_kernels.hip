@@ -756,54 +756,74 @@ struct Env {
       st_bsv(F_CACC, 0, z);
     }
     WSYNC();
+    // The joint arithmetic runs once per step, not once per tree level: with cv_p, ca_p the parent's velocity and
+    // acceleration and P_k the body's own partial velocity before joint k,
+    //   cvel_b = cv_p + sum_i cdof_i qvel_i                                                =: cv_p + vJ
+    //   cacc_b = ca_p + sum_i cross(cv_p + P_k(i), cdof_i) qvel_i = ca_p + cross(cv_p, w) + loc
+    // (w = sum over the dofs that have a cdof_dot - every dof but the translations of a free joint; loc = the same sum
+    // with P_k alone; the motion cross product is bilinear).  vJ, w, loc need no other body and stay in registers; the
+    // level scan is then twelve loads, one cross product and twelve stores.
+    sv vJ = {{0, 0, 0, 0, 0, 0}}, w = {{0, 0, 0, 0, 0, 0}}, loc = {{0, 0, 0, 0, 0, 0}};
+    if (b > 0 && b < m.nb) {
+      for (int k = 0; k < b_jntnum; ++k) {
+        const int jr = m.c_jnt + (b_jntadr + k) * JNT_S, t_ = CI(jr), da = CI(jr + 2);
+        if (t_ == JFREE) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const sv c = ld_dsv(D_CDOF, da + i);
+            const float q = lds[qv + da + i];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) vJ.v[e] += c.v[e] * q;
+          }
+          const sv c3 = ld_dsv(D_CDOF, da + 3), c4 = ld_dsv(D_CDOF, da + 4), c5 = ld_dsv(D_CDOF, da + 5);
+          const sv cd3 = motion_cross(vJ, c3), cd4 = motion_cross(vJ, c4), cd5 = motion_cross(vJ, c5);
+          const float q3 = lds[qv + da + 3], q4 = lds[qv + da + 4], q5 = lds[qv + da + 5];
+#pragma unroll
+          for (int e = 0; e < 6; ++e) {
+            const float add = c3.v[e] * q3 + c4.v[e] * q4 + c5.v[e] * q5;
+            loc.v[e] += cd3.v[e] * q3 + cd4.v[e] * q4 + cd5.v[e] * q5;
+            w.v[e] += add;
+            vJ.v[e] += add;
+          }
+        } else {
+          const int n = t_ == JBALL ? 3 : 1;
+          sv add = {{0, 0, 0, 0, 0, 0}};
+          for (int i = 0; i < n; ++i) {
+            const sv c = ld_dsv(D_CDOF, da + i);
+            const sv cd = motion_cross(vJ, c);
+            const float q = lds[qv + da + i];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) { loc.v[e] += cd.v[e] * q; add.v[e] += c.v[e] * q; }
+          }
+#pragma unroll
+          for (int e = 0; e < 6; ++e) { vJ.v[e] += add.v[e]; w.v[e] += add.v[e]; }
+        }
+      }
+    }
     for (int L = 1; L < m.nlevel; ++L) {
       if (b_level == L) {
-        sv cv = ld_bsv(F_CVEL, b_parent), ca = ld_bsv(F_CACC, b_parent);
-        for (int k = 0; k < b_jntnum; ++k) {
-          const int jr = m.c_jnt + (b_jntadr + k) * JNT_S, t_ = CI(jr), da = CI(jr + 2);
-          if (t_ == JFREE) {
+        const sv cvp = ld_bsv(F_CVEL, b_parent), cap = ld_bsv(F_CACC, b_parent);
+        const sv x = motion_cross(cvp, w);
+        sv cv, ca;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-              const sv c = ld_dsv(D_CDOF, da + i);
-              const float q = lds[qv + da + i];
-#pragma unroll
-              for (int e = 0; e < 6; ++e) cv.v[e] += c.v[e] * q;
-            }
-            const sv c3 = ld_dsv(D_CDOF, da + 3), c4 = ld_dsv(D_CDOF, da + 4), c5 = ld_dsv(D_CDOF, da + 5);
-            const sv cd3 = motion_cross(cv, c3), cd4 = motion_cross(cv, c4), cd5 = motion_cross(cv, c5);
-            const float q3 = lds[qv + da + 3], q4 = lds[qv + da + 4], q5 = lds[qv + da + 5];
-#pragma unroll
-            for (int e = 0; e < 6; ++e) {
-              ca.v[e] += cd3.v[e] * q3 + cd4.v[e] * q4 + cd5.v[e] * q5;
-              cv.v[e] += c3.v[e] * q3 + c4.v[e] * q4 + c5.v[e] * q5;
-            }
-          } else {
-            const int n = t_ == JBALL ? 3 : 1;
-            sv add = {{0, 0, 0, 0, 0, 0}};
-            for (int i = 0; i < n; ++i) {
-              const sv c = ld_dsv(D_CDOF, da + i);
-              const sv cd = motion_cross(cv, c);
-              const float q = lds[qv + da + i];
-#pragma unroll
-              for (int e = 0; e < 6; ++e) { ca.v[e] += cd.v[e] * q; add.v[e] += c.v[e] * q; }
-            }
-#pragma unroll
-            for (int e = 0; e < 6; ++e) cv.v[e] += add.v[e];
-          }
-        }
+        for (int e = 0; e < 6; ++e) { cv.v[e] = cvp.v[e] + vJ.v[e]; ca.v[e] = cap.v[e] + x.v[e] + loc.v[e]; }
         st_bsv(F_CVEL, b, cv);
         st_bsv(F_CACC, b, ca);
-        float I[10];
-#pragma unroll
-        for (int k = 0; k < 10; ++k) I[k] = body(F_CINERT + k, b);
-        sv f = inert_mul(I, ca);
-        const sv g = motion_cross_force(cv, inert_mul(I, cv));
-#pragma unroll
-        for (int e = 0; e < 6; ++e) f.v[e] += g.v[e];
-        st_bsv(F_CFRC, b, f);
       }
       WSYNC();
     }
+    if (b > 0 && b < m.nb) {  // local force of every body in parallel: I cacc + cvel x* (I cvel)
+      const sv cv = ld_bsv(F_CVEL, b), ca = ld_bsv(F_CACC, b);
+      float I[10];
+#pragma unroll
+      for (int k = 0; k < 10; ++k) I[k] = body(F_CINERT + k, b);
+      sv f = inert_mul(I, ca);
+      const sv g = motion_cross_force(cv, inert_mul(I, cv));
+#pragma unroll
+      for (int e = 0; e < 6; ++e) f.v[e] += g.v[e];
+      st_bsv(F_CFRC, b, f);
+    }
+    WSYNC();
     for (int L = m.nlevel - 2; L >= 1; --L) {  // up-scan: gather children
       if (b_level == L && b_childnum > 0) {
         sv f = ld_bsv(F_CFRC, b);
