@@ -1300,14 +1300,17 @@ struct Env {
     bool use_warm = false;
     float ma_warm = 0, ja_warm = 0;
     if (!(m.disableflags & DIS_WARMSTART)) {
+      float gw, gs;
       init_context(D_WARM);
-      const float cw = constraint_cost(D_WARM, &gauss);
+      const float cw = constraint_cost(D_WARM, &gw);
       ma_warm = gl < nv ? dof(D_MA, gl) : 0.0f;
       ja_warm = rJaref;
       WSYNC();
       init_context(D_ASMOOTH);
-      const float cs = constraint_cost(D_ASMOOTH, &gauss);
+      const float cs = constraint_cost(D_ASMOOTH, &gs);
       use_warm = cw < cs;
+      cost = use_warm ? cw : cs;  // the chosen start's cost and Gauss term are the ones just evaluated
+      gauss = use_warm ? gw : gs;
     }
     if (gl < nv) {
       dof(D_QACC, gl) = use_warm ? dof(D_WARM, gl) : dof(D_ASMOOTH, gl);
@@ -1315,8 +1318,10 @@ struct Env {
     }
     if (use_warm) rJaref = ja_warm;
     WSYNC();
-    if (m.disableflags & DIS_WARMSTART) init_context(D_QACC);
-    cost = constraint_cost(D_QACC, &gauss);
+    if (m.disableflags & DIS_WARMSTART) {
+      init_context(D_QACC);
+      cost = constraint_cost(D_QACC, &gauss);
+    }
     prev_cost = INFINITY;
     PROF(9);
     constraint_force_and_grad();
