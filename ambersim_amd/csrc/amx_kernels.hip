@@ -164,6 +164,14 @@ template <int G> DEV float gbcast(float x, int j, int gb4) {
   // G < 64: through the LDS crossbar.  (Measured alternative for G = 32, two v_readlane + a select on the VALU: 12 % slower.)
   return __int_as_float(__builtin_amdgcn_ds_bpermute(gb4 + 4 * j, __float_as_int(x)));
 }
+// value of lane J (compile-time) of my group.  Narrow groups use ds_swizzle in bit-mask mode - lane' = (lane & and) | or
+// inside each 32-lane half, an immediate pattern and no address register: a wave issues one per ~13 cycles against ~24
+// for ds_bpermute (tools/bperm_rate.hip), which is what bounds the eliminations.
+template <int G, int J> DEV float gbcast_s(float x) {
+  if (G == 64) return readlane_f(x, J);
+  constexpr int pattern = G == 32 ? (J << 5) : (0x10 | (J << 5));  // [4:0] and-mask, [9:5] or-mask, [14:10] xor-mask
+  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), pattern));
+}
 DEV bool wave_any(bool p) { return __ballot(p) != 0ull; }
 
 // ---- register-row dense Cholesky: lane i holds row i of the matrix at lds[A_off] (lower part).
@@ -237,17 +245,17 @@ __device__ __noinline__ void chol_solve_rows(int A_off, int ld, int n, int L_off
 // its own column-j entry by 1/pivot and updates its row and right-hand side.  No substitutions, no LDS
 // traffic besides the initial row load, and one cross-lane latency per pivot instead of two plus 2n
 // serial substitution steps for Cholesky.
-// Pivot-row broadcast: v_readlane for one group per wave (G == 64), the LDS crossbar (ds_bpermute, one instruction serves
-// every group of the wave) for narrower groups.  A wave issues one ds_bpermute per ~24 cycles (tools/bperm_rate.hip), which
-// is what bounds an elimination; sending part of each row through v_readlane + exec-masked v_fmac instead was measured
-// three times in this round (branches, selects, one asm block per column quad) and always lost in the kernel, although
-// it wins 13 % in an isolated solve loop with 8 waves per CU (profiles/r01_mfma_probe.txt).
+// Pivot-row broadcast: v_readlane for one group per wave (G == 64), the LDS crossbar for narrower groups (one instruction
+// serves every group of the wave) - as ds_swizzle with an immediate pattern, since the pivot lane is a compile-time
+// constant of the unrolled elimination.  The crossbar issue rate of a wave is what bounds an elimination; sending part of
+// each row through v_readlane + exec-masked v_fmac instead was measured three times in this round and always lost in the
+// kernel (profiles/r01_mfma_probe.txt).
 template <int N, int G, int J> DEV void gj_pivot(float (&a)[N], float &b, int gl, int gb4) {
   float u[N];
-  const float piv = gbcast<G>(a[J], J, gb4);
-  const float bj = gbcast<G>(b, J, gb4);
+  const float piv = gbcast_s<G, J>(a[J]);
+  const float bj = gbcast_s<G, J>(b);
 #pragma unroll
-  for (int k = J + 1; k < N; ++k) u[k] = gbcast<G>(a[k], J, gb4);
+  for (int k = J + 1; k < N; ++k) u[k] = gbcast_s<G, J>(a[k]);
   float f = a[J] * __builtin_amdgcn_rcpf(fmaxf(piv, MINVAL));
   f = gl == J ? 0.0f : f;  // the pivot row itself is left alone
   b = __builtin_fmaf(-f, bj, b);
