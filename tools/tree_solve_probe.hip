@@ -30,6 +30,42 @@ template <int N, int J> struct GJ {
   }
 };
 template <int N> struct GJ<N, N> { static DEV void run(float (&)[N], float &, int, int) {} };
+template <int J> DEV float swz_f(float x) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), (J << 5))); }
+template <int N, int J> struct GJS {
+  static DEV void run(float (&a)[N], float &b, int gl) {
+    float u[N];
+    const float piv = swz_f<J>(a[J]);
+    const float bj = swz_f<J>(b);
+#pragma unroll
+    for (int k = J + 1; k < N; ++k) u[k] = swz_f<J>(a[k]);
+    float f = a[J] * __builtin_amdgcn_rcpf(fmaxf(piv, MINVAL));
+    f = gl == J ? 0.0f : f;
+    b = __builtin_fmaf(-f, bj, b);
+#pragma unroll
+    for (int k = J + 1; k < N; ++k) a[k] = __builtin_fmaf(-f, u[k], a[k]);
+    GJS<N, J + 1>::run(a, b, gl);
+  }
+};
+template <int N> struct GJS<N, N> { static DEV void run(float (&)[N], float &, int) {} };
+template <int N> __device__ __noinline__ void solve_gjs(int A_off, int ld, int n, int rhs_off, int x_off, int gl) {
+  float a[N];
+  const int li = gl < n ? gl : 0;
+  const float4 *rowp = reinterpret_cast<const float4 *>(lds + A_off + li * ld);
+#pragma unroll
+  for (int c = 0; c < (N + 3) / 4; ++c) {
+    const float4 v = rowp[c];
+    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int k = 4 * c + q; if (k < N) a[k] = (gl < n && k < n) ? e[q] : (k == gl ? 1.0f : 0.0f); }
+  }
+  float b = gl < n ? lds[rhs_off + li] : 0.0f;
+  GJS<N, 0>::run(a, b, gl);
+  float d = 1.0f;
+#pragma unroll
+  for (int k = 0; k < N; ++k) d = (k == gl) ? a[k] : d;
+  if (gl < n) lds[x_off + gl] = b / d;
+  WSYNC();
+}
 template <int N> __device__ __noinline__ void solve_gj(int A_off, int ld, int n, int rhs_off, int x_off, int gl, int gb4) {
   float a[N];
   const int li = gl < n ? gl : 0;
@@ -138,7 +174,8 @@ __global__ void __launch_bounds__(256, 2) bench(const float *Hg, const float *bg
   const unsigned long long c0 = __builtin_readcyclecounter();
   for (int it = 0; it < reps; ++it) {
     if (MODE == 0) solve_tree<9>(base, ld, n, base + n * ld, base + n * ld + n, base + n * ld + 2 * n, base + n * ld + 2 * n + 32 * 16, t, gl);
-    else solve_gj<18>(base, ld, n, base + n * ld, base + n * ld + n, gl, 4 * (lane & 32));
+    else if (MODE == 1) solve_gj<18>(base, ld, n, base + n * ld, base + n * ld + n, gl, 4 * (lane & 32));
+    else solve_gjs<18>(base, ld, n, base + n * ld, base + n * ld + n, gl);
   }
   const unsigned long long c1 = __builtin_readcyclecounter();
   if (gl < n) xg[(size_t)genv * n + gl] = lds[base + n * ld + n + gl];
@@ -185,19 +222,20 @@ int main() {
     CK(hipMemcpy(dH, H.data(), H.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(db, b.data(), b.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dt, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
     const int envf = n * 20 + 2 * n + 32 * 16 + 32 + 8, lds_bytes = ((int)tab.size() + 8 * envf) * 4;
-    for (int mode = 0; mode < 2; ++mode) {
+    for (int mode = 0; mode < 3; ++mode) {
       const int reps = 200;
       for (int pass = 0; pass < 2; ++pass) {
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         CK(hipEventRecord(e0));
         if (mode == 0) bench<0><<<blocks, 256, lds_bytes>>>(dH, db, dx, dt, (int)tab.size(), t, n, pass ? reps : 1, dc);
-        else bench<1><<<blocks, 256, lds_bytes>>>(dH, db, dx, dt, (int)tab.size(), t, n, pass ? reps : 1, dc);
+        else if (mode == 1) bench<1><<<blocks, 256, lds_bytes>>>(dH, db, dx, dt, (int)tab.size(), t, n, pass ? reps : 1, dc);
+        else bench<2><<<blocks, 256, lds_bytes>>>(dH, db, dx, dt, (int)tab.size(), t, n, pass ? reps : 1, dc);
         CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
         if (pass == 0) {
           CK(hipMemcpy(x.data(), dx, x.size() * 4, hipMemcpyDeviceToHost));
           double worst = 0;
           for (int e = 0; e < nenv; ++e) { double rn = 0, bn = 0; for (int i = 0; i < n; ++i) { double s = 0; for (int j = 0; j < n; ++j) s += (double)H[(size_t)e * n * n + i * n + j] * x[(size_t)e * n + j]; rn += (s - b[(size_t)e * n + i]) * (s - b[(size_t)e * n + i]); bn += (double)b[(size_t)e * n + i] * b[(size_t)e * n + i]; } worst = fmax(worst, sqrt(rn / bn)); }
-          printf("%-22s blocks=%4d worst relative residual %.3e", mode == 0 ? "tree-sparse LDL^T" : "crossbar Gauss-Jordan", blocks, worst);
+          printf("%-22s blocks=%4d worst relative residual %.3e", mode == 0 ? "tree-sparse LDL^T" : (mode == 1 ? "bpermute Gauss-Jordan" : "swizzle Gauss-Jordan"), blocks, worst);
         } else {
           float ms; CK(hipEventElapsedTime(&ms, e0, e1));
           unsigned long long c; CK(hipMemcpy(&c, dc, 8, hipMemcpyDeviceToHost));
