@@ -20,7 +20,7 @@
 //   * the Newton Hessian M + J'DJ is accumulated on the matrix cores (v_mfma_f32_32x32x1_2b: the two blocks are the two
 //     environments of a G = 32 wave) and handed to the solver through v_permlane32_swap;
 //   * the small dense solves (M, M+J'DJ, M+dt*damping) are one-shot Gauss-Jordan eliminations with one matrix row per
-//     lane in registers; pivot rows travel by v_readlane (G = 64) or through the LDS crossbar (ds_bpermute, G < 64);
+//     lane in registers; pivot rows travel by v_readlane (G = 64) or through the LDS crossbar (ds_swizzle, G < 64);
 //   * group reductions use DPP row operations (+ one ds_swizzle / bpermute step across rows), never LDS memory;
 //   * HBM traffic of a rollout is the control stream in and the state rows out, both coalesced.
 #include <hip/hip_runtime.h>
