@@ -478,6 +478,87 @@ template <int G> DEV void lds_copy(int dst, int src, int n, int gl) {
   }
 }
 
+// max over each 32-lane unit (a G = 32 group, or half of a G = 64 group)
+DEV float umax32(float x) {
+  x = fmaxf(x, dpp_f<0xB1>(x)); x = fmaxf(x, dpp_f<0x4E>(x)); x = fmaxf(x, dpp_f<0x141>(x)); x = fmaxf(x, dpp_f<0x140>(x));
+  return fmaxf(x, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x401F)));
+}
+// plane - convex hull with one lane per hull vertex (MJX's 4-point manifold: deepest-1mm mask, a = first masked, b =
+// farthest from a, c = farthest from line ab, d = farthest from the other two edges).  Every selection is a max over the
+// unit, a ballot of the lanes that hold it and the lowest such lane - the same vertex the serial `>` scan keeps - and
+// the winner's coordinates come back through the crossbar.  Used by 64-lane groups, two pairs per pass (the code also
+// handles one pair per pass on a 32-lane unit).  Out of line: models without such pairs do not pay for its registers.
+//   geom_off / con_off / frame_off: LDS offsets of the lane's environment's geom poses, contacts and contact frames
+template <int G>
+__device__ __noinline__ void plane_convex_parallel(int pcx_first, int pcx_num, int c_pair, int c_vert, int geom_off, int con_off, int frame_off, int gl, int gb4) {
+  const int unit = G == 64 ? (gl >> 5) : 0, v = gl & 31, per_pass = G == 64 ? 2 : 1;
+  const int lane0 = (gb4 >> 2) + 32 * unit;  // first wave lane of my unit
+#define GEO(f, g) lds[geom_off + (g) * GEO_E + (f)]
+  for (int p0 = 0; p0 < pcx_num; p0 += per_pass) {
+    const bool pair_ok = p0 + unit < pcx_num;
+    const int pr = pcx_first + (pair_ok ? p0 + unit : 0), rec = c_pair + pr * PAIR_S;
+    const int g1 = CI(rec), g2 = CI(rec + 1), c0 = CI(rec + 3), nvt = CI(rec + 6), va = c_vert + 3 * CI(rec + 5);
+    const f3 pos1 = mk3(GEO(0, g1), GEO(1, g1), GEO(2, g1)), pos2 = mk3(GEO(0, g2), GEO(1, g2), GEO(2, g2));
+    m33 R2;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R2.a[k] = GEO(3 + k, g2);
+    const f3 nw = mk3(GEO(3 + 2, g1), GEO(3 + 5, g1), GEO(3 + 8, g1));
+    const f3 pl = mulTv(R2, pos1 - pos2), n = mulTv(R2, nw);
+    const bool on = pair_ok && v < nvt;
+    const int vi = on ? v : 0;
+    const f3 vt = mk3(CF(va + 3 * vi), CF(va + 3 * vi + 1), CF(va + 3 * vi + 2));
+    const float sup = dot(pl - vt, n);
+    const float smax = umax32(on ? sup : -1e30f);
+    const float thr = fmaxf(0.0f, smax - 1e-3f);
+    const float mask = sup > thr ? 0.0f : -1e6f;
+    // lowest lane of my unit whose score equals the unit's maximum; returns that vertex
+    auto pick = [&](float sc, int *idx) {
+      const float s = on ? sc : -1e30f;
+      const float best = umax32(s);
+      const unsigned long long bal = __ballot(s == best && on);
+      const unsigned mine = (unsigned)(bal >> (lane0 & 63));  // my unit's 32 bits start at its first lane
+      const int w = mine ? __builtin_ctz(mine) : 0;
+      *idx = w;
+      const int addr = 4 * (lane0 + w);
+      return mk3(__int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(vt.x))), __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(vt.y))),
+                 __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(vt.z))));
+    };
+    int idx[4];
+    const f3 a = pick(mask, &idx[0]);
+    const f3 da = a - vt;
+    const f3 bb = pick(dot(da, da) + mask, &idx[1]);
+    const f3 ab = cross(n, a - bb);
+    const f3 cc = pick(fabsf(dot(a - vt, ab)) + mask, &idx[2]);
+    const f3 ac = cross(n, a - cc), bc = cross(n, bb - cc);
+    // d: the serial scan runs over the bc scores first, then the ac scores continue with the same running maximum
+    const float s1 = fabsf(dot(bb - vt, bc)) + mask, s2 = fabsf(dot(a - vt, ac)) + mask;
+    const float m1 = umax32(on ? s1 : -1e30f), m2 = umax32(on ? s2 : -1e30f);
+    const f3 dd = pick(m2 > m1 ? s2 : s1, &idx[3]);
+    const f3 sel[4] = {a, bb, cc, dd};
+    if (pair_ok && v < 4) {  // lanes 0..3 of the unit write the four contacts
+      f3 me = sel[0];
+      int my = idx[0];
+      bool unique = true;
+#pragma unroll
+      for (int k = 1; k < 4; ++k) { if (v == k) { me = sel[k]; my = idx[k]; } }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) unique = unique && !(j < v && idx[j] == my);
+      const float d = unique ? -dot(pl - me, n) : 1.0f;
+      const f3 cp = pos2 + mulv(R2, me) - nw * (0.5f * d);
+      const int co = con_off + (c0 + v) * CON_E;
+      lds[co] = d; lds[co + 1] = cp.x; lds[co + 2] = cp.y; lds[co + 3] = cp.z;
+    }
+    if (pair_ok && v == 0) {
+      float fr[9];
+      make_frame(nw, fr);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) lds[frame_off + pr * 9 + k] = fr[k];
+    }
+  }
+#undef GEO
+  WSYNC();
+}
+
 // =====================================================================================================
 // One environment's physics, run by a group of G lanes.  `eb` is the group's slab in LDS (per-lane value,
 // equal inside a group); `gl` is the lane's index inside its group; constants live at the front of LDS.
@@ -894,7 +975,24 @@ struct Env {
   DEV void st_contact(int c, float d, f3 cp) const { con(0, c) = d; con(1, c) = cp.x; con(2, c) = cp.y; con(3, c) = cp.z; }
   DEV void collision() {
     const int np = m.npair;
-    if (gl < np) {
+    // plane-convex pairs with at most 32 hull vertices go to the vertex-parallel routine when they form one contiguous run of
+    // pair indices (pairs are grouped by function, so they do unless a larger hull sits among them); found with a ballot
+    // over the pair lanes rather than carried in the model descriptor, which has no scalar registers to spare
+    // (64-lane groups only: in the 32-lane kernel the extra code cost the quadruped 1 % without a model to gain from it)
+    int cx_first = 0, cx_num = 0;
+    if (G >= 64) {
+      const int rec0 = m.c_pair + (gl < np ? gl : 0) * PAIR_S;
+      const bool is_cx = gl < np && CI(rec0 + 2) == 2 && CI(rec0 + 6) <= 32;
+      const unsigned long long bal = __ballot(is_cx) >> ((gb4 >> 2) & 63);
+      const unsigned long long mine = G == 32 ? (bal & 0xFFFFFFFFull) : bal;
+      if (mine != 0ull) {
+        const int lo = __builtin_ctzll(mine), hi = 63 - __builtin_clzll(mine);
+        if (__builtin_popcountll(mine) == hi - lo + 1) { cx_first = lo; cx_num = hi - lo + 1; }
+      }
+    }
+    const bool par_cx = G >= 64 && cx_num > 0;  // one group per wave: uniform
+    if (par_cx) plane_convex_parallel<G>(cx_first, cx_num, m.c_pair, m.c_vert, eb + m.e_geom, eb + m.e_con, eb + m.e_frame, gl, gb4);
+    if (gl < np && !(gl >= cx_first && gl < cx_first + cx_num)) {
       const int pr = gl, rec = m.c_pair + pr * PAIR_S;
       const int g1 = CI(rec), g2 = CI(rec + 1), fn = CI(rec + 2), c0 = CI(rec + 3);
       const f3 pos1 = mk3(geo(0, g1), geo(1, g1), geo(2, g1)), pos2 = mk3(geo(0, g2), geo(1, g2), geo(2, g2));

@@ -453,3 +453,63 @@ def test_quadcost_shapes_vs_einsum(dev, S, N, nx, nu):
                  + torch.einsum("sti,ij,stj->s", us.double(), R.double(), us.double()))
     scale = 0.5 * (torch.einsum("sti,ij,stj->s", xc[:, :-1].abs(), Q.double().abs(), xc[:, :-1].abs()) + 1.0)
     assert ((val.cpu().double() - ref).abs() / scale).max() < 1e-6
+
+
+def test_plane_convex_vertex_parallel_paths(dev):
+    """Plane - convex hull contacts, lane-per-pair scan (16 / 32 lanes) and one lane per hull vertex (64 lanes): a box, two boxes and
+    a 12-vertex mesh in a model wide enough for G = 64 (two pairs per pass, odd pair count), nearly flat, tilted and
+    airborne.  One step and five steps against the oracle; the manifold selection must pick the same vertices (ties
+    included), otherwise the contact positions differ at the 1e-2 level."""
+    from ambersim_amd import mjx
+    from ambersim_amd.mjcf import MjModel
+    from oracle.oracle import Oracle
+    one_box = """<mujoco><option timestep="0.004" iterations="3" ls_iterations="5"/><worldbody><geom type="plane" size="5 5 .1"/>
+      <body name="b" pos="0 0 0.11"><freejoint/><geom type="box" size=".1 .15 .1" mass="1"/></body></worldbody></mujoco>"""
+    verts = " ".join(f"{x} {y} {z}" for x in (-.06, .06) for y in (-.04, .04) for z in (-.02, .02)) + " 0 0 0.05 0 0 -0.05 0.09 0 0 -0.09 0 0"
+    # 33 bodies (30 of them welded, massless-ish riders) force the 64-lane group; only the plane collides with the hulls
+    many = """<mujoco><option timestep="0.004" iterations="3" ls_iterations="5"/>
+      <asset><mesh name="m" vertex="%s"/></asset><worldbody><geom type="plane" size="5 5 .1"/>
+      <body name="b0" pos="0 0 0.3"><freejoint/><geom type="box" size=".1 .1 .05" mass="1" contype="0"/>
+        %s
+      </body>
+      <body name="c" pos="1 0 0.06"><freejoint/><geom type="mesh" mesh="m" mass="0.5" contype="0"/></body>
+      <body name="d" pos="-1 0 0.2" euler="0.3 0.2 0"><freejoint/><geom type="box" size=".05 .08 .03" mass="0.3" contype="0"/></body>
+      </worldbody></mujoco>""" % (verts, "".join(f'<body name="l{k}" pos="0.01 0 0"><inertial pos="0 0 0" mass="0.001" diaginertia="1e-7 1e-7 1e-7"/></body>' for k in range(30)))
+    results = {}
+    for xml, width, npairs in ((one_box, 16, 1), (one_box, 32, 1), (one_box, 64, 1), (many, 64, 3)):  # 16 lanes: the lane-per-pair scan
+        mj = MjModel.from_xml_string(xml)
+        assert mj.npair == npairs and set(mj.pair_fn.tolist()) == {2}
+        os.environ["AMX_FORCE_G"] = str(width)
+        try:
+            model = mjx.put_model(mj, dev)
+        finally:
+            del os.environ["AMX_FORCE_G"]
+        assert model._h.query("lanes_per_env") == width
+        rng = np.random.default_rng(11)
+        nenv = 16
+        q = np.tile(mj.qpos0, (nenv, 1))
+        for j in range(mj.njnt):
+            if mj.jnt_type[j] == 0:
+                a = mj.jnt_qposadr[j]
+                q[:, a + 2] += rng.uniform(-0.003, 0.15, nenv)         # resting / slightly penetrating / airborne
+                # tilted a little or a lot, never exactly flat: a flat box ties its four bottom corners and fp32 / fp64 may
+                # then legitimately pick different manifold points
+                quat = np.array([1.0, 0, 0, 0]) + rng.uniform(-0.3, 0.3, (nenv, 4)) * np.where(np.arange(nenv)[:, None] % 2, 1.0, 0.1)
+                q[:, a + 3:a + 7] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+        x0 = np.concatenate([q, 0.3 * rng.standard_normal((nenv, mj.nv))], axis=1).astype(np.float32)
+        us = np.zeros((nenv, 5, 0), dtype=np.float32)
+        xs = gpu_rollout(model, x0, us)
+        ref = Oracle(mj, np.float64).rollout(x0, us)
+        ref32 = Oracle(mj, np.float32).rollout(x0, us)
+        # per environment: a box pressed on four corners is an over-determined contact problem and an occasional draw
+        # amplifies fp32 rounding tenfold (the CPU fp32 oracle has such draws too) - all but two environments must meet the
+        # usual bound, none may be off by more than 1e-4
+        scale = max(1.0, np.abs(ref[:, 1]).max())
+        e1 = np.abs(xs[:, 1] - ref[:, 1]).max(axis=1) / scale
+        f1 = np.abs(ref32[:, 1] - ref[:, 1]).max(axis=1) / scale
+        assert (e1 <= np.maximum(TOL, 3 * f1)).sum() >= nenv - 2 and e1.max() < 1e-4, (width, e1, f1)
+        assert rel(xs[:, 5], ref[:, 5]) <= max(2e-4, 5 * rel(ref32[:, 5], ref[:, 5])), width
+        results[(xml is one_box, width)] = xs
+    # the vertex-parallel selection (64 lanes) picks the same manifold as the lane-per-pair scan (16 and 32 lanes)
+    for w in (32, 64):
+        assert rel(results[(True, w)][:, 1], results[(True, 16)][:, 1]) < 5e-6, w
