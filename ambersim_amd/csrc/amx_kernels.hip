@@ -1257,13 +1257,21 @@ struct Env {
     if (gl < m.nv) {
       float acc = 0;
       const int mem0 = CI(m.c_dofmemadr + gl), mem1 = CI(m.c_dofmemadr + gl + 1);
-      for (int t = mem0; t < mem1; ++t) {  // one term per contact whose ancestor chain holds this dof
-        const int pk = CI(m.c_dofmem + t), cr0 = pk & 255, slot = pk >> 8;
-        const int Jr = Jo + cr0 * ldc + slot, Fr = eb + m.e_row + (row0 + cr0) * ROW_E + 1;
-        float j[4], f[4];
+      // one term per contact whose ancestor chain holds this dof; two terms per trip so that their sixteen loads are in
+      // flight together (an odd tail re-reads the last term with weight 0)
+      for (int t = mem0; t < mem1; t += 2) {
+        const bool two = t + 1 < mem1;
+        const int pk0 = CI(m.c_dofmem + t), pk1 = CI(m.c_dofmem + (two ? t + 1 : t));
+        const int c0 = pk0 & 255, c1 = pk1 & 255;
+        const int Ja = Jo + c0 * ldc + (pk0 >> 8), Fa = eb + m.e_row + (row0 + c0) * ROW_E + 1;
+        const int Jb = Jo + c1 * ldc + (pk1 >> 8), Fb = eb + m.e_row + (row0 + c1) * ROW_E + 1;
+        float ja[4], fa[4], jb[4], fb[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { j[k] = lds[Jr + k * ldc]; f[k] = lds[Fr + k * ROW_E]; }
-        acc += (j[0] * f[0] + j[1] * f[1]) + (j[2] * f[2] + j[3] * f[3]);
+        for (int k = 0; k < 4; ++k) { ja[k] = lds[Ja + k * ldc]; fa[k] = lds[Fa + k * ROW_E]; jb[k] = lds[Jb + k * ldc]; fb[k] = lds[Fb + k * ROW_E]; }
+        const float sa = (ja[0] * fa[0] + ja[1] * fa[1]) + (ja[2] * fa[2] + ja[3] * fa[3]);
+        const float sb = (jb[0] * fb[0] + jb[1] * fb[1]) + (jb[2] * fb[2] + jb[3] * fb[3]);
+        acc += sa;
+        acc += two ? sb : 0.0f;
       }
       dof(D_FCON, gl) = acc;
     }
