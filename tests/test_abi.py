@@ -79,3 +79,14 @@ def test_capacity_limits_are_reported(mj_models):
     d = build_desc(big)
     assert lib.amx_model_create(C.byref(d), 0, C.byref(h)) == _lib.AMX_ECAPACITY
     assert b"nv=40" in lib.amx_last_error()
+
+
+def test_generated_c_descriptor_is_current(tmp_path):
+    """examples/c_host/pendulum_desc.h is what tools/dump_desc_c.py writes for the shipped pendulum (the C host uploads it)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "pendulum_desc.h"
+    subprocess.run([sys.executable, os.path.join(root, "tools", "dump_desc_c.py"), "models/pendulum/pendulum.xml", str(out), "pendulum"], check=True,
+                   capture_output=True, cwd=root)
+    strip = lambda s: "\n".join(l for l in s.splitlines() if not l.startswith("/* Generated"))
+    assert strip(out.read_text()) == strip(open(os.path.join(root, "examples", "c_host", "pendulum_desc.h")).read())

@@ -513,3 +513,17 @@ def test_plane_convex_vertex_parallel_paths(dev):
     # the vertex-parallel selection (64 lanes) picks the same manifold as the lane-per-pair scan (16 and 32 lanes)
     for w in (32, 64):
         assert rel(results[(True, w)][:, 1], results[(True, 16)][:, 1]) < 5e-6, w
+
+
+def test_c_host_over_the_abi():
+    """The drop-in boundary from plain C (examples/c_host): gcc links libamx.so + libamdhip64, uploads the pendulum from a
+    generated descriptor header, runs amx_rollout and checks the closed form itself (exit code 0)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "examples", "c_host")
+    subprocess.run(["make", "-C", d, "-B", "pendulum_host"], check=True, capture_output=True)
+    env = dict(os.environ)
+    env.pop("LD_PRELOAD", None)
+    r = subprocess.run([os.path.join(d, "pendulum_host")], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "max relative error vs closed form" in r.stdout
