@@ -23,7 +23,7 @@ class AmxForwardOut(C.Structure):
 
 
 EXPORTS = ["amx_version", "amx_last_error", "amx_model_create", "amx_model_destroy", "amx_model_query",
-           "amx_forward", "amx_step", "amx_rollout", "amx_quadcost"]
+           "amx_forward", "amx_step", "amx_rollout", "amx_quadcost", "amx_fd_workspace_bytes", "amx_fd_grad"]
 
 
 def build(force: bool = False) -> Path:
@@ -70,6 +70,9 @@ def lib() -> C.CDLL:
         L.amx_step.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_void_p]
         L.amx_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.amx_quadcost.argtypes = [C.c_int] * 4 + [C.c_void_p] * 7 + [C.c_void_p]
+        L.amx_fd_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
+        L.amx_fd_grad.argtypes = ([C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 5 +
+                                  [C.c_void_p, C.c_size_t, C.c_void_p])
         for name in EXPORTS:
             getattr(L, name)
         _lib = L

@@ -31,6 +31,22 @@ static int fail(int code, const char *fmt, ...) {
     if (e_ != hipSuccess) return fail(AMX_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_));    \
   } while (0)
 
+// Every entry point runs on the model's device and leaves the caller's current HIP device as it found it
+// (a host that drives several GPUs from one thread must not see its current device change under it).
+struct DeviceGuard {
+  int prev = -1;
+  bool good = true, changed = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) { good = hipSetDevice(dev) == hipSuccess; changed = good; }
+  }
+  ~DeviceGuard() { if (changed && prev >= 0) (void)hipSetDevice(prev); }
+  bool ok() const { return good; }
+};
+#define AMX_ON_DEVICE(dev)                                                        \
+  DeviceGuard guard_(dev);                                                        \
+  if (!guard_.ok()) return fail(AMX_EHIP, "hipSetDevice(%d) failed", (int)(dev))
+
 struct amx_model {
   DevModel dev;
   int device, ncu;
@@ -94,6 +110,46 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
   const int nb = d->nbody, nv = d->nv, nq = d->nq, nu = d->nu, nj = d->njnt, np = d->npair;
   if (nb > AMX_WAVE || nj > AMX_WAVE || np > AMX_WAVE)
     return fail(AMX_ECAPACITY, "lane-role capacity: nbody=%d njnt=%d npair=%d must each be <= %d", nb, nj, np, AMX_WAVE);
+
+  // ---- the descriptor comes across a public ABI: every index is range-checked before it is used as one
+  {
+    auto bad = [&](const char *field, int idx, int val, int lo, int hi) {
+      return fail(AMX_EINVAL, "amx_model_desc: %s[%d] = %d outside [%d, %d)", field, idx, val, lo, hi);
+    };
+#define AMX_CHK(field, idx, lo, hi) do { const int v_ = d->field[idx]; if (v_ < (lo) || v_ >= (hi)) return bad(#field, idx, v_, lo, hi); } while (0)
+    if (d->nu < 0 || d->njnt < 0 || d->ngeom < 0 || d->neq < 0 || d->npair < 0 || d->nconvexvert < 0) return fail(AMX_EINVAL, "negative size in amx_model_desc");
+    for (int b = 0; b < nb; b++) {
+      if (b > 0) AMX_CHK(body_parentid, b, 0, b);
+      if (d->body_jntnum[b] < 0 || d->body_dofnum[b] < 0) return fail(AMX_EINVAL, "body %d: negative joint/dof count", b);
+      if (d->body_jntnum[b] > 0 && (d->body_jntadr[b] < 0 || d->body_jntadr[b] + d->body_jntnum[b] > nj)) return bad("body_jntadr", b, d->body_jntadr[b], 0, nj);
+      if (d->body_dofnum[b] > 0 && (d->body_dofadr[b] < 0 || d->body_dofadr[b] + d->body_dofnum[b] > nv)) return bad("body_dofadr", b, d->body_dofadr[b], 0, nv);
+    }
+    static const int QW[4] = {7, 4, 1, 1}, DW[4] = {6, 3, 1, 1};
+    for (int j = 0; j < nj; j++) {
+      AMX_CHK(jnt_type, j, 0, 4);
+      AMX_CHK(jnt_bodyid, j, 1, nb);
+      const int t = d->jnt_type[j];
+      if (d->jnt_qposadr[j] < 0 || d->jnt_qposadr[j] + QW[t] > nq) return bad("jnt_qposadr", j, d->jnt_qposadr[j], 0, nq - QW[t] + 1);
+      if (d->jnt_dofadr[j] < 0 || d->jnt_dofadr[j] + DW[t] > nv) return bad("jnt_dofadr", j, d->jnt_dofadr[j], 0, nv - DW[t] + 1);
+    }
+    for (int i = 0; i < nv; i++) {
+      AMX_CHK(dof_bodyid, i, 1, nb);
+      AMX_CHK(dof_jntid, i, 0, nj);
+      AMX_CHK(dof_parentid, i, -1, i);
+      const int j = d->dof_jntid[i];
+      if (i < d->jnt_dofadr[j] || i >= d->jnt_dofadr[j] + DW[d->jnt_type[j]]) return fail(AMX_EINVAL, "dof %d does not belong to its joint %d", i, j);
+    }
+    for (int g = 0; g < d->ngeom; g++) AMX_CHK(geom_bodyid, g, 0, nb);
+    for (int p = 0; p < np; p++) {
+      AMX_CHK(pair_geom1, p, 0, d->ngeom);
+      AMX_CHK(pair_geom2, p, 0, d->ngeom);
+    }
+    for (int e = 0; e < d->neq; e++) {
+      AMX_CHK(eq_obj1id, e, 0, nj);
+      AMX_CHK(eq_obj2id, e, -1, nj);
+    }
+#undef AMX_CHK
+  }
 
   DevModel m;
   memset(&m, 0, sizeof(m));
@@ -217,7 +273,7 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
     for (int i = 0; i < nv; i++) if (sign[i]) pairdof.push_back(i | (sign[i] << 8));
     int dn = (int)pairdof.size() - d0;
     im.seti(o + 9, d0); im.seti(o + 10, dn);
-    if (dn > 16 || nv > 32) return fail(AMX_ECAPACITY, "pair %d couples %d dofs (limit 16: the row lanes keep the dof list in registers)", p, dn);
+    if (dn > 16) return fail(AMX_ECAPACITY, "pair %d couples %d dofs (limit 16: the row lanes keep the dof list in registers)", p, dn);
     maxchain = std::max(maxchain, dn);
     for (int a = 0; a < dn; a++) {
       for (int k = 0; k < PAIR_NCON[fn]; k++) dofmem[pairdof[d0 + a] & 255].push_back((4 * (ncon + k)) | (a << 8));
@@ -344,7 +400,8 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
   h->ncu = 0;
   h->device = device; h->ncon = m.ncon; h->nefc = m.nefc; h->lds_bytes = lds_bytes; h->d_image = nullptr;
   hipError_t e;
-  if ((e = hipSetDevice(device)) != hipSuccess || (e = hipMalloc((void **)&h->d_image, im.v.size() * sizeof(float))) != hipSuccess ||
+  DeviceGuard guard(device);
+  if ((e = guard.ok() ? hipSuccess : hipErrorInvalidDevice) != hipSuccess || (e = hipMalloc((void **)&h->d_image, im.v.size() * sizeof(float))) != hipSuccess ||
       (e = hipMemcpy(h->d_image, im.v.data(), im.v.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess ||
       (e = set_lds_limit(m.G, lds_bytes)) != hipSuccess) {
     if (h->d_image) (void)hipFree(h->d_image);
@@ -360,8 +417,10 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
 
 extern "C" int amx_model_destroy(amx_model *m) {
   if (!m) return AMX_OK;
-  (void)hipSetDevice(m->device);
-  (void)hipFree(m->d_image);
+  {
+    DeviceGuard guard(m->device);
+    (void)hipFree(m->d_image);
+  }
   delete m;
   return AMX_OK;
 }
@@ -403,7 +462,6 @@ static int choose_wpb(const amx_model *m, int nenv) {
   return best;
 }
 static int pre_launch(const amx_model *m, int nenv, dim3 *grid, int *wpb, int *lds_bytes) {
-  HIP_TRY(hipSetDevice(m->device));
   *wpb = choose_wpb(m, nenv);
   const int per_block = *wpb * (AMX_WAVE / m->dev.G);
   *lds_bytes = (m->dev.nconst + per_block * m->dev.env_floats) * (int)sizeof(float);
@@ -429,6 +487,7 @@ extern "C" int amx_forward(const amx_model *m, int nenv, const float *qpos, cons
     fo.qfrc_constraint = o->qfrc_constraint_dev; fo.qM = o->qM_dev; fo.xpos = o->xpos_dev; fo.xquat = o->xquat_dev;
     fo.cdist = o->contact_dist_dev; fo.nefc = o->nefc_dev;
   }
+  AMX_ON_DEVICE(m->device);
   dim3 grid;
   int wpb, lds_bytes;
   if (int rc = pre_launch(m, nenv, &grid, &wpb, &lds_bytes)) return rc;
@@ -441,6 +500,7 @@ extern "C" int amx_step(const amx_model *m, int nenv, int nsub, float *qpos, flo
                         float *time, void *stream) {
   if (!m || !qpos || !qvel || (m->dev.nu > 0 && !ctrl) || nenv < 0 || nsub < 0) return fail(AMX_EINVAL, "amx_step: bad argument");
   if (nenv == 0) return AMX_OK;
+  AMX_ON_DEVICE(m->device);
   dim3 grid;
   int wpb, lds_bytes;
   if (int rc = pre_launch(m, nenv, &grid, &wpb, &lds_bytes)) return rc;
@@ -459,6 +519,7 @@ extern "C" int amx_rollout(const amx_model *m, int nenv, int nsteps, const float
                            float *xfinal, void *stream) {
   if (!m || !x0 || nenv < 0 || nsteps < 0 || (nsteps > 0 && m->dev.nu > 0 && !us)) return fail(AMX_EINVAL, "amx_rollout: bad argument");
   if (nenv == 0) return AMX_OK;
+  AMX_ON_DEVICE(m->device);
   dim3 grid;
   int wpb, lds_bytes;
   if (int rc = pre_launch(m, nenv, &grid, &wpb, &lds_bytes)) return rc;
@@ -475,6 +536,15 @@ extern "C" int amx_quadcost(int nenv, int nsteps, int nx, int nu, const float *x
                             const float *R, const float *xg, float *cost, void *stream) {
   if (!xs || !Q || !Qf || !xg || !cost || (nu > 0 && (!us || !R)) || nenv < 0 || nsteps < 0) return fail(AMX_EINVAL, "amx_quadcost: bad argument");
   if (nenv == 0) return AMX_OK;
+  // this entry has no model handle: run on the device that owns the trajectories
+  int xdev = -1;
+  {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, xs) == hipSuccess) xdev = attr.device;
+    else (void)hipGetLastError();
+    if (xdev < 0 && hipGetDevice(&xdev) != hipSuccess) return fail(AMX_EHIP, "amx_quadcost: no current HIP device");
+  }
+  AMX_ON_DEVICE(xdev);
   // tiled matrix-core kernel when Q, R and four 32-row tiles fit in LDS; the entry-per-lane kernel otherwise
   const int nbx = (nx + 31) / 32, nbu = (nu + 31) / 32, ldy = 32 * std::max(nbx, std::max(nbu, 1)) + 5;
   const size_t lds_floats = (size_t)((nx + 3) & ~3) * 32 * nbx + (size_t)((nu + 3) & ~3) * 32 * nbu + 32 * nbx + (size_t)QC_WAVES * 32 * ldy;
@@ -485,5 +555,41 @@ extern "C" int amx_quadcost(int nenv, int nsteps, int nx, int nu, const float *x
     hipLaunchKernelGGL(amx_quadcost_kernel, dim3(nenv), dim3(AMX_WAVE), 0, (hipStream_t)stream, nenv, nsteps, nx, nu, xs, us, Q, Qf, R, xg, cost);
   }
   HIP_TRY(hipGetLastError());
+  return AMX_OK;
+}
+
+// ---- C4: forward-difference gradient of the terminal cost over the controls
+static size_t fd_us_bytes(const amx_model *m, int nsamples, int nsteps) {
+  const size_t b = (size_t)nsamples * (size_t)nsteps * (size_t)m->dev.nu * sizeof(float);
+  return (b + 255) & ~(size_t)255;
+}
+extern "C" int amx_fd_workspace_bytes(const amx_model *m, int nsamples, int nsteps, size_t *out) {
+  if (!m || !out || nsamples < 1 || nsteps < 0) return fail(AMX_EINVAL, "amx_fd_workspace_bytes: bad argument");
+  *out = fd_us_bytes(m, nsamples, nsteps) + (size_t)nsamples * (size_t)(m->dev.nq + m->dev.nv) * sizeof(float);
+  return AMX_OK;
+}
+extern "C" int amx_fd_grad(const amx_model *m, int nsamples, int nsteps, const float *x0, const float *us_nominal, const float *eps, int coord0,
+                           const float *Qf, const float *xg, float *J, float *grad, float *xfinal, void *workspace, size_t workspace_bytes,
+                           void *stream) {
+  if (!m || !x0 || !Qf || !xg || !J || !workspace || nsamples < 1 || nsteps < 0 || coord0 < 0 ||
+      (nsteps > 0 && m->dev.nu > 0 && (!us_nominal || !eps)))
+    return fail(AMX_EINVAL, "amx_fd_grad: bad argument");
+  size_t need = 0;
+  if (int rc = amx_fd_workspace_bytes(m, nsamples, nsteps, &need)) return rc;
+  if (workspace_bytes < need) return fail(AMX_EINVAL, "amx_fd_grad: workspace of %zu bytes, %zu needed", workspace_bytes, need);
+  AMX_ON_DEVICE(m->device);
+  float *us = (float *)workspace;
+  float *xf = (float *)((char *)workspace + fd_us_bytes(m, nsamples, nsteps));
+  const int nx = m->dev.nq + m->dev.nv, nu = m->dev.nu;
+  const size_t total = (size_t)nsamples * nsteps * nu;
+  if (total > 0) {
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(amx_fd_perturb_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, nsamples, nsteps, nu, coord0, us_nominal, eps, us);
+    HIP_TRY(hipGetLastError());
+  }
+  if (int rc = amx_rollout(m, nsamples, nsteps, x0, /*x0_batched=*/0, us, /*xs=*/nullptr, xf, stream)) return rc;
+  hipLaunchKernelGGL(amx_fd_cost_kernel, dim3(nsamples), dim3(AMX_WAVE), 0, (hipStream_t)stream, nsamples, nsteps, nx, nu, coord0, xf, Qf, xg, eps, J, grad);
+  HIP_TRY(hipGetLastError());
+  if (xfinal) HIP_TRY(hipMemcpyAsync(xfinal, xf, (size_t)nsamples * nx * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return AMX_OK;
 }

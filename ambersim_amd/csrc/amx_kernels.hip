@@ -1851,3 +1851,43 @@ extern "C" __global__ void __launch_bounds__(AMX_WAVE * QC_WAVES) amx_quadcost_m
   acc = wave_sum(acc);
   if (lane == 0) cost[e] = 0.5f * acc;
 }
+
+// ---- finite-difference gradient of the terminal cost (BASELINE.json configs[3]; include/amx.h amx_fd_grad) ----
+// us[k,t,i] = nominal[t,i] + (the flat coordinate t*nu+i is sample k's own ? eps[i] : 0); sample 0 is the nominal rollout.
+extern "C" __global__ void __launch_bounds__(256) amx_fd_perturb_kernel(int nsamples, int nsteps, int nu, int coord0, const float *__restrict__ nominal,
+                                                                       const float *__restrict__ eps, float *__restrict__ us) {
+  const int per = nsteps * nu;
+  const size_t total = (size_t)nsamples * per;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx / per), c = (int)(idx - (size_t)k * per);
+    float v = nominal[c];
+    if (k >= 1 && c == coord0 + k - 1) v += eps[c % nu];
+    us[idx] = v;
+  }
+}
+// One wave per sample: J[k] = 0.5 (x_N - xg)' Qf (x_N - xg) (reference cost.py:62-85 with Q = R = 0, the same entry order
+// as the terminal row of amx_quadcost), and the forward difference against sample 0 - every wave evaluates the nominal
+// cost itself (same operations, same order: bit-identical in all waves) instead of waiting for another wave's result.
+extern "C" __global__ void __launch_bounds__(AMX_WAVE) amx_fd_cost_kernel(int nsamples, int nsteps, int nx, int nu, int coord0, const float *__restrict__ xfinal,
+                                                                         const float *__restrict__ Qf, const float *__restrict__ xg,
+                                                                         const float *__restrict__ eps, float *__restrict__ J, float *__restrict__ grad) {
+  const int lane = threadIdx.x, k = blockIdx.x;
+  if (k >= nsamples) return;
+  const float *xk = xfinal + (size_t)k * nx;
+  float acc = 0.0f, acc0 = 0.0f;
+  for (int e = lane; e < nx * nx; e += AMX_WAVE) {
+    const int i = e / nx, j = e - i * nx;
+    const float w = Qf[e], gi = xg[i], gj = xg[j];
+    acc = __builtin_fmaf((xk[i] - gi) * w, xk[j] - gj, acc);
+    acc0 = __builtin_fmaf((xfinal[i] - gi) * w, xfinal[j] - gj, acc0);
+  }
+  acc = 0.5f * wave_sum(acc);
+  acc0 = 0.5f * wave_sum(acc0);
+  if (lane == 0) {
+    J[k] = acc;
+    if (k >= 1 && grad) {
+      const int c = coord0 + k - 1;
+      grad[k - 1] = c < nsteps * nu ? (acc - acc0) / eps[c % nu] : 0.0f;
+    }
+  }
+}

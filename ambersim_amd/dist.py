@@ -34,12 +34,18 @@ def shard_range(nenv_total: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_trajectories(xs_local: torch.Tensor, nenv_total: int | None = None) -> torch.Tensor:
+def gather_trajectories(xs_local: torch.Tensor, nenv_total: int | None = None, equal_blocks: bool = False) -> torch.Tensor:
     """All-gathers per-rank trajectory blocks [nenv_local, ...] into [nenv_total, ...] on every rank.
-    Equal blocks use one all_gather_into_tensor (a single RCCL all-gather); ragged blocks are padded."""
+    Equal blocks use one all_gather_into_tensor (a single RCCL all-gather); ragged blocks are padded.
+    `equal_blocks=True`: the caller guarantees every rank passes the same block shape (shard_range of a multiple of the
+    world size, bench.py's layout) - no size exchange and no host synchronisation, just the one collective."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return xs_local
     world = dist.get_world_size()
+    if equal_blocks:
+        out = torch.empty((world * xs_local.shape[0],) + tuple(xs_local.shape[1:]), dtype=xs_local.dtype, device=xs_local.device)
+        dist.all_gather_into_tensor(out, xs_local.contiguous())
+        return out
     n_local = torch.tensor([xs_local.shape[0]], dtype=torch.int64, device=xs_local.device)
     sizes = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(sizes, n_local)

@@ -206,6 +206,7 @@ class MjData(_Namespace):
                 qacc=np.zeros(model.nv), qacc_warmstart=np.zeros(model.nv), time=0.0,
             )
         super().__init__(**kw)
+        self._model = model  # mujoco.MjData knows its model; mjx.device_put(MjData) needs its sizes
 
 
 # ----------------------------------------------------------------------------- parsing

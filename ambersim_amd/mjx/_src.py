@@ -19,7 +19,10 @@ class SolverType:
 
 def _dev(device=None) -> torch.device:
     if device is not None:
-        return torch.device(device)
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        return device
     if not torch.cuda.is_available():
         raise RuntimeError("ambersim_amd.mjx needs a GPU (MI355X): no HIP device is visible and there is no CPU fallback")
     return torch.device("cuda", torch.cuda.current_device())
@@ -156,76 +159,117 @@ def make_data(m: Model, nenv: Optional[int] = None) -> Data:
                 xquat=torch.zeros(shape(m.nbody) + (4,), dtype=torch.float32, device=dev))
 
 
+def _host_data(d: MjData, dev: torch.device, nbody: int) -> Data:
+    f = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32), device=dev)
+    nv = int(np.asarray(d.qvel).shape[-1])
+    z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+    return Data(qpos=f(d.qpos), qvel=f(d.qvel), ctrl=f(d.ctrl), qacc=f(d.qacc), qacc_warmstart=f(d.qacc_warmstart),
+                time=torch.tensor(float(d.time), dtype=torch.float32, device=dev), qacc_smooth=z(nv), qfrc_bias=z(nv),
+                qfrc_constraint=z(nv), xpos=z(nbody, 3), xquat=z(nbody, 4))
+
+
 def put_data(m: Model, d: MjData) -> Data:
-    out = make_data(m)
-    f = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32), device=m.device)
-    return out.replace(qpos=f(d.qpos), qvel=f(d.qvel), ctrl=f(d.ctrl), qacc_warmstart=f(d.qacc_warmstart),
-                       time=torch.tensor(float(d.time), dtype=torch.float32, device=m.device))
+    return _host_data(d, m.device, m.nbody)
 
 
 def device_put(x, device=None):
-    """mjx.device_put for a host model (reference ambersim/rl/base.py:52).  A host MjData needs its model:
-    use `put_data(model, data)` (MjxEnv.pipeline_init does)."""
+    """mjx.device_put: a host MjModel -> Model (reference ambersim/rl/base.py:52, ambersim/utils/io_utils.py:225); a host
+    MjData -> Data on the device (reference ambersim/rl/base.py:83, inside MjxEnv.pipeline_init)."""
     if isinstance(x, MjModel):
         return put_model(x, device)
-    raise NotImplementedError("device_put accepts a host MjModel; for MjData use put_data(model, data)")
+    if isinstance(x, MjData):
+        mj = getattr(x, "_model", None)
+        if mj is None:
+            raise ValueError("device_put(MjData): this MjData was not created from an MjModel (MjData(model))")
+        return _host_data(x, _dev(device), mj.nbody)
+    raise NotImplementedError(f"device_put accepts a host MjModel or MjData, got {type(x).__name__}")
 
 
 def _c(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous() if not t.is_contiguous() else t
 
 
-def _batch(m: Model, d: Data):
-    b = d.batched
-    g = (lambda t: _c(t.to(torch.float32))) if b else (lambda t: _c(t.to(torch.float32).unsqueeze(0)))
-    return b, g
+def _prep(m: Model, d: Data, names):
+    """Validates the Data leaves a kernel will read against the model and returns them as contiguous fp32 [n, width]
+    tensors on the model's device.  The batch size is the leading axis of qpos; a leaf without a batch axis (e.g. the
+    zero `ctrl` the reference's pipeline_init sets, ambersim/rl/base.py:84) is broadcast to it.  Anything else - wrong
+    trailing size, another batch size, another device - is a ValueError here instead of an out-of-bounds access there."""
+    width = {"qpos": m.nq, "qvel": m.nv, "ctrl": m.nu, "qacc_warmstart": m.nv}
+    qpos = d.qpos
+    if not torch.is_tensor(qpos) or qpos.dim() not in (1, 2):
+        raise ValueError("Data.qpos must be a tensor of shape [nq] or [nenv, nq]")
+    batched = qpos.dim() == 2
+    n = qpos.shape[0] if batched else 1
+    out = {}
+    for name in names:
+        t = getattr(d, name)
+        if not torch.is_tensor(t):
+            raise ValueError(f"Data.{name} must be a tensor")
+        if t.device != m.device:
+            raise ValueError(f"Data.{name} lives on {t.device}, the model on {m.device}")
+        if t.dim() not in (1, 2) or t.shape[-1] != width[name]:
+            raise ValueError(f"Data.{name} has shape {tuple(t.shape)}, expected [..., {width[name]}]")
+        if t.dim() == 2 and t.shape[0] != n:
+            raise ValueError(f"Data.{name} has batch {t.shape[0]}, qpos has {n}")
+        t = t.to(torch.float32)
+        if t.dim() == 1:
+            t = t.unsqueeze(0).expand(n, -1)
+        out[name] = _c(t)
+    return batched, n, out
 
 
 def forward(m: Model, d: Data) -> Data:
     """mjx.forward (reference ambersim/rl/base.py:85, ambersim/trajopt/shooting.py:36): derived quantities, no integration."""
-    b, g = _batch(m, d)
-    qpos, qvel, ctrl, warm = g(d.qpos).clone(), g(d.qvel), g(d.ctrl), g(d.qacc_warmstart)
-    n = qpos.shape[0]
+    b, n, t = _prep(m, d, ("qpos", "qvel", "ctrl", "qacc_warmstart"))
+    qpos, qvel, ctrl, warm = t["qpos"], t["qvel"], t["ctrl"], t["qacc_warmstart"]
     dev = m.device
     new = lambda *s: torch.empty((n,) + s, dtype=torch.float32, device=dev)
     qacc, qs, fb, fc, xpos, xquat = new(m.nv), new(m.nv), new(m.nv), new(m.nv), new(m.nbody, 3), new(m.nbody, 4)
     out = _lib.AmxForwardOut(qacc.data_ptr(), qs.data_ptr(), fb.data_ptr(), fc.data_ptr(), None, xpos.data_ptr(), xquat.data_ptr(), None, None)
-    _lib.check(_lib.lib().amx_forward(m._h.ptr, n, qpos.data_ptr(), qvel.data_ptr(), ctrl.data_ptr(), warm.data_ptr(),
-                                      C.byref(out), _stream_ptr(dev)))
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().amx_forward(m._h.ptr, n, qpos.data_ptr(), qvel.data_ptr(), ctrl.data_ptr(), warm.data_ptr(),
+                                          C.byref(out), _stream_ptr(dev)))
     s = (lambda t: t) if b else (lambda t: t[0])
     # the solver's result becomes the next warm start, as in the reference physics
     warm_out = qacc if m.nefc_max > 0 else warm
     return d.replace(qacc=s(qacc), qacc_smooth=s(qs), qfrc_bias=s(fb), qfrc_constraint=s(fc), xpos=s(xpos), xquat=s(xquat),
-                     qacc_warmstart=s(warm_out))
+                     qacc_warmstart=s(warm_out), qvel=s(qvel), ctrl=s(ctrl))
 
 
 def step(m: Model, d: Data, nsub: int = 1) -> Data:
     """mjx.step, `nsub` times with ctrl held (reference ambersim/rl/base.py:88-96).  Functional: returns new Data."""
-    b, g = _batch(m, d)
-    qpos, qvel, warm = g(d.qpos).clone(), g(d.qvel).clone(), g(d.qacc_warmstart).clone()
-    ctrl = g(d.ctrl)
-    n = qpos.shape[0]
-    time = (d.time if b else d.time.reshape(1)).to(torch.float32).clone()
-    time = _c(time.expand(n)) if time.numel() != n else time
-    _lib.check(_lib.lib().amx_step(m._h.ptr, n, int(nsub), qpos.data_ptr(), qvel.data_ptr(), ctrl.data_ptr(), warm.data_ptr(),
-                                   time.data_ptr(), _stream_ptr(m.device)))
+    b, n, t = _prep(m, d, ("qpos", "qvel", "ctrl", "qacc_warmstart"))
+    qpos, qvel, warm = t["qpos"].clone(), t["qvel"].clone(), t["qacc_warmstart"].clone()  # updated in place by the kernel
+    ctrl = t["ctrl"]
+    time = d.time if torch.is_tensor(d.time) else torch.tensor(float(d.time or 0.0))
+    time = time.to(device=m.device, dtype=torch.float32).reshape(-1)
+    if time.numel() not in (1, n):
+        raise ValueError(f"Data.time has {time.numel()} entries, the batch has {n}")
+    time = time.expand(n).clone()
+    with torch.cuda.device(m.device):
+        _lib.check(_lib.lib().amx_step(m._h.ptr, n, int(nsub), qpos.data_ptr(), qvel.data_ptr(), ctrl.data_ptr(), warm.data_ptr(),
+                                       time.data_ptr(), _stream_ptr(m.device)))
     s = (lambda t: t) if b else (lambda t: t[0])
-    return d.replace(qpos=s(qpos), qvel=s(qvel), qacc_warmstart=s(warm), qacc=s(warm) if m.nefc_max > 0 else d.qacc, time=s(time))
+    return d.replace(qpos=s(qpos), qvel=s(qvel), qacc_warmstart=s(warm), qacc=s(warm) if m.nefc_max > 0 else d.qacc, time=s(time),
+                     ctrl=s(ctrl))
 
 
 def rollout(m: Model, x0: torch.Tensor, us: torch.Tensor, return_traj: bool = True):
     """Fused shoot (reference ambersim/trajopt/shooting.py:22-48) for a batch: x0 [nx] or [S,nx], us [S,N,nu]
     -> xs [S,N+1,nx] (or the final states [S,nx] when return_traj is False)."""
     dev = m.device
+    nx = m.nq + m.nv
+    if us.dim() != 3 or x0.dim() not in (1, 2):
+        raise ValueError(f"rollout: x0 must be [nx] or [S,nx] and us [S,N,nu], got {tuple(x0.shape)} and {tuple(us.shape)}")
     us = _c(us.to(device=dev, dtype=torch.float32))
     x0 = _c(x0.to(device=dev, dtype=torch.float32))
     S, N = us.shape[0], us.shape[1]
-    nx = m.nq + m.nv
-    if us.shape[2] != m.nu or x0.shape[-1] != nx or (x0.dim() == 2 and x0.shape[0] != S):
+    if x0.dim() not in (1, 2) or us.shape[2] != m.nu or x0.shape[-1] != nx or (x0.dim() == 2 and x0.shape[0] != S):
         raise ValueError(f"rollout: shapes x0 {tuple(x0.shape)}, us {tuple(us.shape)} do not match nx={nx}, nu={m.nu}")
     xs = torch.empty((S, N + 1, nx), dtype=torch.float32, device=dev) if return_traj else None
     xf = None if return_traj else torch.empty((S, nx), dtype=torch.float32, device=dev)
-    _lib.check(_lib.lib().amx_rollout(m._h.ptr, S, N, x0.data_ptr(), int(x0.dim() == 2), us.data_ptr(),
-                                      xs.data_ptr() if xs is not None else None, xf.data_ptr() if xf is not None else None,
-                                      _stream_ptr(dev)))
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().amx_rollout(m._h.ptr, S, N, x0.data_ptr(), int(x0.dim() == 2), us.data_ptr(),
+                                          xs.data_ptr() if xs is not None else None, xf.data_ptr() if xf is not None else None,
+                                          _stream_ptr(dev)))
     return xs if return_traj else xf

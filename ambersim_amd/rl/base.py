@@ -63,10 +63,10 @@ class MjxEnv(ABC):
 
     def pipeline_init(self, qpos: torch.Tensor, qvel: torch.Tensor) -> mjx.Data:
         """device data <- (qpos, qvel, ctrl=0), then one forward (reference :81-86)."""
-        n = qpos.shape[0] if qpos.dim() == 2 else None
-        data = mjx.make_data(self.sys, n)
-        data = data.replace(qpos=qpos, qvel=qvel, ctrl=torch.zeros_like(data.ctrl))
-        return mjx.forward(self.sys, data)
+        data = mjx.device_put(self.data, self.sys.device)
+        data = data.replace(qpos=qpos, qvel=qvel, ctrl=torch.zeros(self.sys.nu))  # unbatched leaves broadcast to qpos' batch
+        data = mjx.forward(self.sys, data)
+        return data
 
     def pipeline_step(self, data: mjx.Data, ctrl: torch.Tensor) -> mjx.Data:
         """`physics_steps_per_control_step` physics steps with ctrl held (reference :88-96): one fused launch."""

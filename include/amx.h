@@ -9,6 +9,8 @@
  *   amx_step           <- lax.scan of mjx.step            ambersim/rl/base.py:88-96  (MjxEnv.pipeline_step)
  *   amx_rollout        <- shoot(m, x0, us) under vmap     ambersim/trajopt/shooting.py:22-48,152
  *   amx_quadcost       <- StaticGoalQuadraticCost.cost    ambersim/trajopt/cost.py:62-85 (batched over rollouts)
+ *   amx_fd_grad        <- shoot + terminal cost, forward-differenced over ctrl (BASELINE.json configs[3]; composes
+ *                         ambersim/trajopt/shooting.py:22-48 and ambersim/trajopt/cost.py:62-85 with Q = R = 0)
  *
  * Conventions: plain pointers and sizes only.  Pointers named *_dev are device (HBM)
  * addresses owned by the caller (e.g. torch tensors); every other pointer is host memory.
@@ -125,6 +127,21 @@ int amx_rollout(const amx_model *m, int nenv, int nsteps, const float *x0_dev, i
 int amx_quadcost(int nenv, int nsteps, int nx, int nu, const float *xs_dev, const float *us_dev,
                  const float *Q_dev, const float *Qf_dev, const float *R_dev, const float *xg_dev,
                  float *cost_dev, void *stream);
+
+/* Finite-difference gradient of the terminal cost of a shooting rollout with respect to the controls
+ * (BASELINE.json configs[3], SURVEY.md 8(d) "C4 inputs"; the reference itself has no finite-difference code, this
+ * composes its shoot() and StaticGoalQuadraticCost.cost with Q = R = 0).  `nsamples` rollouts of `nsteps` steps start
+ * from ONE shared state x0[nq+nv]: rollout 0 runs under us_nominal[nsteps,nu]; rollout k >= 1 adds eps[i] to the single
+ * control coordinate c = coord0 + k - 1 (step t = c / nu, actuator i = c % nu; coordinates >= nsteps*nu leave the
+ * rollout unperturbed and give grad = 0).  Outputs: J[k] = 0.5 (x_N - xg)' Qf (x_N - xg) for every rollout and
+ * grad[k-1] = (J[k] - J[0]) / eps[i].  One call = one perturbation kernel, one fused rollout (final states only, no
+ * trajectory traffic) and one cost/difference kernel, all on `stream`.  xfinal_dev ([nsamples,nq+nv]) may be NULL.
+ * workspace_dev must hold amx_fd_workspace_bytes() bytes (perturbed controls + final states). */
+int amx_fd_workspace_bytes(const amx_model *m, int nsamples, int nsteps, size_t *out);
+int amx_fd_grad(const amx_model *m, int nsamples, int nsteps, const float *x0_dev, const float *us_nominal_dev,
+                const float *eps_dev /*[nu]*/, int coord0, const float *Qf_dev /*[nx,nx]*/, const float *xg_dev /*[nx]*/,
+                float *J_dev /*[nsamples]*/, float *grad_dev /*[nsamples-1]*/, float *xfinal_dev,
+                void *workspace_dev, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -106,3 +106,43 @@ class Oracle:
 
     def max_threads(self):
         return self.lib.amxo_max_threads()
+
+
+def quadcost(xs, us, Q, Qf, R, xg):
+    """Explicit restatement of StaticGoalQuadraticCost.cost (reference ambersim/trajopt/cost.py:62-85) in the dtype of xs,
+    batched over a leading axis: 0.5*[sum_{t<N}(x_t-xg)'Q(x_t-xg) + (x_N-xg)'Qf(x_N-xg) + sum_t u_t'R u_t]."""
+    xs = np.asarray(xs)
+    dt = xs.dtype
+    e = xs - np.asarray(xg, dtype=dt)
+    val = np.einsum("...ti,ij,...tj->...", e[..., :-1, :], np.asarray(Q, dtype=dt), e[..., :-1, :])
+    val = val + np.einsum("...i,ij,...j->...", e[..., -1, :], np.asarray(Qf, dtype=dt), e[..., -1, :])
+    if us is not None and np.asarray(us).size:
+        u = np.asarray(us, dtype=dt)
+        val = val + np.einsum("...ti,ij,...tj->...", u, np.asarray(R, dtype=dt), u)
+    return (0.5 * val).astype(dt)
+
+
+def fd_grad_terminal_cost(oracle: "Oracle", x0, us_nominal, Qf, xg, eps, nsamples, coord0=0, nthreads=0):
+    """CPU counterpart of amx_fd_grad (BASELINE.json configs[3]): rollout 0 nominal, rollout k adds
+    eps[i] to flat control coordinate c = coord0+k-1 (t = c // nu, i = c % nu); J = terminal cost (cost.py:62-85 with
+    Q = R = 0), g[k-1] = (J[k]-J[0])/eps[i].  Everything in the oracle's dtype.  Returns (J, g, xfinal)."""
+    dt = oracle.dtype
+    us_nominal = np.asarray(us_nominal, dtype=dt)
+    N, nu = us_nominal.shape
+    eps = np.asarray(eps, dtype=dt)
+    us = np.tile(us_nominal[None], (nsamples, 1, 1))
+    flat = us.reshape(nsamples, N * nu)
+    for k in range(1, nsamples):
+        c = coord0 + k - 1
+        if c < N * nu:
+            flat[k, c] = flat[k, c] + eps[c % nu]
+    xs = oracle.rollout(np.asarray(x0, dtype=dt), us, nthreads=nthreads)
+    xf = xs[:, -1]
+    e = xf - np.asarray(xg, dtype=dt)
+    J = (0.5 * np.einsum("ki,ij,kj->k", e, np.asarray(Qf, dtype=dt), e)).astype(dt)
+    g = np.zeros(nsamples - 1, dtype=dt)
+    for k in range(1, nsamples):
+        c = coord0 + k - 1
+        if c < N * nu:
+            g[k - 1] = (J[k] - J[0]) / eps[c % nu]
+    return J, g, xf

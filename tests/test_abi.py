@@ -22,7 +22,7 @@ def declared_functions():
 
 def test_library_exports_every_declared_symbol():
     names = declared_functions()
-    assert set(names) == set(_lib.EXPORTS) and len(names) == 9
+    assert set(names) == set(_lib.EXPORTS) and len(names) == 11
     lib = _lib.lib()
     for n in names:
         assert hasattr(lib, n), n
@@ -65,6 +65,31 @@ def test_error_reporting_without_gpu(mj_models):
         _lib.check(_lib.AMX_EINVAL)
     assert lib.amx_rollout(None, 1, 1, None, 0, None, None, None, None) == _lib.AMX_EINVAL
     assert lib.amx_quadcost(1, 1, 1, 1, None, None, None, None, None, None, None, None) == _lib.AMX_EINVAL
+    assert lib.amx_fd_grad(None, 2, 1, None, None, None, 0, None, None, None, None, None, None, 0, None) == _lib.AMX_EINVAL
+    assert lib.amx_fd_workspace_bytes(None, 2, 1, None) == _lib.AMX_EINVAL
+
+
+def test_descriptor_indices_are_validated(mj_models):
+    """amx_model_create is a public ABI: a descriptor with an out-of-range index is refused with AMX_EINVAL naming the
+    field, before any of it is used as an index (no GPU needed: validation precedes the upload)."""
+    import numpy as np
+    lib = _lib.lib()
+    h = C.c_void_p()
+
+    def corrupt(field, idx, val):
+        d = build_desc(mj_models["quadruped"])
+        arr = np.ctypeslib.as_array(getattr(d, field), shape=(idx + 1,)).copy()
+        arr[idx] = val
+        d._keep = getattr(d, "_keep", []) + [arr]
+        setattr(d, field, arr.ctypes.data_as(C.POINTER(C.c_int)))
+        rc = lib.amx_model_create(C.byref(d), 0, C.byref(h))
+        return rc, lib.amx_last_error().decode()
+
+    for field, idx, val in [("body_parentid", 3, 7), ("jnt_qposadr", 2, 1000), ("jnt_dofadr", 1, -3), ("dof_bodyid", 4, 99),
+                            ("dof_parentid", 5, 5), ("dof_jntid", 0, 40), ("geom_bodyid", 1, -2), ("pair_geom1", 0, 500),
+                            ("jnt_type", 1, 9), ("jnt_bodyid", 1, 0)]:
+        rc, msg = corrupt(field, idx, val)
+        assert rc == _lib.AMX_EINVAL and field in msg, (field, rc, msg)
 
 
 def test_capacity_limits_are_reported(mj_models):
