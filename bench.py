@@ -1,29 +1,83 @@
 #!/usr/bin/env python3
 """Headline benchmark: env-steps/sec of the fused rollout (BASELINE.json metric).
 
-One "step" = one amx_rollout launch over one batch: NENV envs x HORIZON physics steps of the
-build-authored quadruped (4096 envs, random ctrl, 1000-step rollout), inputs
-resident in HBM.  With --gpus N every rank runs its own NENV envs (weak scaling, no collective in the
-data path) and the returned trajectories are all-gathered over RCCL once per step, overlapped with the next rollout.
+One "step" = one amx_rollout launch over one batch: NENV envs x HORIZON physics steps, inputs resident in HBM.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+  N = 1   headline = BASELINE.md C2 (build-authored quadruped, 4096 envs, random ctrl, 1000-step rollout); the same JSON
+          line carries `secondary`: C3 (the ~30-DoF biped, 4096 x 1000, north_star's target config) with its own roofline,
+          C4 (1024 x 64 forward-difference gradient through amx_fd_grad) and the FP32 figure (flop census of the CPU
+          oracle / 157.3 TFLOP/s, VALU-busy from the committed PMC pass); `cpu_baseline`; the MJX-CPU probe.
+  N > 1   C5: every rank runs its own 4096 envs of the biped (weak scaling, no collective in the data path) and the
+          returned trajectories are all-gathered over RCCL once per step, overlapped with the next rollout; the line
+          carries `scaling_report` (rollout alone, gather alone, with / without overlap).
+
+`python bench.py --gpus N` is self-contained: with WORLD_SIZE unset and N > 1 the parent - which has not imported torch
+or touched the GPU - starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process, relays
+its output and returns its exit code.  Under an external torchrun (WORLD_SIZE set) it is a plain rank.
+`--dry-run` replaces the kernel by a zero-filled trajectory on the CPU (gloo): it exercises the launcher, the sharding and
+the gather path without a GPU (tests/test_dist_cpu.py).
+
+Prints ONE JSON line on rank 0 (contract in the task statement).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md); 6290 GB/s measured copy
+HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md); 6290 GB/s measured copy
+FP32_PEAK_TFLOPS = 157.3  # MI355X FP32 vector peak (same guide)
+QUADRUPED = "models/quadruped/quadruped.xml"
+BIPED = "models/biped/biped.xml"
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nenv", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--horizon", type=int, default=1000)
+    ap.add_argument("--model", default=None, help=f"default: {QUADRUPED} (C2) at N=1, {BIPED} (C5) at N>1")
+    ap.add_argument("--gather", choices=["traj", "none"], default="traj", help="N>1: all-gather returned trajectories")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="N=1: skip the C3 / C4 / FP32 secondary measurements")
+    ap.add_argument("--no-overlap", action="store_true", help="N>1: wait for each all-gather before the next rollout")
+    ap.add_argument("--no-scaling-report", action="store_true", help="N>1: skip the extra rollout-only / gather-only timings")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: zero trajectories on the CPU, gloo collectives")
+    ap.add_argument("--master-port", type=int, default=0, help="self-launch only: rendezvous port (0 = pick a free one)")
+    return ap.parse_args(argv)
+
+
+# --------------------------------------------------------------------------------------------- self-launch (no torch here)
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """Parent of an N > 1 run started from a plain shell.  Nothing in this process has imported torch or initialised
+    HIP, and it never replaces itself: the ranks are children of a torch.distributed.run child."""
+    port = args.master_port or free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + [a for a in argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
+
+
+# --------------------------------------------------------------------------------------------- inputs
 def make_inputs(mj, nenv, horizon, seed_state, seed_ctrl, device):
     """Standing keyframe + N(0, 0.01^2) joint-velocity noise (seed 1); ctrl ~ U(ctrlrange) i.i.d. (seed 2)."""
+    import numpy as np
     import torch
     q0 = mj.key_qpos[0] if mj.nkey else mj.qpos0
     rng = np.random.default_rng(seed_state)
@@ -36,28 +90,48 @@ def make_inputs(mj, nenv, horizon, seed_state, seed_ctrl, device):
     return torch.tensor(x0, device=device), us
 
 
-def pmc_traffic(default_workload):
-    """HBM bytes per launch of the rollout kernel from the committed rocprofv3 PMC passes (profiles/, collected with
-    tools/pmc_collect.sh: FETCH_SIZE and WRITE_SIZE in separate passes, KiB).  gfx950 correction from the guide: FETCH_SIZE
-    tallies 128-byte read requests at 64 bytes, so it is doubled; WRITE_SIZE is exact.  Only valid for the default workload."""
-    path = os.path.join(ROOT, "profiles", "r01_rocprofv3_pmc_amx_rollout.csv")
-    if not default_workload or not os.path.exists(path):
+def pmc_record(model_path, nenv, horizon):
+    """Recorded (NOT measured by this run) rocprofv3 PMC figures of the rollout kernel for the default workloads, from the
+    newest committed profiles/rNN_rocprofv3_pmc_<model>.csv (tools/pmc_collect.sh: one counter per pass).  gfx950
+    correction from the guide: FETCH_SIZE tallies 128-byte read requests at 64 bytes, so it is doubled; WRITE_SIZE is exact."""
+    import glob
+    if nenv != 4096 or horizon != 1000:
+        return None
+    tag = os.path.basename(model_path).split(".")[0]
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_rocprofv3_pmc_{tag}.csv")))
+    if not cands and tag == "quadruped":
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_rocprofv3_pmc_amx_rollout.csv")))
+    if not cands:
         return None
     vals = {}
-    for line in open(path):
+    for line in open(cands[-1]):
         p = line.strip().split(",")
-        if len(p) >= 2 and p[0] in ("FETCH_SIZE", "WRITE_SIZE"):
-            vals[p[0]] = float(p[1])
-    if len(vals) != 2:
-        return None
-    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+        if len(p) >= 2:
+            try:
+                vals[p[0]] = float(p[1])
+            except ValueError:
+                pass
+    out = {"file": os.path.relpath(cands[-1], ROOT)}
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+        out["hbm_bytes_per_launch"] = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    if "valu_busy_frac" in vals:
+        out["valu_busy_frac"] = vals["valu_busy_frac"]
+    return out
 
 
-def cpu_baseline(mj, x0_np, us_np, target_s=12.0):
+def cpu_baseline(mj, x0_np, us_np, target_s):
     """Times the CPU oracle (oracle/amx_oracle.c, fp32, OpenMP over envs, all host threads) on a bounded sample of the
-    same workload: whole-horizon rollouts of the first envs, repeated until about `target_s` seconds of wall time."""
+    same workload: whole-horizon rollouts of the first envs, repeated until about `target_s` seconds of wall time.  The
+    timed library is built here, on the host that runs it, with -O3 -march=native (`make -C oracle native`); if that
+    build fails the portable -O2 build is timed and the sample string says so."""
     from oracle.oracle import Oracle
-    o = Oracle(mj, np.float32)
+    flags = "-O3 -march=native"
+    try:
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "native"], check=True, capture_output=True, timeout=300)
+        o = Oracle(mj, variant="native")
+    except Exception as e:  # no compiler / read-only tree: the portable build still gives a baseline
+        o = Oracle(mj, "float32")
+        flags = f"-O2 (native build failed: {type(e).__name__})"
     cores = o.max_threads()
     nenv = min(us_np.shape[0], 8 * cores)
     horizon = us_np.shape[1]
@@ -70,109 +144,276 @@ def cpu_baseline(mj, x0_np, us_np, target_s=12.0):
         if dt >= target_s:
             break
     return {"value": done / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{done // (nenv * horizon)} x ({nenv} envs x {horizon} steps) of the same workload, fp32 C oracle "
-                      f"(oracle/amx_oracle.c), OpenMP over envs, {dt:.1f} s"}
+            "sample": f"{done // (nenv * horizon)} x ({nenv} envs x {horizon} steps) of the same workload, fp32 C restatement of the MJX algorithm "
+                      f"(oracle/amx_oracle.c: dense M, dense Cholesky, scalar loops; gcc {flags}), OpenMP over envs, {dt:.1f} s"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--nenv", type=int, default=4096, help="envs per GPU")
-    ap.add_argument("--horizon", type=int, default=1000)
-    ap.add_argument("--model", default="models/quadruped/quadruped.xml")
-    ap.add_argument("--gather", choices=["traj", "none"], default="traj", help="N>1: all-gather returned trajectories")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="N>1: wait for each all-gather before the next rollout")
-    args = ap.parse_args()
+def probe_mjx_cpu():
+    """is MJX-on-CPU (jax[cpu] + mujoco.mjx) available on this box?  Import probe only."""
+    missing = []
+    for mod in ("jax", "mujoco", "mujoco.mjx"):
+        try:
+            __import__(mod)
+        except Exception as e:
+            missing.append(f"{mod}: {type(e).__name__}")
+    return "available (not timed here)" if not missing else "unavailable on this box (" + "; ".join(missing) + ") - cpu_baseline is the build's own CPU restatement"
 
+
+def flop_census(mj, x0_np, us_np, nsteps=40):
+    """Arithmetic operations per env-step of the restated algorithm (oracle flop census, fp64 counting build), averaged
+    over `nsteps` steps of the first envs of the workload."""
+    import numpy as np
+    from oracle.oracle import Oracle
+    oc = Oracle(mj, variant="count")
+    tot, n = 0.0, 0
+    for e in range(min(4, x0_np.shape[0])):
+        oc.set_state(x0_np[e, :mj.nq], x0_np[e, mj.nq:], np.zeros(mj.nu), np.zeros(mj.nv))
+        oc.forward()
+        oc.lib.amxo_flops_read_and_reset.restype = __import__("ctypes").c_double
+        oc.lib.amxo_flops_read_and_reset()
+        for t in range(min(nsteps, us_np.shape[1])):
+            oc.set_state(None, None, us_np[e, t], None)
+            oc.step()
+        tot += oc.lib.amxo_flops_read_and_reset()
+        n += min(nsteps, us_np.shape[1])
+    return tot / n
+
+
+def roofline(mj, nenv, horizon, kern_ms, model_path):
+    nx = mj.nq + mj.nv
+    bytes_per_launch = 4.0 * (mj.nu + nx) * nenv * horizon  # ctrl row in, state row out per env-step (SURVEY.md §8d)
+    achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+    rec = pmc_record(model_path, nenv, horizon)
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": rec.get("hbm_bytes_per_launch") if rec else None,
+            "traffic_source": (f"RECORDED, not measured by this run: rocprofv3 PMC passes in {rec['file']} (2*FETCH_SIZE + WRITE_SIZE, KiB)" if rec else None),
+            "kernel": "amx_rollout_kernel", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+            "binding": "the named bound (north_star) is HBM; the counters say the kernel is VALU-issue / dependent-latency bound "
+                       "(DESIGN.md §4): algorithmic intensity ~1e3 flop/B against a machine balance of ~25"}
+
+
+# --------------------------------------------------------------------------------------------- one rank
+def worker(args):
+    import numpy as np
     import torch
     import torch.distributed as dist
-    from ambersim_amd import mjx
     from ambersim_amd.dist import gather_trajectories, gather_trajectories_async, init_from_env
     from ambersim_amd.utils.io_utils import load_mj_model_from_file
 
-    rank, world, local = init_from_env()
+    rank, world, local = init_from_env("gloo" if args.dry_run else None)
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dry = args.dry_run
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    sync = (lambda: None) if dry else torch.cuda.synchronize
 
-    mj = load_mj_model_from_file(args.model)
-    model = mjx.put_model(mj, dev)
-    x0, us = make_inputs(mj, args.nenv, args.horizon, 1 + 1000 * rank, 2 + 1000 * rank, dev)
+    model_path = args.model or (QUADRUPED if world == 1 else BIPED)
+    mj = load_mj_model_from_file(model_path)
     nx = mj.nq + mj.nv
+    if dry:
+        model = None
+        x0 = torch.zeros(args.nenv, nx)
+        us = torch.zeros(args.nenv, args.horizon, mj.nu)
+        rollout = lambda: torch.full((args.nenv, args.horizon + 1, nx), float(rank))
+    else:
+        from ambersim_amd import mjx
+        model = mjx.put_model(mj, dev)
+        x0, us = make_inputs(mj, args.nenv, args.horizon, 1 + 1000 * rank, 2 + 1000 * rank, dev)
+        rollout = lambda: mjx.rollout(model, x0, us)
 
-    overlap = world > 1 and args.gather == "traj" and not args.no_overlap
-
-    def run_steps(nsteps, events=None):
-        """`nsteps` rollouts; with N > 1 each trajectory block is all-gathered.  The gather of step k runs on the
-        communication stream while rollout k+1 runs on the compute stream (at most two gathers in flight); all of them
-        are complete when this returns (the caller synchronises)."""
+    def run_steps(nsteps, mode, events=None):
+        """`nsteps` rollouts.  mode "overlap": the all-gather of step k runs on the communication stream while rollout k+1
+        runs on the compute stream (at most two gathers in flight); "serial": each gather is waited for; "none": no
+        gather.  Everything is complete when this returns (the caller synchronises)."""
         pending, xs = [], None
         for k in range(nsteps):
             if events is not None:
                 events[k][0].record()  # HIP events on the launch stream (torch's current stream is the one handed to amx_rollout)
-            xs = mjx.rollout(model, x0, us)
+            xs = rollout()
             if events is not None:
                 events[k][1].record()
-            if world > 1 and args.gather == "traj":
-                if overlap:
-                    pending.append(gather_trajectories_async(xs))
-                    if len(pending) > 2:
-                        pending.pop(0)[1].wait()
-                else:
-                    xs = gather_trajectories(xs)
+            if world > 1 and mode == "overlap":
+                pending.append(gather_trajectories_async(xs))
+                if len(pending) > 2:
+                    pending.pop(0)[1].wait()
+            elif world > 1 and mode == "serial":
+                xs = gather_trajectories(xs, equal_blocks=True)
         for out, work in pending:
             work.wait()
             xs = out
         return xs
 
-    run_steps(args.warmup)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    xs = run_steps(args.steps, ev)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    def timed(nsteps, mode, with_events=False):
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
+        ev = None
+        if with_events and not dry:
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nsteps)]
+        t0 = time.perf_counter()
+        xs = run_steps(nsteps, mode, ev)
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
+        return elapsed, kern_ms, xs
+
+    mode = "none" if (world == 1 or args.gather == "none") else ("serial" if args.no_overlap else "overlap")
+    run_steps(args.warmup, mode)
+    elapsed, kern_ms, xs = timed(args.steps, mode, with_events=True)
     finite = bool(torch.isfinite(xs).all().item())
+    if dry:
+        # gathered blocks are in rank order: block r is filled with r
+        want = torch.arange(world, dtype=torch.float32).repeat_interleave(args.nenv) if mode != "none" else torch.full((args.nenv,), float(rank))
+        assert torch.equal(xs[:, 0, 0], want), "gathered trajectory blocks are out of order"
+
+    report = None
+    if world > 1 and not args.no_scaling_report:
+        k = args.steps
+        t_roll, _, _ = timed(k, "none")
+        t_serial, _, _ = timed(k, "serial")
+        t_over, _, _ = timed(k, "overlap")
+        xs_local = rollout()
+        sync()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            gather_trajectories(xs_local, equal_blocks=True)
+        sync()
+        dist.barrier()
+        t_gather = time.perf_counter() - t0
+        tg = torch.tensor([t_gather], dtype=torch.float64, device=dev)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        t_gather = float(tg.item())
+        es = args.nenv * args.horizon * k * world
+        gb = xs_local.numel() * 4 * world / 1e9
+        report = {"rollout_only_env_steps_per_s": es / t_roll, "with_gather_serial_env_steps_per_s": es / t_serial,
+                  "with_gather_overlapped_env_steps_per_s": es / t_over, "gather_alone_ms": 1e3 * t_gather / k,
+                  "gathered_GB_per_rank": gb, "gather_GBps_per_rank_received": gb * (world - 1) / world / (t_gather / k),
+                  "note": "single-GPU throughput of this workload = the C3 entry under `secondary` of the N=1 line"}
 
     if rank == 0:
         env_steps = args.nenv * args.horizon * args.steps * world
-        bytes_per_launch = 4.0 * (mj.nu + nx) * args.nenv * args.horizon  # ctrl row in, state row out per env-step
-        achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
+        tag = {QUADRUPED: "BASELINE.md C2", BIPED: "BASELINE.md C3 per GPU / C5 sharded"}.get(model_path, "custom")
         out = {
             "metric": "env-steps/sec, 4096 envs x 1000-step rollout",
             "value": env_steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{os.path.basename(args.model)} (build-authored, BASELINE.md C2), {args.nenv} envs/GPU x "
+            "dtype": "f32", "data": "synthetic" + (" (dry run: no kernel, zero trajectories on the CPU)" if dry else ""),
+            "config": {"workload": f"{os.path.basename(model_path)} (build-authored, {tag}), {args.nenv} envs/GPU x "
                                    f"{args.horizon}-step fused rollout, random ctrl ~U(ctrlrange), Newton {mj.opt.iterations} it / "
                                    f"{mj.opt.ls_iterations} ls, dt={mj.opt.timestep}",
                        "nenv_per_gpu": args.nenv, "horizon": args.horizon, "nq": mj.nq, "nv": mj.nv, "nu": mj.nu,
-                       "gather": (args.gather + ("+overlapped" if overlap else "")) if world > 1 else "none", "outputs_finite": finite},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(args.nenv == 4096 and args.horizon == 1000 and args.model.endswith("quadruped.xml")),
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_rocprofv3_pmc_amx_rollout.csv)",
-                         "kernel": "amx_rollout_kernel", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
+                       "gather": {"none": "none", "serial": "traj", "overlap": "traj+overlapped"}[mode], "outputs_finite": finite},
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(mj, x0.cpu().numpy(), us.cpu().numpy())
+        if not dry:
+            out["roofline"] = roofline(mj, args.nenv, args.horizon, kern_ms, model_path)
+        if report:
+            out["scaling_report"] = report
+        if world == 1 and not dry:
+            x0_np, us_np = x0.cpu().numpy(), us.cpu().numpy()
+            if not args.no_secondary:
+                out["secondary"] = secondary(args, model, mj, model_path, x0_np, us_np, kern_ms, dev)
+            out["mjx_cpu"] = probe_mjx_cpu()
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(mj, x0_np, us_np, target_s=10.0)
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def secondary(args, model, mj, model_path, x0_np, us_np, kern_ms, dev):
+    """N = 1 extras: C3 (biped rollout, its own roofline + CPU baseline), C4 (FD gradient), the FP32 figure."""
+    import numpy as np
+    import torch
+    from ambersim_amd import mjx
+    from ambersim_amd.trajopt.fd import fd_eps, fd_grad_terminal_cost
+    from ambersim_amd.utils.io_utils import load_mj_model_from_file
+    out = []
+
+    def fp32(mj_, x0n, usn, steps_per_s, path):
+        fl = flop_census(mj_, x0n, usn)
+        rec = pmc_record(path, args.nenv, args.horizon)
+        return {"algorithmic_flops_per_env_step": fl, "achieved_tflops": fl * steps_per_s / 1e12, "peak_tflops": FP32_PEAK_TFLOPS,
+                "frac": fl * steps_per_s / 1e12 / FP32_PEAK_TFLOPS,
+                "flops_source": "flop census of the CPU restatement (oracle/count_real.hpp: every +,-,*,/,sqrt,sin,cos on a REAL), dense algorithm",
+                "valu_busy_frac": rec.get("valu_busy_frac") if rec else None,
+                "valu_busy_source": (f"RECORDED: {rec['file']}" if rec and "valu_busy_frac" in rec else None)}
+
+    steps_per_s = args.nenv * args.horizon / (kern_ms * 1e-3)
+    out.append({"name": "fp32_valu", "workload": os.path.basename(model_path), **fp32(mj, x0_np, us_np, steps_per_s, model_path)})
+
+    if model_path != BIPED:
+        mjb = load_mj_model_from_file(BIPED)
+        mb = mjx.put_model(mjb, dev)
+        x0b, usb = make_inputs(mjb, args.nenv, args.horizon, 1, 2, dev)
+        mjx.rollout(mb, x0b, usb)
+        torch.cuda.synchronize()
+        k = 3
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(k)]
+        t0 = time.perf_counter()
+        for a, b in ev:
+            a.record()
+            xs = mjx.rollout(mb, x0b, usb)
+            b.record()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        kms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        x0bn, usbn = x0b.cpu().numpy(), usb.cpu().numpy()
+        entry = {"name": "C3", "metric": "env-steps/sec, 4096 envs x 1000-step rollout", "value": args.nenv * args.horizon * k / el, "unit": "env-steps/s",
+                 "steps": k, "ms_per_step": 1e3 * el / k,
+                 "config": {"workload": f"biped.xml (build-authored ~30-DoF biped, two 12-vertex convex-mesh feet on a plane; BASELINE.md C3, north_star's target), "
+                                        f"{args.nenv} envs x {args.horizon}-step fused rollout, random ctrl", "nq": mjb.nq, "nv": mjb.nv, "nu": mjb.nu,
+                            "outputs_finite": bool(torch.isfinite(xs).all().item())},
+                 "roofline": roofline(mjb, args.nenv, args.horizon, kms, BIPED),
+                 "fp32_valu": fp32(mjb, x0bn, usbn, args.nenv * args.horizon / (kms * 1e-3), BIPED)}
+        if not args.no_cpu_baseline:
+            entry["cpu_baseline"] = cpu_baseline(mjb, x0bn, usbn, target_s=6.0)
+        out.append(entry)
+        del xs, usb
+        # C4: 1024 rollouts x 64 knots from one x0, forward-difference gradient of the terminal cost (amx_fd_grad)
+        S, N = 1024, 64
+        nxb = mjb.nq + mjb.nv
+        lo = torch.tensor(mjb.actuator_ctrlrange[:, 0], dtype=torch.float32, device=dev)
+        hi = torch.tensor(mjb.actuator_ctrlrange[:, 1], dtype=torch.float32, device=dev)
+        g = torch.Generator(device=dev).manual_seed(4)
+        usn = 0.5 * (lo + hi) + 0.25 * (hi - lo) * (2 * torch.rand((N, mjb.nu), generator=g, device=dev) - 1)
+        Qf = torch.eye(nxb, device=dev)
+        call = lambda: fd_grad_terminal_cost(mb, x0b[0], usn, Qf, x0b[0], fd_eps(mb), nsamples=S)
+        call()
+        torch.cuda.synchronize()
+        k = 10
+        t0 = time.perf_counter()
+        for _ in range(k):
+            r = call()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        out.append({"name": "C4", "metric": "env-steps/sec, 1024 rollouts x 64 knots, forward-difference gradient of the terminal cost wrt ctrl",
+                    "value": S * N * k / el, "unit": "env-steps/s", "steps": k, "ms_per_gradient_launch": 1e3 * el / k,
+                    "config": {"workload": f"biped.xml, {S} rollouts x {N} steps from one shared x0 (rollout 0 nominal, rollout k perturbs control coordinate k-1 "
+                                           "by 1e-3*range), terminal cost + difference on device (amx_fd_grad: 3 kernels, final states only)",
+                               "coordinates_per_launch": S - 1, "grad_finite": bool(torch.isfinite(r.grad).all().item())}})
+    return out
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, argv))
+    worker(args)
 
 
 if __name__ == "__main__":

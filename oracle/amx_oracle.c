@@ -17,7 +17,8 @@
  * Call sites restated:  mjx.forward / mjx.step  — ambersim/rl/base.py:85,93;
  *                       ambersim/trajopt/shooting.py:36,41.   shoot — trajopt/shooting.py:22-48.
  *
- * Build: see oracle/Makefile (-DREAL=double -> libamxo_f64.so, -DREAL=float -> libamxo_f32.so).
+ * Build: see oracle/Makefile (-DREAL=double -> libamxo_f64.so, -DREAL=float -> libamxo_f32.so; `native`: the fp32 build
+ * with -O3 -march=native for bench.py's cpu_baseline leg, built on the machine that times it; `count`: the flop census).
  * Dense M, dense Cholesky, scalar loops in MJX's stage order; one env per call, OpenMP over envs.
  */
 #include <math.h>
@@ -32,10 +33,20 @@
 #define REAL double
 #endif
 #define IS_FLOAT (sizeof(REAL) == 4)
-static inline REAL r_sqrt(REAL x) { return IS_FLOAT ? (REAL)sqrtf((float)x) : (REAL)sqrt((double)x); }
-static inline REAL r_sin(REAL x) { return IS_FLOAT ? (REAL)sinf((float)x) : (REAL)sin((double)x); }
-static inline REAL r_cos(REAL x) { return IS_FLOAT ? (REAL)cosf((float)x) : (REAL)cos((double)x); }
-static inline REAL r_pow(REAL x, REAL y) { return IS_FLOAT ? (REAL)powf((float)x, (float)y) : (REAL)pow((double)x, (double)y); }
+/* Flop census build (oracle/Makefile: libamxo_count.so): this file compiled as C++ with REAL = CountReal
+ * (oracle/count_real.hpp), every arithmetic operation on a REAL adds one to amxo_flop_count. */
+#ifdef AMXO_COUNT_FLOPS
+thread_local double amxo_flop_count = 0;
+#define FLOP1() (amxo_flop_count += 1)
+extern "C" {
+double amxo_flops_read_and_reset(void) { double c = amxo_flop_count; amxo_flop_count = 0; return c; }
+#else
+#define FLOP1() ((void)0)
+#endif
+static inline REAL r_sqrt(REAL x) { FLOP1(); return IS_FLOAT ? (REAL)sqrtf((float)x) : (REAL)sqrt((double)x); }
+static inline REAL r_sin(REAL x) { FLOP1(); return IS_FLOAT ? (REAL)sinf((float)x) : (REAL)sin((double)x); }
+static inline REAL r_cos(REAL x) { FLOP1(); return IS_FLOAT ? (REAL)cosf((float)x) : (REAL)cos((double)x); }
+static inline REAL r_pow(REAL x, REAL y) { FLOP1(); return IS_FLOAT ? (REAL)powf((float)x, (float)y) : (REAL)pow((double)x, (double)y); }
 static inline REAL r_abs(REAL x) { return x < 0 ? -x : x; }
 static inline REAL r_max(REAL a, REAL b) { return a > b ? a : b; }
 static inline REAL r_min(REAL a, REAL b) { return a < b ? a : b; }
@@ -1100,3 +1111,6 @@ int amxo_max_threads(void) {
   return 1;
 #endif
 }
+#ifdef AMXO_COUNT_FLOPS
+} /* extern "C" */
+#endif

@@ -21,9 +21,9 @@ def build():
 
 
 def _lib(dtype):
-    key = np.dtype(dtype).name
+    key = dtype if dtype in ("native", "count") else np.dtype(dtype).name
     if key not in _LIBS:
-        name = {"float64": "libamxo_f64.so", "float32": "libamxo_f32.so"}[key]
+        name = {"float64": "libamxo_f64.so", "float32": "libamxo_f32.so", "native": "libamxo_f32_native.so", "count": "libamxo_count.so"}[key]
         path = _DIR / name
         if not path.exists():
             build()
@@ -49,9 +49,12 @@ def _lib(dtype):
 class Oracle:
     """One model + one scratch data block in the chosen precision."""
 
-    def __init__(self, mj_model, dtype=np.float64):
-        self.dtype = np.dtype(dtype)
-        self.lib = _lib(dtype)
+    def __init__(self, mj_model, dtype=np.float64, variant=None):
+        """variant: None (portable -O2 build), "native" (fp32, -O3 -march=native, `make -C oracle native` on this host) or
+        "count" (flop census build: fp64 arithmetic through a counting scalar)."""
+        self.dtype = np.dtype(np.float32 if variant == "native" else (np.float64 if variant == "count" else dtype))
+        self.lib = _lib(variant or dtype)
+        self.variant = variant
         self.mj = mj_model
         if getattr(mj_model, "nunsupported_pairs", 0):
             raise NotImplementedError("model has collision pairs outside the implemented pair functions")
@@ -106,6 +109,18 @@ class Oracle:
 
     def max_threads(self):
         return self.lib.amxo_max_threads()
+
+    def flops_per_step(self, qpos, qvel, ctrl, nsteps=1):
+        """Flop census (variant="count" only): arithmetic operations on REALs executed by `nsteps` amxo_step calls from the
+        given state, per step.  Single-threaded by construction (the counter is thread-local)."""
+        assert self.variant == "count"
+        self.lib.amxo_flops_read_and_reset.restype = C.c_double
+        self.set_state(qpos, qvel, ctrl, np.zeros(self.nv))
+        self.forward()
+        self.lib.amxo_flops_read_and_reset()
+        for _ in range(nsteps):
+            self.step()
+        return self.lib.amxo_flops_read_and_reset() / nsteps
 
 
 def quadcost(xs, us, Q, Qf, R, xg):

@@ -49,3 +49,54 @@ def test_gloo_shard_and_gather(tmp_path, nenv_total):
     for r in range(world):
         got = np.load(tmp_path / f"rank{r}.npy")
         assert got.shape == (nenv_total, 4, 3) and np.array_equal(got, expect)
+
+
+def test_equal_blocks_gather_skips_the_size_exchange(tmp_path):
+    world = 2
+    mp.spawn(_worker_equal, args=(world, _free_port()), nprocs=world, join=True)
+
+
+def _worker_equal(rank, world, port):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from ambersim_amd.dist import gather_trajectories, init_from_env
+    init_from_env("gloo")
+    xs = torch.full((3, 2, 5), float(rank))
+    full = gather_trajectories(xs, equal_blocks=True)
+    assert full.shape == (6, 2, 5) and torch.equal(full[:, 0, 0], torch.tensor([0., 0., 0., 1., 1., 1.]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("extra", [[], ["--no-overlap"], ["--gather", "none"]])
+def test_bench_self_launch_dry_run(extra):
+    """`python bench.py --gpus 2` from a plain shell (WORLD_SIZE unset): the parent starts torch.distributed.run as a child
+    before importing torch, both ranks run, rank 0 prints ONE JSON line, the exit code is the child's.  --dry-run swaps
+    the kernel for zero trajectories on the CPU over gloo, everything else (sharding, barriers, gathers in rank order,
+    overlap bookkeeping, scaling report) is the real code path."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run", "--nenv", "6",
+           "--horizon", "4"] + extra
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak" and out["value"] > 0
+    assert "biped.xml" in out["config"]["workload"] and out["config"]["nenv_per_gpu"] == 6  # C5 default for N > 1
+    want = {"": "traj+overlapped", "--no-overlap": "traj", "--gather": "none"}[extra[0] if extra else ""]
+    assert out["config"]["gather"] == want
+    rep = out["scaling_report"]
+    assert rep["gather_alone_ms"] > 0 and rep["rollout_only_env_steps_per_s"] > 0
+
+
+def test_bench_self_launch_propagates_failure():
+    """A rank that dies makes `python bench.py --gpus N` exit non-zero (here: --gpus disagrees with the forced model path)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--model", "models/does_not_exist.xml", "--nenv", "2", "--horizon", "2"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]

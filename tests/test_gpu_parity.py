@@ -132,8 +132,9 @@ def test_forward_outputs(cases, golden, name):
     # qM and nefc through the raw C ABI
     dev = model.device
     qM = torch.empty((n, mj.nv, mj.nv), device=dev); nefc = torch.zeros(n, dtype=torch.int32, device=dev)
+    cdist = torch.zeros((n, max(model.ncon, 1)), device=dev)
     tq, tv, tu = (torch.tensor(a, dtype=torch.float32, device=dev) for a in (q, v, u))
-    out = _lib.AmxForwardOut(None, None, None, None, qM.data_ptr(), None, None, None, nefc.data_ptr())
+    out = _lib.AmxForwardOut(None, None, None, None, qM.data_ptr(), None, None, cdist.data_ptr(), nefc.data_ptr())
     _lib.check(_lib.lib().amx_forward(model._h.ptr, n, tq.data_ptr(), tv.data_ptr(), tu.data_ptr(), None, C.byref(out), None))
     torch.cuda.synchronize()
     o = Oracle(mj, np.float64)
@@ -146,6 +147,17 @@ def test_forward_outputs(cases, golden, name):
         assert rel(d.qacc_smooth[e].cpu().numpy(), o.get("qacc_smooth")) < 2e-5
         assert rel(d.qacc[e].cpu().numpy(), o.get("qacc")) < 1e-4  # solver output: conditioning of H amplifies fp32 rounding
         assert int(nefc[e]) == int(o.get("nefc")[0])
+        # J' * efc_force: the same conditioning as qacc (it is M (qacc - qacc_smooth))
+        fc, fc_ref = d.qfrc_constraint[e].cpu().numpy(), o.get("qfrc_constraint")
+        assert np.abs(fc - fc_ref).max() < 1e-4 * max(1.0, np.abs(fc_ref).max())
+        if model.ncon:
+            # signed contact distances: the same contacts are active and their depths agree.  (Inactive slots may differ: with
+            # every hull vertex above the plane all manifold scores carry the -1e6 mask, which swallows the distances in fp32
+            # - there, like MJX in fp32, the kernel keeps the first vertices where the fp64 oracle still ranks them.)
+            cd, cd_ref = cdist[e, :model.ncon].cpu().numpy(), o.get("con_dist")
+            act = cd_ref < 0
+            assert np.array_equal(cd < 0, act) and (not act.any() or np.abs(cd[act] - cd_ref[act]).max() < TOL)
+            assert (cd[~act] > 0).all()
 
 
 def test_step_api_matches_rollout_bitwise(cases):
@@ -204,6 +216,33 @@ def test_full_size_properties(dev):
     hi = torch.tensor(mj.jnt_range[1:, 1], device=dev) + 0.35
     q = xs[:, :, 7:19]
     assert bool(((q > lo) & (q < hi)).all())  # soft joint limits hold under random control
+
+
+def test_full_size_properties_biped(dev):
+    """BASELINE.md C3 at full size (4096 envs x 1000 steps of the biped, convex-mesh feet on the plane; north_star's target
+    config): finite, x0 row preserved, size-independent (the first envs are bit-identical to a small launch of the same
+    envs, whatever the residency of the big launch), quaternions stay normalised, soft joint limits hold under random
+    torques (only the feet collide with the floor in this model: a biped that falls keeps going)."""
+    from ambersim_amd import mjx
+    from ambersim_amd.utils.io_utils import load_mj_model_from_file
+    from bench import make_inputs
+    mj = load_mj_model_from_file("models/biped/biped.xml")
+    model = mjx.put_model(mj, dev)
+    x0, us = make_inputs(mj, 4096, 1000, 1, 2, dev)
+    xs = mjx.rollout(model, x0, us)
+    assert xs.shape == (4096, 1001, mj.nq + mj.nv) and bool(torch.isfinite(xs).all())
+    assert torch.equal(xs[:, 0], x0)
+    small = mjx.rollout(model, x0[:6], us[:6])
+    assert torch.equal(small, xs[:6])
+    last = mjx.rollout(model, x0[-3:], us[-3:])
+    assert torch.equal(last, xs[-3:])
+    quat_norm = xs[:, :, 3:7].norm(dim=-1)
+    assert float((quat_norm - 1).abs().max()) < 1e-4
+    lim = torch.tensor(mj.jnt_range[1:], dtype=torch.float32, device=dev)
+    q = xs[:, :, 7:mj.nq]
+    assert bool(((q > lim[:, 0] - 0.5) & (q < lim[:, 1] + 0.5)).all())  # soft limits: overshoot bounded under full random torques
+    xf = mjx.rollout(model, x0[:64], us[:64], return_traj=False)
+    assert torch.equal(xf, xs[:64, -1])  # the final-state-only output (C4's path) is the last trajectory row
 
 
 @pytest.mark.parametrize("flags,solver", [(0, 1), (16, 2), (64 | 16, 2), (16384, 2), (256, 2)])
