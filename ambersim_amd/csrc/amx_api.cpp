@@ -15,6 +15,7 @@
 #include "../../include/amx.h"
 #include "amx_dev.h"
 
+#include "amx_specs_gen.h"
 #include "amx_kernels.hip"  // single translation unit: kernels + launchers, no relocatable device code
 
 static thread_local char g_err[512] = "";
@@ -49,6 +50,7 @@ struct DeviceGuard {
 
 struct amx_model {
   DevModel dev;
+  int spec;  // index into AMX_SPECS of the compile-time specialisation whose plan equals this model's, -1 = generic kernels
   int device, ncu;
   float *d_image;
   int ncon, nefc, lds_bytes;
@@ -56,12 +58,28 @@ struct amx_model {
 
 template <int G> static hipError_t set_lds_limit_g(int bytes) {
   hipError_t e;
-  if ((e = hipFuncSetAttribute((const void *)amx_rollout_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return e;
-  if ((e = hipFuncSetAttribute((const void *)amx_step_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return e;
-  return hipFuncSetAttribute((const void *)amx_forward_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if ((e = hipFuncSetAttribute((const void *)amx_rollout_kernel<G, DynSpec>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute((const void *)amx_step_kernel<G, DynSpec>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return e;
+  return hipFuncSetAttribute((const void *)amx_forward_kernel<G, DynSpec>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 static hipError_t set_lds_limit(int G, int bytes) {
   return G == 16 ? set_lds_limit_g<16>(bytes) : (G == 32 ? set_lds_limit_g<32>(bytes) : set_lds_limit_g<64>(bytes));
+}
+
+// Runs f(Spec{}) for the spec with index `spec`; false when there is none (generic kernels).
+template <class F> static bool for_spec(int spec, F &&f) {
+  int idx = 0;
+  bool done = false;
+#define X(S) if (!done && spec == idx) { f(S{}); done = true; } idx++;
+  AMX_SPECS(X)
+#undef X
+  return done;
+}
+template <class S> static hipError_t set_lds_limit_spec(int bytes) {
+  hipError_t e;
+  if ((e = hipFuncSetAttribute((const void *)amx_rollout_kernel<S::G, S>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute((const void *)amx_step_kernel<S::G, S>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return e;
+  return hipFuncSetAttribute((const void *)amx_forward_kernel<S::G, S>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 namespace {
@@ -99,8 +117,30 @@ void write_kbi(Image &im, int off, const double *solref, const double *solimp, d
 extern "C" int amx_version(void) { return AMX_VERSION; }
 extern "C" const char *amx_last_error(void) { return g_err; }
 
-extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model **out) {
-  if (!d || !out) return fail(AMX_EINVAL, "null argument");
+// True when J' D J has the sparsity of the dof tree: every contact pair's dof list and every two-joint equality couple dofs
+// that lie on ONE ancestor chain (plane - body contacts do; contacts between two branches and mimic joints across fingers do
+// not).  Then H = M + J'DJ is eliminated leaves-first without fill-in, like M (static sparse Gauss-Jordan of a spec).
+static bool plan_tree_H(const amx_model_desc *d, const DevModel &m, const Image &im) {
+  auto is_anc = [&](int a, int i) { for (int k = i; k >= 0; k = d->dof_parentid[k]) if (k == a) return true; return false; };
+  for (int p = 0; p < m.npair; p++) {
+    const int o = m.c_pair + p * PAIR_S, d0 = im.geti(o + 9), dn = im.geti(o + 10);
+    for (int a = 0; a < dn; a++)
+      for (int b = 0; b < a; b++) {
+        const int i = im.geti(m.c_pairdof + d0 + a) & 255, j = im.geti(m.c_pairdof + d0 + b) & 255;
+        if (!is_anc(j, i) && !is_anc(i, j)) return false;
+      }
+  }
+  for (int r = 0; r < m.neq; r++) {
+    const int o = m.c_eq + r * EQ_S, d1 = im.geti(o + 1), d2 = im.geti(o + 3);
+    if (d2 >= 0 && !is_anc(d1, d2) && !is_anc(d2, d1)) return false;
+  }
+  return true;
+}
+
+// Host-only part of amx_model_create: validates the descriptor and builds the constant image and the launch plan.
+// No HIP call in here (tools/gen_specs.py runs it without a GPU through amx_model_plan_describe).
+static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
+  if (!d) return fail(AMX_EINVAL, "null argument");
   if (d->version != AMX_VERSION) return fail(AMX_EINVAL, "amx_model_desc version %d, library %d", d->version, AMX_VERSION);
   if (d->nbody < 1 || d->nq < 0 || d->nv < 0) return fail(AMX_EINVAL, "bad sizes");
   if (d->integrator != 0) return fail(AMX_EUNSUPPORTED, "only the Euler integrator is supported (integrator=%d)", d->integrator);
@@ -151,7 +191,6 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
 #undef AMX_CHK
   }
 
-  DevModel m;
   memset(&m, 0, sizeof(m));
   m.nq = nq; m.nv = nv; m.nu = nu; m.nb = nb; m.njnt = nj; m.npair = np;
   m.iterations = d->iterations; m.ls_iterations = d->ls_iterations; m.solver = d->solver; m.disableflags = d->disableflags;
@@ -179,7 +218,6 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
     child_num[b] = (int)child_list.size() - child_adr[b];
   }
 
-  Image im;
   // bodies
   m.c_body = im.reserve(nb * BODY_S);
   for (int b = 0; b < nb; b++) {
@@ -395,15 +433,45 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
     return fail(AMX_ECAPACITY, "model needs %d bytes of LDS per workgroup (%d constants + %d x %d per environment; limit 163840)",
                 lds_bytes, m.nconst * 4, envs_per_block, m.env_floats * 4);
 
+  return AMX_OK;
+}
+
+// A generated spec applies when the model's whole plan equals it: every integer, the dof tree, the H-sparsity class.
+template <class S> static bool spec_matches(const DevModel &m, const amx_model_desc *d, bool tree_H) {
+#define X(f) if (m.f != S::f) return false;
+  AMX_MODEL_INTS(X)
+#undef X
+  for (int i = 0; i < m.nv; i++) if (d->dof_parentid[i] != S::dof_parent[i]) return false;
+  return tree_H == S::tree_H;
+}
+static int find_spec(const DevModel &m, const amx_model_desc *d, const Image &im) {
+  if (const char *off = getenv("AMX_NO_SPEC")) { if (atoi(off) != 0) return -1; }  // diagnostic: force the generic kernels
+  const bool tree_H = plan_tree_H(d, m, im);
+  int idx = 0, found = -1;
+#define X(S) if (found < 0 && spec_matches<S>(m, d, tree_H)) found = idx; idx++;
+  AMX_SPECS(X)
+#undef X
+  return found;
+}
+
+extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model **out) {
+  if (!d || !out) return fail(AMX_EINVAL, "null argument");
+  DevModel m;
+  Image im;
+  if (int rc = plan_model(d, m, im)) return rc;
+  const int spec = find_spec(m, d, im);
+  const int lds_bytes = (m.nconst + m.wpb * (AMX_WAVE / m.G) * m.env_floats) * (int)sizeof(float);
   amx_model *h = new (std::nothrow) amx_model();
   if (!h) return fail(AMX_ENOMEM, "out of host memory");
   h->ncu = 0;
+  h->spec = spec;
   h->device = device; h->ncon = m.ncon; h->nefc = m.nefc; h->lds_bytes = lds_bytes; h->d_image = nullptr;
   hipError_t e;
   DeviceGuard guard(device);
   if ((e = guard.ok() ? hipSuccess : hipErrorInvalidDevice) != hipSuccess || (e = hipMalloc((void **)&h->d_image, im.v.size() * sizeof(float))) != hipSuccess ||
       (e = hipMemcpy(h->d_image, im.v.data(), im.v.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess ||
-      (e = set_lds_limit(m.G, lds_bytes)) != hipSuccess) {
+      (e = set_lds_limit(m.G, lds_bytes)) != hipSuccess ||
+      (for_spec(spec, [&](auto sp) { e = set_lds_limit_spec<decltype(sp)>(lds_bytes); }) && e != hipSuccess)) {
     if (h->d_image) (void)hipFree(h->d_image);
     delete h;
     return fail(AMX_EHIP, "model upload failed: %s", hipGetErrorString(e));
@@ -412,6 +480,29 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
   h->dev = m;
   { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) h->ncu = n; }
   *out = h;
+  return AMX_OK;
+}
+
+// Tooling (not part of include/amx.h): the launch plan of a descriptor as "name=value" lines - every AMX_MODEL_INTS
+// field, then the dof tree (dof_parent) and whether each contact / equality row couples dofs of one ancestor chain only.
+// tools/gen_specs.py writes amx_specs_gen.h from this; tests/test_abi.py checks the committed header is current.
+extern "C" int amx_model_plan_describe(const amx_model_desc *d, char *out, size_t cap) {
+  if (!d || !out || cap == 0) return fail(AMX_EINVAL, "null argument");
+  DevModel m;
+  Image im;
+  if (int rc = plan_model(d, m, im)) return rc;
+  std::string t;
+  char line[128];
+#define X(f) snprintf(line, sizeof(line), #f "=%d\n", m.f); t += line;
+  AMX_MODEL_INTS(X)
+#undef X
+  t += "dof_parent=";
+  for (int i = 0; i < m.nv; i++) { snprintf(line, sizeof(line), "%d%s", d->dof_parentid[i], i + 1 < m.nv ? "," : ""); t += line; }
+  t += "\n";
+  snprintf(line, sizeof(line), "tree_H=%d\n", plan_tree_H(d, m, im) ? 1 : 0);
+  t += line;
+  if (t.size() + 1 > cap) return fail(AMX_EINVAL, "amx_model_plan_describe: buffer of %zu bytes, %zu needed", cap, t.size() + 1);
+  memcpy(out, t.c_str(), t.size() + 1);
   return AMX_OK;
 }
 
@@ -439,6 +530,7 @@ extern "C" int amx_model_query(const amx_model *m, const char *name, int *out) {
   else if (n == "envs_per_block") *out = m->dev.wpb * (AMX_WAVE / m->dev.G);
   else if (n == "env_slab_bytes") *out = m->dev.env_floats * 4;
   else if (n == "const_bytes") *out = m->dev.nconst * 4;
+  else if (n == "specialised") *out = m->spec >= 0 ? 1 : 0;
   else return fail(AMX_EINVAL, "unknown query '%s'", name);
   return AMX_OK;
 }
@@ -471,9 +563,9 @@ static int pre_launch(const amx_model *m, int nenv, dim3 *grid, int *wpb, int *l
 // one instantiation per group width; the model picks its own at creation
 #define AMX_LAUNCH_G(kernel, m, grid, stream, ...)                                                                       \
   do {                                                                                                                   \
-    if ((m)->dev.G == 16) hipLaunchKernelGGL(kernel<16>, grid, dim3(AMX_WAVE * wpb), lds_bytes, (hipStream_t)stream, __VA_ARGS__);      \
-    else if ((m)->dev.G == 32) hipLaunchKernelGGL(kernel<32>, grid, dim3(AMX_WAVE * wpb), lds_bytes, (hipStream_t)stream, __VA_ARGS__); \
-    else hipLaunchKernelGGL(kernel<64>, grid, dim3(AMX_WAVE * wpb), lds_bytes, (hipStream_t)stream, __VA_ARGS__);                       \
+    if ((m)->dev.G == 16) hipLaunchKernelGGL((kernel<16, DynSpec>), grid, dim3(AMX_WAVE * wpb), lds_bytes, (hipStream_t)stream, __VA_ARGS__);      \
+    else if ((m)->dev.G == 32) hipLaunchKernelGGL((kernel<32, DynSpec>), grid, dim3(AMX_WAVE * wpb), lds_bytes, (hipStream_t)stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL((kernel<64, DynSpec>), grid, dim3(AMX_WAVE * wpb), lds_bytes, (hipStream_t)stream, __VA_ARGS__);                       \
   } while (0)
 
 extern "C" int amx_forward(const amx_model *m, int nenv, const float *qpos, const float *qvel, const float *ctrl,
@@ -491,7 +583,11 @@ extern "C" int amx_forward(const amx_model *m, int nenv, const float *qpos, cons
   dim3 grid;
   int wpb, lds_bytes;
   if (int rc = pre_launch(m, nenv, &grid, &wpb, &lds_bytes)) return rc;
-  AMX_LAUNCH_G(amx_forward_kernel, m, grid, stream, m->dev, nenv, qpos, qvel, ctrl, warm, fo);
+  if (!for_spec(m->spec, [&](auto sp) {
+        using S = decltype(sp);
+        hipLaunchKernelGGL((amx_forward_kernel<S::G, S>), grid, dim3(AMX_WAVE * wpb), lds_bytes, (hipStream_t)stream, m->dev, nenv, qpos, qvel, ctrl, warm, fo);
+      }))
+    AMX_LAUNCH_G(amx_forward_kernel, m, grid, stream, m->dev, nenv, qpos, qvel, ctrl, warm, fo);
   HIP_TRY(hipGetLastError());
   return AMX_OK;
 }
@@ -504,7 +600,11 @@ extern "C" int amx_step(const amx_model *m, int nenv, int nsub, float *qpos, flo
   dim3 grid;
   int wpb, lds_bytes;
   if (int rc = pre_launch(m, nenv, &grid, &wpb, &lds_bytes)) return rc;
-  AMX_LAUNCH_G(amx_step_kernel, m, grid, stream, m->dev, nenv, nsub, qpos, qvel, ctrl, warm, time);
+  if (!for_spec(m->spec, [&](auto sp) {
+        using S = decltype(sp);
+        hipLaunchKernelGGL((amx_step_kernel<S::G, S>), grid, dim3(AMX_WAVE * wpb), lds_bytes, (hipStream_t)stream, m->dev, nenv, nsub, qpos, qvel, ctrl, warm, time);
+      }))
+    AMX_LAUNCH_G(amx_step_kernel, m, grid, stream, m->dev, nenv, nsub, qpos, qvel, ctrl, warm, time);
   HIP_TRY(hipGetLastError());
   return AMX_OK;
 }
@@ -527,7 +627,11 @@ extern "C" int amx_rollout(const amx_model *m, int nenv, int nsteps, const float
 #ifdef AMX_PROFILE
   prof = g_prof;
 #endif
-  AMX_LAUNCH_G(amx_rollout_kernel, m, grid, stream, m->dev, nenv, nsteps, x0_batched, x0, us, xs, xfinal, prof);
+  if (!for_spec(m->spec, [&](auto sp) {
+        using S = decltype(sp);
+        hipLaunchKernelGGL((amx_rollout_kernel<S::G, S>), grid, dim3(AMX_WAVE * wpb), lds_bytes, (hipStream_t)stream, m->dev, nenv, nsteps, x0_batched, x0, us, xs, xfinal, prof);
+      }))
+    AMX_LAUNCH_G(amx_rollout_kernel, m, grid, stream, m->dev, nenv, nsteps, x0_batched, x0, us, xs, xfinal, prof);
   HIP_TRY(hipGetLastError());
   return AMX_OK;
 }

@@ -27,29 +27,47 @@ enum { BODY_S = 25, JNT_S = 13, DOF_S = 9, ACT_S = 13, GEOM_S = 13, PAIR_S = 29,
 // EqRec  : 0 q1 1 d1 2 q2 3 d2 4-8 polycoef 9 k 10 b 11 dmin 12 dmax 13 width 14 mid 15 power 16 ca 17 cb 18 invw 19 qref1 20 qref2
 
 // Everything the kernel needs besides the constant image: sizes, options, and a few base offsets.
+// The integer fields are listed ONCE, here: DevModel, the model-view accessors (amx_kernels.hip: MV<S>), the plan dump that
+// tools/gen_specs.py turns into amx_specs_gen.h and the specialisation match in amx_api.cpp all expand this list.
+//   sizes .. options
+#define AMX_MODEL_INTS(X)                                                                                                  \
+  X(nconst)                                                                                                                \
+  X(nq) X(nv) X(nu) X(nb) X(njnt) X(ngc) X(npair) X(ncon) X(neq) X(nlim) X(nefc) X(nlevel) X(nM) X(nroot)                    \
+  X(ldc) /* contact-row stride: longest pair dof list, odd */                                                              \
+  X(ldm) /* row stride of M and H: >= nv, ldm/4 odd */                                                                     \
+  X(nchol) X(njac) X(nhent)                                                                                                \
+  X(iterations) X(ls_iterations) X(solver) X(disableflags)                                                                 \
+  X(G)   /* lanes per environment: 16, 32 or 64 */                                                                         \
+  X(wpb) /* wavefronts per workgroup (1..AMX_WAVES_PER_BLOCK), chosen to maximise resident waves per CU */                 \
+  /* bases inside the constant image (float offsets) */                                                                    \
+  X(c_body) X(c_jnt) X(c_dof) X(c_act) X(c_geom) X(c_pair) X(c_lim) X(c_eq)                                                \
+  X(c_qpos0) /* [nq] */ X(c_child) X(c_M) /* packed i|j<<8 */ X(c_dofact) X(c_pairdof) /* packed dof|sign<<8 */            \
+  X(c_jac) /* packed contact|slot<<6|dof<<11|chain sign<<16|pair<<18 */                                                    \
+  X(c_hent) /* [nhent] terms: packed dof_i|dof_j<<5|first contact row<<10|slot_i<<18|slot_j<<23 (dof_j <= dof_i) */         \
+  X(c_dofmemadr) /* [nv+1] */ X(c_dofmem) /* terms: packed first contact row|slot<<8 */ X(c_conpair) /* [ncon] */           \
+  X(c_vert) X(c_rootbody) X(c_slot) /* [ncon][32]: position of dof j in the contact's dof chain, -1 if absent */            \
+  /* bases inside one environment slab (float offsets from the slab start) */                                              \
+  X(e_qpos) X(e_qvel) X(e_ctrl)                                                                                            \
+  X(e_body) /* records [nb][BODY_E]: xpos 0-2 xquat 3-6 cinert 7-16 (then cfrc 7-12) crb 17-26 (then cvel 17-22 cacc 23-28) */ \
+  X(e_jnt)  /* records [njnt][JNT_E]: xanchor 0-2 xaxis 3-5 */                                                             \
+  X(e_dof)  /* records [nv][DOF_E]: cdof 0-5 fcrb 6-11 (then Ma grad Mgrad search mv fcon) fsmooth 12 asmooth 13 qacc 14 warm 15 fbias 16 */ \
+  X(e_com) X(e_actf)                                                                                                       \
+  X(e_M) X(e_H) /* full symmetric [nv][ldm], 16-byte aligned rows */                                                       \
+  X(e_Lb) /* packed lower-triangular Cholesky factor, only allocated for the CG solver */                                  \
+  X(e_row) /* records [nefc][ROW_E]: Dact 0 frow 1 */                                                                      \
+  X(e_J) /* contact rows only, chain-compressed: [4*ncon][ldc] */                                                          \
+  X(e_con) /* records [ncon][CON_E]: dist 0 pos 1-3 */ X(e_frame) /* [npair][9] */                                         \
+  X(e_geom) /* records [ngc][GEO_E]: pos 0-2 mat 3-11 */                                                                   \
+  X(e_prof)                                                                                                                \
+  X(env_floats) /* floats per environment slab */
+#define AMX_MODEL_FLOATS(X) X(dt) X(gx) X(gy) X(gz) X(tolerance) X(ls_tolerance) X(impratio) X(scale) /* scale = meaninertia*max(1,nv) */
+
 struct DevModel {
   const float *image;  // HBM copy of the constant image (ints stored bit-cast), nconst floats
-  int nconst;
-  int nq, nv, nu, nb, njnt, ngc, npair, ncon, neq, nlim, nefc, nlevel, nM, nroot, ldc /*contact-row stride: longest pair dof list, odd*/, ldm /*row stride of M and H: >= nv, ldm/4 odd*/, nchol, njac, nhent;
-  int iterations, ls_iterations, solver, disableflags;
-  int G;    // lanes per environment: 16, 32 or 64
-  int wpb;  // wavefronts per workgroup (1..AMX_WAVES_PER_BLOCK), chosen to maximise resident waves per CU
-  float dt, gx, gy, gz, tolerance, ls_tolerance, impratio, scale /* meaninertia*max(1,nv) */;
-  // bases inside the constant image (float offsets)
-  int c_body, c_jnt, c_dof, c_act, c_geom, c_pair, c_lim, c_eq;
-  int c_qpos0 /*[nq]*/, c_child, c_M /*packed i|j<<8*/, c_dofact, c_pairdof /*packed dof|sign<<8*/, c_jac /*packed contact|slot<<6|dof<<11|chain sign<<16|pair<<18*/,
-      c_hent /*[nhent] terms: packed dof_i|dof_j<<5|first contact row<<10|slot_i<<18|slot_j<<23 (dof_j <= dof_i)*/, c_dofmemadr /*[nv+1]*/, c_dofmem /*terms: packed first contact row|slot<<8*/, c_conpair /*[ncon]*/, c_vert, c_rootbody, c_slot /*[ncon][32]: position of dof j in the contact's dof chain, -1 if absent*/;
-  // bases inside one environment slab (float offsets from the slab start)
-  int e_qpos, e_qvel, e_ctrl;
-  int e_body /* records [nb][BODY_E]: xpos 0-2 xquat 3-6 cinert 7-16 (then cfrc 7-12) crb 17-26 (then cvel 17-22 cacc 23-28) */;
-  int e_jnt  /* records [njnt][JNT_E]: xanchor 0-2 xaxis 3-5 */;
-  int e_dof  /* records [nv][DOF_E]: cdof 0-5 fcrb 6-11 (then Ma grad Mgrad search mv fcon) fsmooth 12 asmooth 13 qacc 14 warm 15 fbias 16 */;
-  int e_com, e_actf;
-  int e_M, e_H /* full symmetric [nv][ldm], 16-byte aligned rows */, e_Lb /* packed lower-triangular Cholesky factor, only allocated for the CG solver */;
-  int e_row /* records [nefc][ROW_E]: Dact 0 frow 1 */;
-  int e_J /* contact rows only, chain-compressed: [4*ncon][ldc] */;
-  int e_con /* records [ncon][CON_E]: dist 0 pos 1-3 */, e_frame /* [npair][9] */, e_geom /* records [ngc][GEO_E]: pos 0-2 mat 3-11 */;
-  int e_prof;
-  int env_floats;  // floats per environment slab
+#define X(f) int f;
+  AMX_MODEL_INTS(X)
+#undef X
+#define X(f) float f;
+  AMX_MODEL_FLOATS(X)
+#undef X
 };
-

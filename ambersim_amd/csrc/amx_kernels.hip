@@ -46,6 +46,30 @@ extern __shared__ float lds[];
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
   } while (0)
 
+// Model view.  Every integer of the launch plan (sizes, options, LDS offsets - the AMX_MODEL_INTS list of amx_dev.h) is read
+// through MV<S>.  S = DynSpec answers from the by-value descriptor: any model the C ABI accepts.  A generated spec
+// (amx_specs_gen.h, one per shipped model) answers with compile-time constants: loops unroll with static trip counts, LDS
+// offsets fold into instruction immediates, the tree sparsity of M and H is static in the eliminations, and the descriptor
+// never occupies scalar registers.  Floats (dt, gravity, tolerances) stay run-time values in both.
+struct DynSpec {
+  static constexpr bool is_static = false;
+#define X(f) static constexpr int f = 0;
+  AMX_MODEL_INTS(X)
+#undef X
+  static constexpr bool tree_H = false;
+  static constexpr int dof_parent[32] = {};
+};
+template <class S> struct MV {
+  const DevModel &d;
+#define X(f) DEV int f() const { return S::is_static ? S::f : d.f; }
+  AMX_MODEL_INTS(X)
+#undef X
+#define X(f) DEV float f() const { return d.f; }
+  AMX_MODEL_FLOATS(X)
+#undef X
+  DEV const float *image() const { return d.image; }
+};
+
 struct f3 { float x, y, z; };
 struct f4 { float w, x, y, z; };
 DEV f3 mk3(float x, float y, float z) { f3 r = {x, y, z}; return r; }
@@ -445,7 +469,7 @@ struct LSPoint { float alpha, cost, d0, d1; };
 #ifdef AMX_PROFILE
 #define PROF_N 24
 #define PROF_DECL unsigned prof_t;
-#define PROF(id) do { unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); if (gl == 0) lds[eb + m.e_prof + (id)] += (float)(t_ - prof_t); prof_t = t_; } while (0)
+#define PROF(id) do { unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); if (gl == 0) lds[eb + m.e_prof() + (id)] += (float)(t_ - prof_t); prof_t = t_; } while (0)
 #else
 #define PROF_DECL
 #define PROF(id)
@@ -563,9 +587,9 @@ __device__ __noinline__ void plane_convex_parallel(int pcx_first, int pcx_num, i
 // One environment's physics, run by a group of G lanes.  `eb` is the group's slab in LDS (per-lane value,
 // equal inside a group); `gl` is the lane's index inside its group; constants live at the front of LDS.
 // =====================================================================================================
-template <int G>
+template <int G, class S>
 struct Env {
-  const DevModel &m;
+  const MV<S> m;
   const int eb, gl, gb4;  // slab base, lane-in-group, 4 * first lane of the group (crossbar address base)
   // static role constants of this lane
   int b_parent, b_level, b_root, b_jntadr, b_jntnum, b_childadr, b_childnum;  // body `lane`
@@ -578,22 +602,22 @@ struct Env {
   bool ract;  // row role: the row is active at the current iterate (set by constraint_force_and_grad)
   PROF_DECL
 
-  DEV Env(const DevModel &m_, int eb_, int gl_, int gb4_) : m(m_), eb(eb_), gl(gl_), gb4(gb4_) {
+  DEV Env(const MV<S> &m_, int eb_, int gl_, int gb4_) : m(m_), eb(eb_), gl(gl_), gb4(gb4_) {
     const int lane = gl;
-    const int br = m.c_body + (lane < m.nb ? lane : 0) * BODY_S;
-    b_parent = CI(br); b_level = lane < m.nb ? CI(br + 1) : -1; b_root = CI(br + 2); b_jntadr = CI(br + 3); b_jntnum = CI(br + 4);
+    const int br = m.c_body() + (lane < m.nb() ? lane : 0) * BODY_S;
+    b_parent = CI(br); b_level = lane < m.nb() ? CI(br + 1) : -1; b_root = CI(br + 2); b_jntadr = CI(br + 3); b_jntnum = CI(br + 4);
     b_childadr = CI(br + 5); b_childnum = CI(br + 6);
-    const int dr = m.c_dof + (lane < m.nv ? lane : 0) * DOF_S;
+    const int dr = m.c_dof() + (lane < m.nv() ? lane : 0) * DOF_S;
     d_body = CI(dr); d_jnt = CI(dr + 1); d_kind = CI(dr + 2); d_axis = CI(dr + 3); d_root = CI(dr + 8);
     rD = rAref = rJaref = rJv = rJ1 = rJ2 = 0.0f;
     ract = false;
     rd1 = 0; rd2 = -1;
-    if (lane < m.neq) { const int er = m.c_eq + lane * EQ_S; rd1 = CI(er + 1); rd2 = CI(er + 3); }
-    else if (lane < m.neq + m.nlim) rd1 = CI(m.c_lim + (lane - m.neq) * LIM_S + 1);
+    if (lane < m.neq()) { const int er = m.c_eq() + lane * EQ_S; rd1 = CI(er + 1); rd2 = CI(er + 3); }
+    else if (lane < m.neq() + m.nlim()) rd1 = CI(m.c_lim() + (lane - m.neq()) * LIM_S + 1);
     rchain[0] = rchain[1] = rchain[2] = rchain[3] = 0; rdn = 0; rcr = 0;
-    if (lane >= m.neq + m.nlim && lane < m.nefc) {
-      rcr = lane - m.neq - m.nlim;
-      const int prec = m.c_pair + CI(m.c_conpair + (rcr >> 2)) * PAIR_S, d0 = CI(prec + 9);
+    if (lane >= m.neq() + m.nlim() && lane < m.nefc()) {
+      rcr = lane - m.neq() - m.nlim();
+      const int prec = m.c_pair() + CI(m.c_conpair() + (rcr >> 2)) * PAIR_S, d0 = CI(prec + 9);
       rdn = CI(prec + 10);
 #pragma unroll
       for (int w = 0; w < 4; ++w) {  // static register indices only (a runtime-indexed array would live in scratch)
@@ -601,7 +625,7 @@ struct Env {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int t = 4 * w + q;
-          if (t < rdn) pk |= (CI(m.c_pairdof + d0 + t) & 255) << (8 * q);
+          if (t < rdn) pk |= (CI(m.c_pairdof() + d0 + t) & 255) << (8 * q);
         }
         rchain[w] = pk;
       }
@@ -611,15 +635,15 @@ struct Env {
   // SoA accessors of the environment slab
   // Records with odd compile-time strides: gl-per-record access is bank-conflict free and every field
   // is an immediate offset from one base address (no per-field address registers).
-  DEV float &body(int f, int b) const { return lds[eb + m.e_body + b * BODY_E + f]; }
-  DEV float &jnt(int f, int j) const { return lds[eb + m.e_jnt + j * JNT_E + f]; }
-  DEV float &dof(int f, int i) const { return lds[eb + m.e_dof + i * DOF_E + f]; }
-  DEV float &row(int f, int r) const { return lds[eb + m.e_row + r * ROW_E + f]; }
-  DEV float &con(int f, int c) const { return lds[eb + m.e_con + c * CON_E + f]; }
-  DEV float &geo(int f, int g) const { return lds[eb + m.e_geom + g * GEO_E + f]; }
+  DEV float &body(int f, int b) const { return lds[eb + m.e_body() + b * BODY_E + f]; }
+  DEV float &jnt(int f, int j) const { return lds[eb + m.e_jnt() + j * JNT_E + f]; }
+  DEV float &dof(int f, int i) const { return lds[eb + m.e_dof() + i * DOF_E + f]; }
+  DEV float &row(int f, int r) const { return lds[eb + m.e_row() + r * ROW_E + f]; }
+  DEV float &con(int f, int c) const { return lds[eb + m.e_con() + c * CON_E + f]; }
+  DEV float &geo(int f, int g) const { return lds[eb + m.e_geom() + g * GEO_E + f]; }
   DEV f3 ld_xpos(int b) const { return mk3(body(0, b), body(1, b), body(2, b)); }
   DEV f4 ld_xquat(int b) const { f4 q = {body(3, b), body(4, b), body(5, b), body(6, b)}; return q; }
-  DEV f3 ld_com(int r) const { const int o = eb + m.e_com + 3 * r; return mk3(lds[o], lds[o + 1], lds[o + 2]); }
+  DEV f3 ld_com(int r) const { const int o = eb + m.e_com() + 3 * r; return mk3(lds[o], lds[o + 1], lds[o + 2]); }
   DEV sv ld_bsv(int f0, int b) const { sv r = {{body(f0, b), body(f0 + 1, b), body(f0 + 2, b), body(f0 + 3, b), body(f0 + 4, b), body(f0 + 5, b)}}; return r; }
   DEV void st_bsv(int f0, int b, const sv &v) const {
 #pragma unroll
@@ -636,7 +660,7 @@ struct Env {
   // crb*cdof (6) is dead once M is built; the six solver vectors reuse its space
   enum { D_CDOF = 0, D_FCRB = 6, D_MA = 6, D_GRAD = 7, D_MGRAD = 8, D_SEARCH = 9, D_MV = 10, D_FCON = 11,
          D_FSMOOTH = 12, D_ASMOOTH = 13, D_QACC = 14, D_WARM = 15, D_FBIAS = 16 };
-  DEV int dofoff(int f) const { return eb + m.e_dof + f; }  // element i of dof field f lives at dofoff(f) + i*DOF_E
+  DEV int dofoff(int f) const { return eb + m.e_dof() + f; }  // element i of dof field f lives at dofoff(f) + i*DOF_E
 
   // ------------------------------------------------------------------ A9.1 kinematics
   // Three passes, so that the joint arithmetic (type switch, sin/cos, quaternion products) runs once per step and not once
@@ -652,13 +676,13 @@ struct Env {
       body(0, 0) = 0; body(1, 0) = 0; body(2, 0) = 0;
       body(3, 0) = 1; body(4, 0) = 0; body(5, 0) = 0; body(6, 0) = 0;
     }
-    if (b > 0 && b < m.nb) {
-      const int br = m.c_body + b * BODY_S;
+    if (b > 0 && b < m.nb()) {
+      const int br = m.c_body() + b * BODY_S;
       f3 pos = mk3(CF(br + 7), CF(br + 8), CF(br + 9));
       f4 quat = {CF(br + 10), CF(br + 11), CF(br + 12), CF(br + 13)};
       for (int k = 0; k < b_jntnum; ++k) {
-        const int j = b_jntadr + k, jr = m.c_jnt + j * JNT_S;
-        const int t_ = CI(jr), qa = eb + m.e_qpos + CI(jr + 1);
+        const int j = b_jntadr + k, jr = m.c_jnt() + j * JNT_S;
+        const int t_ = CI(jr), qa = eb + m.e_qpos() + CI(jr + 1);
         const f3 jpos = mk3(CF(jr + 4), CF(jr + 5), CF(jr + 6)), jax = mk3(CF(jr + 7), CF(jr + 8), CF(jr + 9));
         f3 anchor, axis;
         if (t_ == JFREE) {
@@ -692,7 +716,7 @@ struct Env {
       body(3, b) = quat.w; body(4, b) = quat.x; body(5, b) = quat.y; body(6, b) = quat.z;
     }
     WSYNC();
-    for (int L = 2; L < m.nlevel; ++L) {
+    for (int L = 2; L < m.nlevel(); ++L) {
       if (b_level == L) {
         const f4 pq = ld_xquat(b_parent);
         const f3 pos = ld_xpos(b_parent) + qrot(pq, ld_xpos(b));
@@ -702,8 +726,8 @@ struct Env {
       }
       WSYNC();
     }
-    if (gl < m.njnt) {
-      const int p = CI(m.c_body + CI(m.c_jnt + gl * JNT_S + 3) * BODY_S);  // parent of the joint's body
+    if (gl < m.njnt()) {
+      const int p = CI(m.c_body() + CI(m.c_jnt() + gl * JNT_S + 3) * BODY_S);  // parent of the joint's body
       if (p > 0) {  // the world's frame is the identity
         const f4 pq = ld_xquat(p);
         const f3 anchor = ld_xpos(p) + qrot(pq, mk3(jnt(0, gl), jnt(1, gl), jnt(2, gl)));
@@ -717,9 +741,9 @@ struct Env {
 
   // ------------------------------------------------------------------ A9.2 com_pos: tree COM, cinert, cdof (+ collision geom poses)
   DEV void com_pos() {
-    const int b = gl, nb = m.nb;
+    const int b = gl, nb = m.nb();
     const bool isb = b > 0 && b < nb;
-    const int br = m.c_body + (isb ? b : 0) * BODY_S;
+    const int br = m.c_body() + (isb ? b : 0) * BODY_S;
     f3 xi = mk3(0, 0, 0);
     f4 xq = {1, 0, 0, 0};
     const float ms = isb ? CF(br + 21) : 0.0f;
@@ -727,13 +751,13 @@ struct Env {
       xq = ld_xquat(b);
       xi = ld_xpos(b) + qrot(xq, mk3(CF(br + 14), CF(br + 15), CF(br + 16)));
     }
-    for (int r = 0; r < m.nroot; ++r) {
+    for (int r = 0; r < m.nroot(); ++r) {
       const bool mine = isb && b_root == r;
       float sx = gsum<G>(mine ? xi.x * ms : 0.0f), sy = gsum<G>(mine ? xi.y * ms : 0.0f), sz = gsum<G>(mine ? xi.z * ms : 0.0f),
             sm = gsum<G>(mine ? ms : 0.0f);
-      const int rb = CI(m.c_rootbody + r);
+      const int rb = CI(m.c_rootbody() + r);
       if (b == rb) {  // the root body itself writes the tree's COM
-        const int o = eb + m.e_com + 3 * r;
+        const int o = eb + m.e_com() + 3 * r;
         if (sm < MINVAL) { lds[o] = xi.x; lds[o + 1] = xi.y; lds[o + 2] = xi.z; }
         else { lds[o] = sx / sm; lds[o + 1] = sy / sm; lds[o + 2] = sz / sm; }
       }
@@ -762,7 +786,7 @@ struct Env {
 #pragma unroll
       for (int k = 0; k < 10; ++k) body(F_CINERT + k, b) = r[k];
     }
-    if (gl < m.nv) {
+    if (gl < m.nv()) {
       const int i = gl, j = d_jnt;
       const f3 off = ld_com(d_root) - mk3(jnt(0, j), jnt(1, j), jnt(2, j));
       f3 w = mk3(0, 0, 0), l = mk3(0, 0, 0);
@@ -780,8 +804,8 @@ struct Env {
       }
       dof(0, i) = w.x; dof(1, i) = w.y; dof(2, i) = w.z; dof(3, i) = l.x; dof(4, i) = l.y; dof(5, i) = l.z;
     }
-    if (gl < m.ngc) {
-      const int g = gl, gr = m.c_geom + g * GEOM_S, gb = CI(gr);
+    if (gl < m.ngc()) {
+      const int g = gl, gr = m.c_geom() + g * GEOM_S, gb = CI(gr);
       const f4 q = ld_xquat(gb);
       const f3 pos = ld_xpos(gb) + qrot(q, mk3(CF(gr + 2), CF(gr + 3), CF(gr + 4)));
       const f4 gq = {CF(gr + 5), CF(gr + 6), CF(gr + 7), CF(gr + 8)};
@@ -795,14 +819,14 @@ struct Env {
 
   // ------------------------------------------------------------------ A9.3 crb + mass matrix
   DEV void crb_and_M() {
-    const int b = gl, nv = m.nv;
-    for (int L = m.nlevel - 1; L >= 1; --L) {
+    const int b = gl, nv = m.nv();
+    for (int L = m.nlevel() - 1; L >= 1; --L) {
       if (b_level == L) {
         float r[10];
 #pragma unroll
         for (int k = 0; k < 10; ++k) r[k] = body(F_CINERT + k, b);
         for (int c = 0; c < b_childnum; ++c) {
-          const int cb = CI(m.c_child + b_childadr + c);
+          const int cb = CI(m.c_child() + b_childadr + c);
 #pragma unroll
           for (int k = 0; k < 10; ++k) r[k] += body(F_CRB + k, cb);
         }
@@ -818,13 +842,13 @@ struct Env {
       st_dsv(D_FCRB, gl, inert_mul(I, ld_dsv(D_CDOF, gl)));
     }
     WSYNC();
-    const int Mo = eb + m.e_M, ldm = m.ldm;
+    const int Mo = eb + m.e_M(), ldm = m.ldm();
     struct MEnt { int at, at2; float v; };
-    item_loop2<G>(m.nM, gl,
+    item_loop2<G>(m.nM(), gl,
       [&](int e) {
-        const int pk = CI(m.c_M + e), i = pk & 255, j = pk >> 8;
+        const int pk = CI(m.c_M() + e), i = pk & 255, j = pk >> 8;
         const sv f = ld_dsv(D_FCRB, i), c = ld_dsv(D_CDOF, j);
-        const float arm = CF(m.c_dof + i * DOF_S + 4);
+        const float arm = CF(m.c_dof() + i * DOF_S + 4);
         float v = (c.v[0] * f.v[0] + c.v[1] * f.v[1]) + (c.v[2] * f.v[2] + c.v[3] * f.v[3]) + (c.v[4] * f.v[4] + c.v[5] * f.v[5]);
         if (i == j) v += arm;
         return MEnt{Mo + i * ldm + j, Mo + j * ldm + i, v};  // j is an ancestor of i: j <= i; both triangles are stored
@@ -836,12 +860,12 @@ struct Env {
   // ------------------------------------------------------------------ A9.8 com_vel + A9.10 rne (one down-scan, one up-scan)
   DEV void velocity_and_bias() {
     const int b = gl;
-    const int qv = eb + m.e_qvel;
+    const int qv = eb + m.e_qvel();
     if (gl == 0) {
       sv z = {{0, 0, 0, 0, 0, 0}};
       st_bsv(F_CVEL, 0, z);
       st_bsv(F_CFRC, 0, z);
-      if (!(m.disableflags & DIS_GRAVITY)) { z.v[3] = -m.gx; z.v[4] = -m.gy; z.v[5] = -m.gz; }
+      if (!(m.disableflags() & DIS_GRAVITY)) { z.v[3] = -m.gx(); z.v[4] = -m.gy(); z.v[5] = -m.gz(); }
       st_bsv(F_CACC, 0, z);
     }
     WSYNC();
@@ -853,9 +877,9 @@ struct Env {
     // with P_k alone; the motion cross product is bilinear).  vJ, w, loc need no other body and stay in registers; the
     // level scan is then twelve loads, one cross product and twelve stores.
     sv vJ = {{0, 0, 0, 0, 0, 0}}, w = {{0, 0, 0, 0, 0, 0}}, loc = {{0, 0, 0, 0, 0, 0}};
-    if (b > 0 && b < m.nb) {
+    if (b > 0 && b < m.nb()) {
       for (int k = 0; k < b_jntnum; ++k) {
-        const int jr = m.c_jnt + (b_jntadr + k) * JNT_S, t_ = CI(jr), da = CI(jr + 2);
+        const int jr = m.c_jnt() + (b_jntadr + k) * JNT_S, t_ = CI(jr), da = CI(jr + 2);
         if (t_ == JFREE) {
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
@@ -889,7 +913,7 @@ struct Env {
         }
       }
     }
-    for (int L = 1; L < m.nlevel; ++L) {
+    for (int L = 1; L < m.nlevel(); ++L) {
       if (b_level == L) {
         const sv cvp = ld_bsv(F_CVEL, b_parent), cap = ld_bsv(F_CACC, b_parent);
         const sv x = motion_cross(cvp, w);
@@ -901,7 +925,7 @@ struct Env {
       }
       WSYNC();
     }
-    if (b > 0 && b < m.nb) {  // local force of every body in parallel: I cacc + cvel x* (I cvel)
+    if (b > 0 && b < m.nb()) {  // local force of every body in parallel: I cacc + cvel x* (I cvel)
       const sv cv = ld_bsv(F_CVEL, b), ca = ld_bsv(F_CACC, b);
       float I[10];
 #pragma unroll
@@ -913,11 +937,11 @@ struct Env {
       st_bsv(F_CFRC, b, f);
     }
     WSYNC();
-    for (int L = m.nlevel - 2; L >= 1; --L) {  // up-scan: gather children
+    for (int L = m.nlevel() - 2; L >= 1; --L) {  // up-scan: gather children
       if (b_level == L && b_childnum > 0) {
         sv f = ld_bsv(F_CFRC, b);
         for (int c = 0; c < b_childnum; ++c) {
-          const sv g = ld_bsv(F_CFRC, CI(m.c_child + b_childadr + c));
+          const sv g = ld_bsv(F_CFRC, CI(m.c_child() + b_childadr + c));
 #pragma unroll
           for (int e = 0; e < 6; ++e) f.v[e] += g.v[e];
         }
@@ -929,28 +953,28 @@ struct Env {
 
   // ------------------------------------------------------------------ A9.9 passive, A9.7/A9.11 actuation, A9.12 qfrc_smooth
   DEV void smooth_forces() {
-    const int qp = eb + m.e_qpos, qv = eb + m.e_qvel;
-    const bool act_on = m.nu > 0 && !(m.disableflags & DIS_ACTUATION);
-    if (act_on && gl < m.nu) {
-      const int ar = m.c_act + gl * ACT_S, fl = CI(ar + 2);
+    const int qp = eb + m.e_qpos(), qv = eb + m.e_qvel();
+    const bool act_on = m.nu() > 0 && !(m.disableflags() & DIS_ACTUATION);
+    if (act_on && gl < m.nu()) {
+      const int ar = m.c_act() + gl * ACT_S, fl = CI(ar + 2);
       const float gear = CF(ar + 3);
-      float c = lds[eb + m.e_ctrl + gl];
-      if (!(m.disableflags & DIS_CLAMPCTRL) && (fl & 1)) c = fminf(fmaxf(c, CF(ar + 8)), CF(ar + 9));
+      float c = lds[eb + m.e_ctrl() + gl];
+      if (!(m.disableflags() & DIS_CLAMPCTRL) && (fl & 1)) c = fminf(fmaxf(c, CF(ar + 8)), CF(ar + 9));
       float force = CF(ar + 4) * c;
       if (fl & 4) force += CF(ar + 5) + CF(ar + 6) * (lds[qp + CI(ar)] * gear) + CF(ar + 7) * (lds[qv + CI(ar + 1)] * gear);
       if (fl & 2) force = fminf(fmaxf(force, CF(ar + 10)), CF(ar + 11));
-      lds[eb + m.e_actf + gl] = gear * force;
+      lds[eb + m.e_actf() + gl] = gear * force;
     }
     WSYNC();
-    if (gl < m.nv) {
-      const int i = gl, dr = m.c_dof + i * DOF_S;
+    if (gl < m.nv()) {
+      const int i = gl, dr = m.c_dof() + i * DOF_S;
       const sv c = ld_dsv(D_CDOF, i), f = ld_bsv(F_CFRC, d_body);
       float bias = 0;
 #pragma unroll
       for (int e = 0; e < 6; ++e) bias += c.v[e] * f.v[e];
       float pas = 0;
-      if (!(m.disableflags & DIS_PASSIVE)) {
-        const int jr = m.c_jnt + d_jnt * JNT_S;
+      if (!(m.disableflags() & DIS_PASSIVE)) {
+        const int jr = m.c_jnt() + d_jnt * JNT_S;
         const float k = CF(jr + 11);
         if (k != 0.0f && d_kind >= 2) pas -= k * (lds[qp + CI(jr + 1)] - CF(jr + 12));
         pas -= CF(dr + 5) * lds[qv + i];
@@ -958,7 +982,7 @@ struct Env {
       float act = 0;
       if (act_on) {
         const int a0 = CI(dr + 6), an = CI(dr + 7);
-        for (int a = 0; a < an; ++a) act += lds[eb + m.e_actf + CI(m.c_dofact + a0 + a)];
+        for (int a = 0; a < an; ++a) act += lds[eb + m.e_actf() + CI(m.c_dofact() + a0 + a)];
       }
       dof(D_FBIAS, i) = bias;
       dof(D_FSMOOTH, i) = pas - bias + act;
@@ -974,14 +998,14 @@ struct Env {
   }
   DEV void st_contact(int c, float d, f3 cp) const { con(0, c) = d; con(1, c) = cp.x; con(2, c) = cp.y; con(3, c) = cp.z; }
   DEV void collision() {
-    const int np = m.npair;
+    const int np = m.npair();
     // plane-convex pairs with at most 32 hull vertices go to the vertex-parallel routine when they form one contiguous run of
     // pair indices (pairs are grouped by function, so they do unless a larger hull sits among them); found with a ballot
     // over the pair lanes rather than carried in the model descriptor, which has no scalar registers to spare
     // (64-lane groups only: in the 32-lane kernel the extra code cost the quadruped 1 % without a model to gain from it)
     int cx_first = 0, cx_num = 0;
     if (G >= 64) {
-      const int rec0 = m.c_pair + (gl < np ? gl : 0) * PAIR_S;
+      const int rec0 = m.c_pair() + (gl < np ? gl : 0) * PAIR_S;
       const bool is_cx = gl < np && CI(rec0 + 2) == 2 && CI(rec0 + 6) <= 32;
       const unsigned long long bal = __ballot(is_cx) >> ((gb4 >> 2) & 63);
       const unsigned long long mine = G == 32 ? (bal & 0xFFFFFFFFull) : bal;
@@ -991,15 +1015,15 @@ struct Env {
       }
     }
     const bool par_cx = G >= 64 && cx_num > 0;  // one group per wave: uniform
-    if (par_cx) plane_convex_parallel<G>(cx_first, cx_num, m.c_pair, m.c_vert, eb + m.e_geom, eb + m.e_con, eb + m.e_frame, gl, gb4);
+    if (par_cx) plane_convex_parallel<G>(cx_first, cx_num, m.c_pair(), m.c_vert(), eb + m.e_geom(), eb + m.e_con(), eb + m.e_frame(), gl, gb4);
     if (gl < np && !(gl >= cx_first && gl < cx_first + cx_num)) {
-      const int pr = gl, rec = m.c_pair + pr * PAIR_S;
+      const int pr = gl, rec = m.c_pair() + pr * PAIR_S;
       const int g1 = CI(rec), g2 = CI(rec + 1), fn = CI(rec + 2), c0 = CI(rec + 3);
       const f3 pos1 = mk3(geo(0, g1), geo(1, g1), geo(2, g1)), pos2 = mk3(geo(0, g2), geo(1, g2), geo(2, g2));
       m33 R1, R2;
 #pragma unroll
       for (int k = 0; k < 9; ++k) { R1.a[k] = geo(3 + k, g1); R2.a[k] = geo(3 + k, g2); }
-      const int s1 = m.c_geom + g1 * GEOM_S + 9, s2 = m.c_geom + g2 * GEOM_S + 9;
+      const int s1 = m.c_geom() + g1 * GEOM_S + 9, s2 = m.c_geom() + g2 * GEOM_S + 9;
       float fr[9];
       if (fn == 0) {
         const f3 n = mk3(R1.a[2], R1.a[5], R1.a[8]);
@@ -1023,7 +1047,7 @@ struct Env {
           st_contact(c0 + k, d, cp);
         }
       } else if (fn == 2) {
-        const int nvt = CI(rec + 6), va = m.c_vert + 3 * CI(rec + 5);
+        const int nvt = CI(rec + 6), va = m.c_vert() + 3 * CI(rec + 5);
         const f3 nw = mk3(R1.a[2], R1.a[5], R1.a[8]);
         const f3 pl = mulTv(R2, pos1 - pos2), n = mulTv(R2, nw);
         float smax = -1e30f;
@@ -1082,7 +1106,7 @@ struct Env {
         make_frame(n, fr);
       }
 #pragma unroll
-      for (int k = 0; k < 9; ++k) lds[eb + m.e_frame + pr * 9 + k] = fr[k];
+      for (int k = 0; k < 9; ++k) lds[eb + m.e_frame() + pr * 9 + k] = fr[k];
     }
     WSYNC();
   }
@@ -1091,22 +1115,22 @@ struct Env {
   // Row table (static): [0,neq) joint equalities, [neq,neq+nlim) joint limits, then 4 pyramid rows per
   // contact slot.  A row that is inactive this step gets D = 0 (the reference zeroes it instead).
   DEV void make_constraint() {
-    const int Jo = eb + m.e_J, ldc = m.ldc;
-    const int qp = eb + m.e_qpos, qv = eb + m.e_qvel;
-    const bool con_on = !(m.disableflags & DIS_CONSTRAINT);
-    const int row0 = m.neq + m.nlim;
-    if (con_on && !(m.disableflags & DIS_CONTACT)) {
+    const int Jo = eb + m.e_J(), ldc = m.ldc();
+    const int qp = eb + m.e_qpos(), qv = eb + m.e_qvel();
+    const bool con_on = !(m.disableflags() & DIS_CONSTRAINT);
+    const int row0 = m.neq() + m.nlim();
+    if (con_on && !(m.disableflags() & DIS_CONTACT)) {
       // contact Jacobian entries: one lane per (contact, dof of the pair's ancestor chains); rows are stored
       // chain-compressed: Jc[contact row][slot], slot = position of the dof in the pair's dof list
       struct JEnt { int at; float r0, r1, r2, r3; };
-      item_loop2<G>(m.njac, gl,
+      item_loop2<G>(m.njac(), gl,
         [&](int t) {
-          const int pk = CI(m.c_jac + t), c = pk & 63, slot = (pk >> 6) & 31, i = (pk >> 11) & 31, sg = (pk >> 16) & 3, pr = pk >> 18;  // resolved on the host
-          const int rec = m.c_pair + pr * PAIR_S;
+          const int pk = CI(m.c_jac() + t), c = pk & 63, slot = (pk >> 6) & 31, i = (pk >> 11) & 31, sg = (pk >> 16) & 3, pr = pk >> 18;  // resolved on the host
+          const int rec = m.c_pair() + pr * PAIR_S;
           const float mu = CF(rec + 11);
           const int root1 = CI(rec + 7), root2 = CI(rec + 8);
           const f3 pt = mk3(con(1, c), con(2, c), con(3, c));
-          const int fo = eb + m.e_frame + pr * 9;
+          const int fo = eb + m.e_frame() + pr * 9;
           const f3 fn_ = mk3(lds[fo], lds[fo + 1], lds[fo + 2]), ft1 = mk3(lds[fo + 3], lds[fo + 4], lds[fo + 5]),
                    ft2 = mk3(lds[fo + 6], lds[fo + 7], lds[fo + 8]);
           const f3 w = mk3(dof(0, i), dof(1, i), dof(2, i)), l = mk3(dof(3, i), dof(4, i), dof(5, i));
@@ -1121,15 +1145,15 @@ struct Env {
     }
     WSYNC();
     float dd = 0, ar = 0;
-    if (con_on && gl < m.nefc) {
+    if (con_on && gl < m.nefc()) {
       const int r = gl;
       float pos = 0, invw = 0, jv = 0;
       bool active = false;
       int rec = 0;  // points at the {k,b,dmin,...} block of the row's record
-      if (r < m.neq) {
-        if (!(m.disableflags & DIS_EQUALITY)) {
+      if (r < m.neq()) {
+        if (!(m.disableflags() & DIS_EQUALITY)) {
           active = true;
-          const int er = m.c_eq + r * EQ_S, q1 = CI(er), q2 = CI(er + 2);
+          const int er = m.c_eq() + r * EQ_S, q1 = CI(er), q2 = CI(er + 2);
           const float pos1 = lds[qp + q1] - CF(er + 19);
           invw = CF(er + 18);
           rJ1 = 1.0f; rJ2 = 0.0f;
@@ -1148,8 +1172,8 @@ struct Env {
           rec = er + 9;
         }
       } else if (r < row0) {
-        if (!(m.disableflags & DIS_LIMIT)) {
-          const int lr = m.c_lim + (r - m.neq) * LIM_S;
+        if (!(m.disableflags() & DIS_LIMIT)) {
+          const int lr = m.c_lim() + (r - m.neq()) * LIM_S;
           const float q = lds[qp + CI(lr)];
           const float dmin = q - CF(lr + 2), dmax = CF(lr + 3) - q;
           pos = fminf(dmin, dmax) - CF(lr + 4);
@@ -1159,15 +1183,15 @@ struct Env {
           invw = CF(lr + 14);
           rec = lr + 5;
         }
-      } else if (!(m.disableflags & DIS_CONTACT)) {
+      } else if (!(m.disableflags() & DIS_CONTACT)) {
         const int cr = r - row0, c = cr >> 2, k = cr & 3;
-        const int pr = CI(m.c_conpair + c), prec = m.c_pair + pr * PAIR_S;
+        const int pr = CI(m.c_conpair() + c), prec = m.c_pair() + pr * PAIR_S;
         const float margin = CF(prec + 21), dist = con(0, c);
         active = dist < margin;
         pos = dist - margin;
         const float mu = CF(prec + 11), tw = CF(prec + 22);
         const float f = (k & 1) ? -mu : mu;
-        invw = (tw + f * f * tw) * 2 * f * f / m.impratio;
+        invw = (tw + f * f * tw) * 2 * f * f / m.impratio();
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
           const int pk = rchain[w];
@@ -1194,10 +1218,10 @@ struct Env {
   // (M v)[gl], v = dof field vf.  v is first staged contiguously in the (idle) H buffer so that both the lane's M row and
   // v stream in as ds_read_b128 (v: one address per group = broadcast); 2 * ldm/4 wide loads replace 2 * nv scalar ones.
   DEV float mul_M_row(int vf) const {
-    const int nv = m.nv, ldm = m.ldm, i = gl < nv ? gl : 0, Vo = eb + m.e_H;
+    const int nv = m.nv(), ldm = m.ldm(), i = gl < nv ? gl : 0, Vo = eb + m.e_H();
     if (gl < ldm) lds[Vo + gl] = gl < nv ? dof(vf, gl) : 0.0f;
     WSYNC();
-    const float4 *mr = reinterpret_cast<const float4 *>(lds + eb + m.e_M + i * ldm), *vv = reinterpret_cast<const float4 *>(lds + Vo);
+    const float4 *mr = reinterpret_cast<const float4 *>(lds + eb + m.e_M() + i * ldm), *vv = reinterpret_cast<const float4 *>(lds + Vo);
     float acc0 = 0, acc1 = 0;
 #pragma unroll 5
     for (int c = 0; c < (ldm >> 2); ++c) {
@@ -1209,13 +1233,13 @@ struct Env {
   }
   DEV float row_dot(int vf) const {  // J[gl,:] . v over the row's static support
     const int r = gl, vo = dofoff(vf);
-    if (r >= m.nefc) return 0.0f;
-    if (r < m.neq + m.nlim) {
+    if (r >= m.nefc()) return 0.0f;
+    if (r < m.neq() + m.nlim()) {
       float a = rJ1 * lds[vo + rd1 * DOF_E];
       if (rd2 >= 0) a += rJ2 * lds[vo + rd2 * DOF_E];
       return a;
     }
-    const int Jr = eb + m.e_J + rcr * m.ldc;
+    const int Jr = eb + m.e_J() + rcr * m.ldc();
     float a = 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {  // dof list from registers: no metadata loads on this path
@@ -1231,14 +1255,14 @@ struct Env {
   // Ma = M v, Jaref = J v - aref  (v = dof field vf)
   DEV void init_context(int vf) {
     const float ma = mul_M_row(vf);
-    if (gl < m.nv) dof(D_MA, gl) = ma;
+    if (gl < m.nv()) dof(D_MA, gl) = ma;
     rJaref = row_dot(vf) - rAref;
     WSYNC();
   }
   DEV float constraint_cost(int vf, float *gauss_out) const {
-    const bool act = gl < m.nefc && (rJaref < 0 || gl < m.neq);
+    const bool act = gl < m.nefc() && (rJaref < 0 || gl < m.neq());
     float c = act ? 0.5f * rD * rJaref * rJaref : 0.0f;
-    float g = gl < m.nv ? (dof(D_MA, gl) - dof(D_FSMOOTH, gl)) * (dof(vf, gl) - dof(D_ASMOOTH, gl)) : 0.0f;
+    float g = gl < m.nv() ? (dof(D_MA, gl) - dof(D_FSMOOTH, gl)) * (dof(vf, gl) - dof(D_ASMOOTH, gl)) : 0.0f;
     c = gsum<G>(c);
     g = 0.5f * gsum<G>(g);
     *gauss_out = g;
@@ -1247,24 +1271,24 @@ struct Env {
   // qfrc_constraint = J' f with f = -D*Jaref on active rows, grad = Ma - qfrc_smooth - qfrc_constraint;
   // also publishes D*active per row for the Hessian assembly.
   DEV void constraint_force_and_grad() {
-    const int Jo = eb + m.e_J, ldc = m.ldc, row0 = m.neq + m.nlim;
-    const bool act = gl < m.nefc && (rJaref < 0 || gl < m.neq) && rD > 0;
+    const int Jo = eb + m.e_J(), ldc = m.ldc(), row0 = m.neq() + m.nlim();
+    const bool act = gl < m.nefc() && (rJaref < 0 || gl < m.neq()) && rD > 0;
     ract = act;
     const float f = act ? -rD * rJaref : 0.0f;
-    if (gl < m.nefc) { row(0, gl) = act ? rD : 0.0f; row(1, gl) = f; }
+    if (gl < m.nefc()) { row(0, gl) = act ? rD : 0.0f; row(1, gl) = f; }
     WSYNC();
     // contact rows: dof lane i gathers over the (pair, slot) memberships of its dof
-    if (gl < m.nv) {
+    if (gl < m.nv()) {
       float acc = 0;
-      const int mem0 = CI(m.c_dofmemadr + gl), mem1 = CI(m.c_dofmemadr + gl + 1);
+      const int mem0 = CI(m.c_dofmemadr() + gl), mem1 = CI(m.c_dofmemadr() + gl + 1);
       // one term per contact whose ancestor chain holds this dof; two terms per trip so that their sixteen loads are in
       // flight together (an odd tail re-reads the last term with weight 0)
       for (int t = mem0; t < mem1; t += 2) {
         const bool two = t + 1 < mem1;
-        const int pk0 = CI(m.c_dofmem + t), pk1 = CI(m.c_dofmem + (two ? t + 1 : t));
+        const int pk0 = CI(m.c_dofmem() + t), pk1 = CI(m.c_dofmem() + (two ? t + 1 : t));
         const int c0 = pk0 & 255, c1 = pk1 & 255;
-        const int Ja = Jo + c0 * ldc + (pk0 >> 8), Fa = eb + m.e_row + (row0 + c0) * ROW_E + 1;
-        const int Jb = Jo + c1 * ldc + (pk1 >> 8), Fb = eb + m.e_row + (row0 + c1) * ROW_E + 1;
+        const int Ja = Jo + c0 * ldc + (pk0 >> 8), Fa = eb + m.e_row() + (row0 + c0) * ROW_E + 1;
+        const int Jb = Jo + c1 * ldc + (pk1 >> 8), Fb = eb + m.e_row() + (row0 + c1) * ROW_E + 1;
         float ja[4], fa[4], jb[4], fb[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { ja[k] = lds[Ja + k * ldc]; fa[k] = lds[Fa + k * ROW_E]; jb[k] = lds[Jb + k * ldc]; fb[k] = lds[Fb + k * ROW_E]; }
@@ -1282,7 +1306,7 @@ struct Env {
       if (rd2 >= 0) atomicAdd(&dof(D_FCON, rd2), rJ2 * f);
     }
     WSYNC();
-    if (gl < m.nv) dof(D_GRAD, gl) = dof(D_MA, gl) - dof(D_FSMOOTH, gl) - dof(D_FCON, gl);
+    if (gl < m.nv()) dof(D_GRAD, gl) = dof(D_MA, gl) - dof(D_FSMOOTH, gl) - dof(D_FCON, gl);
     WSYNC();
   }
   // Mgrad = (M + J' D_active J)^-1 grad, H a full symmetric matrix in LDS.
@@ -1290,14 +1314,14 @@ struct Env {
   // limit rows, rarely active and one or two entries each, are added with LDS atomics only when one of them is active.
   // G = 16 (four environments per wave do not map onto the two MFMA blocks): copy of M + atomics for every row kind.
   DEV void newton_direction() {
-    const int nv = m.nv, Mo = eb + m.e_M, Ho = eb + m.e_H, Jo = eb + m.e_J, ldc = m.ldc, ldm = m.ldm;
-    const int row0 = m.neq + m.nlim;
+    const int nv = m.nv(), Mo = eb + m.e_M(), Ho = eb + m.e_H(), Jo = eb + m.e_J(), ldc = m.ldc(), ldm = m.ldm();
+    const int row0 = m.neq() + m.nlim();
     bool scalar_rows = true;  // wave-uniform: some equality / limit row is active
     if (G >= 32) {
       const unsigned long long act = __ballot(ract);
       const unsigned long long rows = G == 32 ? ((act | (act >> 32)) & 0xFFFFFFFFull) : act;  // row active in any environment of the wave
       scalar_rows = (rows & (row0 >= 64 ? ~0ull : (1ull << row0) - 1ull)) != 0ull;
-      build_H_mfma<G>(Mo, Ho, ldm, nv, row0 < 64 ? rows >> row0 : 0ull, m.ncon, eb + m.e_row + row0 * ROW_E, Jo, ldc, m.c_slot, gl);
+      build_H_mfma<G>(Mo, Ho, ldm, nv, row0 < 64 ? rows >> row0 : 0ull, m.ncon(), eb + m.e_row() + row0 * ROW_E, Jo, ldc, m.c_slot(), gl);
     } else {
       lds_copy<G>(Ho, Mo, nv * ldm, gl);
       WSYNC();
@@ -1322,10 +1346,10 @@ struct Env {
       // contact rows: one lane per term (H entry, contact): the twelve operands of the contact's four pyramid rows are
       // fetched back to back, then reduced and added to the entry (ds_add_f32; entries are shared between contacts)
       struct HEnt { int at, at2; float v; };
-      item_loop2<G>(m.nhent, gl,
+      item_loop2<G>(m.nhent(), gl,
         [&](int t) {
-          const int pk = CI(m.c_hent + t), di = pk & 31, dj = (pk >> 5) & 31, cr0 = (pk >> 10) & 255, sa = (pk >> 18) & 31, sb = pk >> 23;
-          const int Jr = Jo + cr0 * ldc, Dr = eb + m.e_row + (row0 + cr0) * ROW_E;
+          const int pk = CI(m.c_hent() + t), di = pk & 31, dj = (pk >> 5) & 31, cr0 = (pk >> 10) & 255, sa = (pk >> 18) & 31, sb = pk >> 23;
+          const int Jr = Jo + cr0 * ldc, Dr = eb + m.e_row() + (row0 + cr0) * ROW_E;
           float d[4], ja[4], jb[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) { d[k] = lds[Dr + k * ROW_E]; ja[k] = lds[Jr + k * ldc + sa]; jb[k] = lds[Jr + k * ldc + sb]; }
@@ -1335,7 +1359,7 @@ struct Env {
       WSYNC();
     }
     PROF(14);
-    spd_solve<G>(m.nchol, Ho, ldm, nv, dofoff(D_GRAD), dofoff(D_MGRAD), gl, gb4);
+    spd_solve<G>(m.nchol(), Ho, ldm, nv, dofoff(D_GRAD), dofoff(D_MGRAD), gl, gb4);
   }
 
   DEV LSPoint ls_point(float alpha, bool valid, bool iseq, float g0, float g1, float g2) const {
@@ -1353,7 +1377,7 @@ struct Env {
 
   // MJX's bracketing line search.  `alive` freezes the state of a group that has already converged.
   DEV void linesearch(float gauss, bool alive) {
-    const int nv = m.nv;
+    const int nv = m.nv();
     const float mv = mul_M_row(D_SEARCH);
     rJv = row_dot(D_SEARCH);
     float sn = 0, g1 = 0, g2 = 0;
@@ -1365,8 +1389,8 @@ struct Env {
     }
     sn = gsum<G>(sn); g1 = gsum<G>(g1); g2 = gsum<G>(g2);
     PROF(21);
-    const float gtol = m.tolerance * m.ls_tolerance * sqrtf(sn) * m.scale;
-    const bool valid = gl < m.nefc, iseq = gl < m.neq;
+    const float gtol = m.tolerance() * m.ls_tolerance() * sqrtf(sn) * m.scale();
+    const bool valid = gl < m.nefc(), iseq = gl < m.neq();
 #define POINT(al) ls_point((al), valid, iseq, gauss, g1, g2)
 #define PICK(c, a, b) { (c) ? (a).alpha : (b).alpha, (c) ? (a).cost : (b).cost, (c) ? (a).d0 : (b).d0, (c) ? (a).d1 : (b).d1 }
     const LSPoint p0 = POINT(0.0f);
@@ -1374,7 +1398,7 @@ struct Env {
     const bool first = p1.d0 < p0.d0;
     LSPoint lo = PICK(first, p1, p0), hi = PICK(first, p0, p1);
     bool swap = true;
-    for (int it = 0; it < m.ls_iterations; ++it) {
+    for (int it = 0; it < m.ls_iterations(); ++it) {
       bool done = !swap;
       done = done || ((lo.d0 < 0) && (lo.d0 > -gtol));
       done = done || ((hi.d0 > 0) && (hi.d0 < gtol));
@@ -1409,11 +1433,11 @@ struct Env {
   }
 
   DEV void solve() {
-    const int nv = m.nv;
+    const int nv = m.nv();
     float gauss, cost, prev_cost;
     bool use_warm = false;
     float ma_warm = 0, ja_warm = 0;
-    if (!(m.disableflags & DIS_WARMSTART)) {
+    if (!(m.disableflags() & DIS_WARMSTART)) {
       float gw, gs;
       init_context(D_WARM);
       const float cw = constraint_cost(D_WARM, &gw);
@@ -1432,7 +1456,7 @@ struct Env {
     }
     if (use_warm) rJaref = ja_warm;
     WSYNC();
-    if (m.disableflags & DIS_WARMSTART) {
+    if (m.disableflags() & DIS_WARMSTART) {
       init_context(D_QACC);
       cost = constraint_cost(D_QACC, &gauss);
     }
@@ -1440,18 +1464,18 @@ struct Env {
     PROF(9);
     constraint_force_and_grad();
     PROF(10);
-    if (m.solver == 2) newton_direction();
-    else chol_solve<G>(m.nchol, eb + m.e_M, m.ldm, nv, eb + m.e_Lb, dofoff(D_GRAD), dofoff(D_MGRAD), false, gl, gb4);
+    if (m.solver() == 2) newton_direction();
+    else chol_solve<G>(m.nchol(), eb + m.e_M(), m.ldm(), nv, eb + m.e_Lb(), dofoff(D_GRAD), dofoff(D_MGRAD), false, gl, gb4);
     if (gl < nv) dof(D_SEARCH, gl) = -dof(D_MGRAD, gl);
     WSYNC();
     PROF(11);
     bool alive = true;  // per group: still iterating
-    for (int niter = 0; niter < m.iterations; ++niter) {
-      if (m.iterations != 1) {
+    for (int niter = 0; niter < m.iterations(); ++niter) {
+      if (m.iterations() != 1) {
         const float g = gl < nv ? dof(D_GRAD, gl) : 0.0f;
         const float gn = gsum<G>(g * g);
-        bool done = ((prev_cost - cost) / m.scale < m.tolerance);
-        done = done || (sqrtf(gn) / m.scale < m.tolerance);
+        bool done = ((prev_cost - cost) / m.scale() < m.tolerance());
+        done = done || (sqrtf(gn) / m.scale() < m.tolerance());
         alive = alive && !done;
       }
       if (!wave_any(alive)) break;
@@ -1459,8 +1483,8 @@ struct Env {
       linesearch(gauss, alive);
       PROF(13);
       float pg = 0;  // CG: keep grad.Mgrad of the previous iterate
-      if (m.solver != 2) {
-        if (gl < nv) { pg = dof(D_GRAD, gl) * dof(D_MGRAD, gl); lds[eb + m.e_H + gl] = dof(D_MGRAD, gl); }  // CG scratch: the H buffer is idle
+      if (m.solver() != 2) {
+        if (gl < nv) { pg = dof(D_GRAD, gl) * dof(D_MGRAD, gl); lds[eb + m.e_H() + gl] = dof(D_MGRAD, gl); }  // CG scratch: the H buffer is idle
         pg = gsum<G>(pg);
       }
       // a finished group's state is frozen, so recomputing its cost / force / gradient below is idempotent
@@ -1471,16 +1495,16 @@ struct Env {
       gauss = alive ? ngauss : gauss;
       constraint_force_and_grad();
       PROF(10);
-      if (m.solver == 2) {
+      if (m.solver() == 2) {
         // the search direction of an iteration that will not run is never read: skip its factorisation
-        if (niter + 1 < m.iterations) {
+        if (niter + 1 < m.iterations()) {
           newton_direction();
           PROF(11);
           if (gl < nv) dof(D_SEARCH, gl) = -dof(D_MGRAD, gl);
         }
       } else {
-        chol_solve<G>(m.nchol, eb + m.e_M, m.ldm, nv, eb + m.e_Lb, dofoff(D_GRAD), dofoff(D_MGRAD), false, gl, gb4);
-        float num = gl < nv ? dof(D_GRAD, gl) * (dof(D_MGRAD, gl) - lds[eb + m.e_H + gl]) : 0.0f;
+        chol_solve<G>(m.nchol(), eb + m.e_M(), m.ldm(), nv, eb + m.e_Lb(), dofoff(D_GRAD), dofoff(D_MGRAD), false, gl, gb4);
+        float num = gl < nv ? dof(D_GRAD, gl) * (dof(D_MGRAD, gl) - lds[eb + m.e_H() + gl]) : 0.0f;
         num = gsum<G>(num);
         const float beta = fmaxf(0.0f, num / fmaxf(MINVAL, pg));
         if (alive && gl < nv) dof(D_SEARCH, gl) = -dof(D_MGRAD, gl) + beta * dof(D_SEARCH, gl);
@@ -1491,7 +1515,7 @@ struct Env {
 
   // ------------------------------------------------------------------ forward (A9.1-A9.13)
   DEV void forward() {
-    const int nv = m.nv;
+    const int nv = m.nv();
     PROF(0);
     kinematics();
     PROF(1);
@@ -1499,9 +1523,9 @@ struct Env {
     PROF(2);
     crb_and_M();
     PROF(3);
-    if (m.ncon > 0 && !(m.disableflags & (DIS_CONTACT | DIS_CONSTRAINT))) collision();
+    if (m.ncon() > 0 && !(m.disableflags() & (DIS_CONTACT | DIS_CONSTRAINT))) collision();
     PROF(4);
-    if (m.nefc > 0) make_constraint();
+    if (m.nefc() > 0) make_constraint();
     PROF(5);
     velocity_and_bias();
     PROF(6);
@@ -1509,10 +1533,10 @@ struct Env {
     PROF(7);
     // qacc_smooth = M^-1 qfrc_smooth.  Newton never reuses the factor: one-shot Gauss-Jordan solve;
     // CG keeps a Cholesky factor in Lb as its preconditioner.
-    if (m.solver == 2) spd_solve<G>(m.nchol, eb + m.e_M, m.ldm, nv, dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), gl, gb4);
-    else chol_solve<G>(m.nchol, eb + m.e_M, m.ldm, nv, eb + m.e_Lb, dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), true, gl, gb4);
+    if (m.solver() == 2) spd_solve<G>(m.nchol(), eb + m.e_M(), m.ldm(), nv, dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), gl, gb4);
+    else chol_solve<G>(m.nchol(), eb + m.e_M(), m.ldm(), nv, eb + m.e_Lb(), dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), true, gl, gb4);
     PROF(8);
-    if (m.nefc == 0) {
+    if (m.nefc() == 0) {
       if (gl < nv) { dof(D_QACC, gl) = dof(D_ASMOOTH, gl); dof(D_FCON, gl) = 0; }
       WSYNC();
       return;
@@ -1525,35 +1549,35 @@ struct Env {
 
   // ------------------------------------------------------------------ A9.14 semi-implicit Euler
   DEV void euler() {
-    const int nv = m.nv, Mo = eb + m.e_M, Ho = eb + m.e_H;
-    const int qp = eb + m.e_qpos, qv = eb + m.e_qvel;
-    if (!(m.disableflags & DIS_EULERDAMP)) {
+    const int nv = m.nv(), Mo = eb + m.e_M(), Ho = eb + m.e_H();
+    const int qp = eb + m.e_qpos(), qv = eb + m.e_qvel();
+    if (!(m.disableflags() & DIS_EULERDAMP)) {
       // M + dt*diag(damping) in place: this is the last reader of M in the step and the crb pass rewrites it
-      if (gl < nv) { dof(D_SEARCH, gl) = dof(D_FSMOOTH, gl) + dof(D_FCON, gl); lds[Mo + gl * m.ldm + gl] += m.dt * CF(m.c_dof + gl * DOF_S + 5); }
+      if (gl < nv) { dof(D_SEARCH, gl) = dof(D_FSMOOTH, gl) + dof(D_FCON, gl); lds[Mo + gl * m.ldm() + gl] += m.dt() * CF(m.c_dof() + gl * DOF_S + 5); }
       WSYNC();
-      spd_solve<G>(m.nchol, Mo, m.ldm, nv, dofoff(D_SEARCH), dofoff(D_MV), gl, gb4);
+      spd_solve<G>(m.nchol(), Mo, m.ldm(), nv, dofoff(D_SEARCH), dofoff(D_MV), gl, gb4);
     } else {
       if (gl < nv) dof(D_MV, gl) = dof(D_QACC, gl);
       WSYNC();
     }
     PROF(16);
-    if (gl < nv) lds[qv + gl] += dof(D_MV, gl) * m.dt;
+    if (gl < nv) lds[qv + gl] += dof(D_MV, gl) * m.dt();
     WSYNC();
-    if (gl < m.njnt) {
-      const int jr = m.c_jnt + gl * JNT_S, t_ = CI(jr), qa = qp + CI(jr + 1), da = qv + CI(jr + 2);
+    if (gl < m.njnt()) {
+      const int jr = m.c_jnt() + gl * JNT_S, t_ = CI(jr), qa = qp + CI(jr + 1), da = qv + CI(jr + 2);
       if (t_ == JFREE || t_ == JBALL) {
         int qq = qa, dd = da;
         if (t_ == JFREE) {
-          lds[qa] += lds[da] * m.dt; lds[qa + 1] += lds[da + 1] * m.dt; lds[qa + 2] += lds[da + 2] * m.dt;
+          lds[qa] += lds[da] * m.dt(); lds[qa + 1] += lds[da + 1] * m.dt(); lds[qa + 2] += lds[da + 2] * m.dt();
           qq = qa + 3; dd = da + 3;
         }
         float n;
         const f3 w = normalize3(mk3(lds[dd], lds[dd + 1], lds[dd + 2]), &n);
         f4 q = {lds[qq], lds[qq + 1], lds[qq + 2], lds[qq + 3]};
-        q = qnormalize(qmul(q, axisangle(w, m.dt * n)));
+        q = qnormalize(qmul(q, axisangle(w, m.dt() * n)));
         lds[qq] = q.w; lds[qq + 1] = q.x; lds[qq + 2] = q.y; lds[qq + 3] = q.z;
       } else {
-        lds[qa] += lds[da] * m.dt;
+        lds[qa] += lds[da] * m.dt();
       }
     }
     WSYNC();
@@ -1583,28 +1607,29 @@ DEV DevModel split_scalars(const DevModel &in) {
 // =====================================================================================================
 #define AMX_BLOCK (AMX_WAVE * AMX_WAVES_PER_BLOCK)  // largest workgroup; the host launches 1..AMX_WAVES_PER_BLOCK waves per workgroup
 #define AMX_KERNEL_PROLOGUE()                                                                               \
-  const DevModel m = split_scalars(m_in);                                                                    \
+  const DevModel md_ = S::is_static ? m_in : split_scalars(m_in); /* a static spec reads a handful of words: no need */ \
+  const MV<S> m{md_};                                                                                        \
   const int lane = threadIdx.x & (AMX_WAVE - 1), wave = threadIdx.x / AMX_WAVE;                              \
   const int gl = lane & (G - 1), grp = lane / G, gb4 = 4 * (lane & ~(G - 1));                                \
   const int slot = wave * (AMX_WAVE / G) + grp; /* environment slot inside the workgroup */                 \
   const int wpb = blockDim.x / AMX_WAVE; /* waves in this workgroup, chosen by the host to fill the CU's LDS */ \
   const int e = blockIdx.x * (wpb * (AMX_WAVE / G)) + slot;                                  \
   /* stage the model constants once per workgroup (coalesced, shared by its waves) */                       \
-  for (int i = threadIdx.x; i < m.nconst; i += blockDim.x) lds[i] = m.image[i];                               \
+  for (int i = threadIdx.x; i < m.nconst(); i += blockDim.x) lds[i] = m.image()[i];                               \
   __syncthreads(); /* the only workgroup barrier; the waves are independent from here on */                 \
   if (blockIdx.x * (wpb * (AMX_WAVE / G)) + wave * (AMX_WAVE / G) >= nenv) return; /* whole wave idle */ \
   const bool live = e < nenv; /* a trailing group without an environment still runs, on a zero slab, and never touches HBM */ \
-  const int eb = m.nconst + slot * m.env_floats;                                                             \
-  const int nq = m.nq, nv = m.nv, nu = m.nu, nx = nq + nv;                                                   \
+  const int eb = m.nconst() + slot * m.env_floats();                                                             \
+  const int nq = m.nq(), nv = m.nv(), nu = m.nu(), nx = nq + nv;                                                   \
   /* zero the slab once: J, M and H have static sparsity and are only written on their support */           \
-  for (int i = gl; i < m.env_floats; i += G) lds[eb + i] = 0.0f;                                             \
-  if (!live && gl < nq) lds[eb + m.e_qpos + gl] = CF(m.c_qpos0 + gl); /* keep the idle group's state finite */ \
+  for (int i = gl; i < m.env_floats(); i += G) lds[eb + i] = 0.0f;                                             \
+  if (!live && gl < nq) lds[eb + m.e_qpos() + gl] = CF(m.c_qpos0() + gl); /* keep the idle group's state finite */ \
   WSYNC();                                                                                                   \
-  Env<G> env(m, eb, gl, gb4);                                                                                \
-  const int qp = eb + m.e_qpos, qv = eb + m.e_qvel;
+  Env<G, S> env(m, eb, gl, gb4);                                                                               \
+  const int qp = eb + m.e_qpos(), qv = eb + m.e_qvel();
 
 // vmap(shoot): state stays in LDS for the whole horizon; HBM sees one control row in and one state row out per step.
-template <int G>
+template <int G, class S>
 __global__ void __launch_bounds__(AMX_BLOCK, AMX_MIN_WAVES_PER_SIMD)
 amx_rollout_kernel(const DevModel m_in, int nenv, int nsteps, int x0_batched, const float *__restrict__ x0g, const float *__restrict__ usg,
                    float *__restrict__ xs, float *__restrict__ xfinal, float *__restrict__ prof) {
@@ -1627,8 +1652,8 @@ amx_rollout_kernel(const DevModel m_in, int nenv, int nsteps, int x0_batched, co
   // t = -1 is shoot()'s forward before the scan (ctrl = 0): it only seeds qacc_warmstart
   for (int t = -1; t < nsteps; ++t) {
     if (t >= 0) {
-      if (gl < nu) lds[eb + m.e_ctrl + gl] = unext;
-      if (live) for (int i = gl + G; i < nu; i += G) lds[eb + m.e_ctrl + i] = us[(size_t)t * nu + i];
+      if (gl < nu) lds[eb + m.e_ctrl() + gl] = unext;
+      if (live) for (int i = gl + G; i < nu; i += G) lds[eb + m.e_ctrl() + i] = us[(size_t)t * nu + i];
       if (live && t + 1 < nsteps && gl < nu) unext = us[(size_t)(t + 1) * nu + gl];
       WSYNC();
     }
@@ -1641,20 +1666,20 @@ amx_rollout_kernel(const DevModel m_in, int nenv, int nsteps, int x0_batched, co
       }
     }
 #ifdef AMX_PROFILE
-    { unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); if (gl == 0) lds[eb + m.e_prof + 18] += (float)(t_ - env.prof_t); env.prof_t = t_; }
+    { unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); if (gl == 0) lds[eb + m.e_prof() + 18] += (float)(t_ - env.prof_t); env.prof_t = t_; }
 #endif
   }
   if (xfinal && live)
     for (int i = gl; i < nx; i += G) xfinal[(size_t)e * nx + i] = i < nq ? lds[qp + i] : lds[qv + i - nq];
 #ifdef AMX_PROFILE
   WSYNC();
-  if (prof && live && gl < PROF_N) prof[(size_t)e * PROF_N + gl] = lds[eb + m.e_prof + gl];
-  if (prof && live && G < PROF_N && gl + G < PROF_N) prof[(size_t)e * PROF_N + gl + G] = lds[eb + m.e_prof + gl + G];
+  if (prof && live && gl < PROF_N) prof[(size_t)e * PROF_N + gl] = lds[eb + m.e_prof() + gl];
+  if (prof && live && G < PROF_N && gl + G < PROF_N) prof[(size_t)e * PROF_N + gl + G] = lds[eb + m.e_prof() + gl + G];
 #endif
 }
 
 // MjxEnv.pipeline_step: nsub physics steps with ctrl held; state comes from and returns to HBM.
-template <int G>
+template <int G, class S>
 __global__ void __launch_bounds__(AMX_BLOCK, AMX_MIN_WAVES_PER_SIMD)
 amx_step_kernel(const DevModel m_in, int nenv, int nsub, float *__restrict__ qpos, float *__restrict__ qvel, const float *__restrict__ ctrl,
                 float *__restrict__ warm, float *__restrict__ time) {
@@ -1663,9 +1688,9 @@ amx_step_kernel(const DevModel m_in, int nenv, int nsub, float *__restrict__ qpo
     for (int i = gl; i < nq; i += G) lds[qp + i] = qpos[(size_t)e * nq + i];
     if (gl < nv) {
       lds[qv + gl] = qvel[(size_t)e * nv + gl];
-      env.dof(Env<G>::D_WARM, gl) = warm ? warm[(size_t)e * nv + gl] : 0.0f;
+      env.dof(Env<G, S>::D_WARM, gl) = warm ? warm[(size_t)e * nv + gl] : 0.0f;
     }
-    for (int i = gl; i < nu; i += G) lds[eb + m.e_ctrl + i] = ctrl[(size_t)e * nu + i];
+    for (int i = gl; i < nu; i += G) lds[eb + m.e_ctrl() + i] = ctrl[(size_t)e * nu + i];
   }
   WSYNC();
   for (int t = 0; t < nsub; ++t) { env.forward(); env.euler(); }
@@ -1673,15 +1698,15 @@ amx_step_kernel(const DevModel m_in, int nenv, int nsub, float *__restrict__ qpo
   for (int i = gl; i < nq; i += G) qpos[(size_t)e * nq + i] = lds[qp + i];
   if (gl < nv) {
     qvel[(size_t)e * nv + gl] = lds[qv + gl];
-    if (warm) warm[(size_t)e * nv + gl] = env.dof(Env<G>::D_WARM, gl);
+    if (warm) warm[(size_t)e * nv + gl] = env.dof(Env<G, S>::D_WARM, gl);
   }
-  if (time && gl == 0) time[e] += m.dt * nsub;
+  if (time && gl == 0) time[e] += m.dt() * nsub;
 }
 
 struct ForwardOut { float *qacc, *qacc_smooth, *qfrc_bias, *qfrc_constraint, *qM, *xpos, *xquat, *cdist; int *nefc; };
 
 // mjx.forward: derived quantities for a given state, no integration.
-template <int G>
+template <int G, class S>
 __global__ void __launch_bounds__(AMX_BLOCK, AMX_MIN_WAVES_PER_SIMD)
 amx_forward_kernel(const DevModel m_in, int nenv, const float *__restrict__ qpos, const float *__restrict__ qvel, const float *__restrict__ ctrl,
                    const float *__restrict__ warm, const ForwardOut o) {
@@ -1690,31 +1715,31 @@ amx_forward_kernel(const DevModel m_in, int nenv, const float *__restrict__ qpos
     for (int i = gl; i < nq; i += G) lds[qp + i] = qpos[(size_t)e * nq + i];
     if (gl < nv) {
       lds[qv + gl] = qvel[(size_t)e * nv + gl];
-      env.dof(Env<G>::D_WARM, gl) = warm ? warm[(size_t)e * nv + gl] : 0.0f;
+      env.dof(Env<G, S>::D_WARM, gl) = warm ? warm[(size_t)e * nv + gl] : 0.0f;
     }
-    for (int i = gl; i < nu; i += G) lds[eb + m.e_ctrl + i] = ctrl[(size_t)e * nu + i];
+    for (int i = gl; i < nu; i += G) lds[eb + m.e_ctrl() + i] = ctrl[(size_t)e * nu + i];
   }
   WSYNC();
   env.forward();
-  const int nactive = __popcll(__ballot(gl < m.nefc && env.rD > 0) >> (lane & ~(G - 1)) & (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1)));
+  const int nactive = __popcll(__ballot(gl < m.nefc() && env.rD > 0) >> (lane & ~(G - 1)) & (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1)));
   if (!live) return;
   if (gl < nv) {
-    if (o.qacc) o.qacc[(size_t)e * nv + gl] = env.dof(Env<G>::D_QACC, gl);
-    if (o.qacc_smooth) o.qacc_smooth[(size_t)e * nv + gl] = env.dof(Env<G>::D_ASMOOTH, gl);
-    if (o.qfrc_bias) o.qfrc_bias[(size_t)e * nv + gl] = env.dof(Env<G>::D_FBIAS, gl);
-    if (o.qfrc_constraint) o.qfrc_constraint[(size_t)e * nv + gl] = env.dof(Env<G>::D_FCON, gl);
+    if (o.qacc) o.qacc[(size_t)e * nv + gl] = env.dof(Env<G, S>::D_QACC, gl);
+    if (o.qacc_smooth) o.qacc_smooth[(size_t)e * nv + gl] = env.dof(Env<G, S>::D_ASMOOTH, gl);
+    if (o.qfrc_bias) o.qfrc_bias[(size_t)e * nv + gl] = env.dof(Env<G, S>::D_FBIAS, gl);
+    if (o.qfrc_constraint) o.qfrc_constraint[(size_t)e * nv + gl] = env.dof(Env<G, S>::D_FCON, gl);
   }
   if (o.qM)
     for (int k = gl; k < nv * nv; k += G) {
       const int r = k / nv, c = k % nv, hi = r > c ? r : c, lo = r > c ? c : r;
-      o.qM[(size_t)e * nv * nv + k] = lds[eb + m.e_M + hi * m.ldm + lo];
+      o.qM[(size_t)e * nv * nv + k] = lds[eb + m.e_M() + hi * m.ldm() + lo];
     }
   if (o.xpos)
-    for (int k = gl; k < m.nb * 3; k += G) o.xpos[(size_t)e * m.nb * 3 + k] = env.body(k % 3, k / 3);
+    for (int k = gl; k < m.nb() * 3; k += G) o.xpos[(size_t)e * m.nb() * 3 + k] = env.body(k % 3, k / 3);
   if (o.xquat)
-    for (int k = gl; k < m.nb * 4; k += G) o.xquat[(size_t)e * m.nb * 4 + k] = env.body(3 + k % 4, k / 4);
+    for (int k = gl; k < m.nb() * 4; k += G) o.xquat[(size_t)e * m.nb() * 4 + k] = env.body(3 + k % 4, k / 4);
   if (o.cdist)
-    for (int k = gl; k < m.ncon; k += G) o.cdist[(size_t)e * m.ncon + k] = env.con(0, k);
+    for (int k = gl; k < m.ncon(); k += G) o.cdist[(size_t)e * m.ncon() + k] = env.con(0, k);
   if (o.nefc && gl == 0) o.nefc[e] = nactive;
 }
 
