@@ -425,6 +425,60 @@ __device__ __noinline__ void spd_solve_rows(int A_off, int ld, int n, int rhs_of
   WSYNC();
 }
 
+// The same solve for a compile-time spec: N = nv exactly, offsets are immediates, and - TREE - the elimination follows the
+// dof tree.  M[i][j] != 0 only when j is an ancestor of i (or i of j); H = M + J'DJ keeps that pattern when every constraint
+// row couples dofs of one ancestor chain (Spec::tree_H).  Pivots then run from the last dof to the first (leaves before
+// their ancestors): when pivot J is reached, row J holds nothing but its diagonal and its ancestors' columns, so only those
+// depth(J) entries travel through the crossbar and only they are updated - no fill-in, ever (MuJoCo's own L'DL order).
+// Quadruped: 135 broadcasts per solve instead of 207; biped: 291 instead of 495; eliminations of different limbs are
+// independent chains the scheduler interleaves.
+template <class S, int G, int J, int K> struct GJAnc {  // K walks J's ancestor chain
+  static DEV void run(float (&a)[S::nv], float f) {
+    a[K] = __builtin_fmaf(-f, gbcast_s<G, J>(a[K]), a[K]);
+    GJAnc<S, G, J, S::dof_parent[K]>::run(a, f);
+  }
+};
+template <class S, int G, int J> struct GJAnc<S, G, J, -1> { static DEV void run(float (&)[S::nv], float) {} };
+template <class S, int G, int J> struct GJTree {
+  static DEV void run(float (&a)[S::nv], float &b, int gl) {
+    const float piv = gbcast_s<G, J>(a[J]);
+    const float bj = gbcast_s<G, J>(b);
+    float f = a[J] * __builtin_amdgcn_rcpf(fmaxf(piv, MINVAL));
+    f = gl == J ? 0.0f : f;  // the pivot row itself is left alone
+    b = __builtin_fmaf(-f, bj, b);
+    GJAnc<S, G, J, S::dof_parent[J]>::run(a, f);
+    GJTree<S, G, J - 1>::run(a, b, gl);
+  }
+};
+template <class S, int G> struct GJTree<S, G, -1> { static DEV void run(float (&)[S::nv], float &, int) {} };
+
+template <class S, int G, bool TREE>
+__device__ __noinline__ void spd_solve_static(int A_off, int rhs_off, int x_off, int gl) {
+  constexpr int N = S::nv, ld = S::ldm;
+  float a[N];
+  const int li = gl < N ? gl : 0;
+  const float4 *rowp = reinterpret_cast<const float4 *>(lds + A_off + li * ld);
+#pragma unroll
+  for (int c = 0; c < (N + 3) / 4; ++c) {
+    const float4 v = rowp[c];
+    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = 4 * c + q;
+      if (k < N) a[k] = gl < N ? e[q] : (k == gl ? 1.0f : 0.0f);
+    }
+  }
+  float b = lds[rhs_off + li * DOF_E];
+  b = gl < N ? b : 0.0f;
+  if (TREE) GJTree<S, G, N - 1>::run(a, b, gl);
+  else GJ<N, G, 0>::run(a, b, gl, 0);
+  float d = 1.0f;
+#pragma unroll
+  for (int k = 0; k < N; ++k) d = (k == gl) ? a[k] : d;
+  if (gl < N) lds[x_off + gl * DOF_E] = b / d;
+  WSYNC();
+}
+
 template <int G>
 __device__ __noinline__ void spd_solve(int nchol, int A_off, int ld, int n, int rhs_off, int x_off, int gl, int gb4) {
   const int vstride = DOF_E;
@@ -1359,7 +1413,8 @@ struct Env {
       WSYNC();
     }
     PROF(14);
-    spd_solve<G>(m.nchol(), Ho, ldm, nv, dofoff(D_GRAD), dofoff(D_MGRAD), gl, gb4);
+    if constexpr (S::is_static) spd_solve_static<S, G, S::tree_H>(Ho, dofoff(D_GRAD), dofoff(D_MGRAD), gl);
+    else spd_solve<G>(m.nchol(), Ho, ldm, nv, dofoff(D_GRAD), dofoff(D_MGRAD), gl, gb4);
   }
 
   DEV LSPoint ls_point(float alpha, bool valid, bool iseq, float g0, float g1, float g2) const {
@@ -1533,7 +1588,10 @@ struct Env {
     PROF(7);
     // qacc_smooth = M^-1 qfrc_smooth.  Newton never reuses the factor: one-shot Gauss-Jordan solve;
     // CG keeps a Cholesky factor in Lb as its preconditioner.
-    if (m.solver() == 2) spd_solve<G>(m.nchol(), eb + m.e_M(), m.ldm(), nv, dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), gl, gb4);
+    if (m.solver() == 2) {
+      if constexpr (S::is_static) spd_solve_static<S, G, true>(eb + m.e_M(), dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), gl);
+      else spd_solve<G>(m.nchol(), eb + m.e_M(), m.ldm(), nv, dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), gl, gb4);
+    }
     else chol_solve<G>(m.nchol(), eb + m.e_M(), m.ldm(), nv, eb + m.e_Lb(), dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), true, gl, gb4);
     PROF(8);
     if (m.nefc() == 0) {
@@ -1555,7 +1613,8 @@ struct Env {
       // M + dt*diag(damping) in place: this is the last reader of M in the step and the crb pass rewrites it
       if (gl < nv) { dof(D_SEARCH, gl) = dof(D_FSMOOTH, gl) + dof(D_FCON, gl); lds[Mo + gl * m.ldm() + gl] += m.dt() * CF(m.c_dof() + gl * DOF_S + 5); }
       WSYNC();
-      spd_solve<G>(m.nchol(), Mo, m.ldm(), nv, dofoff(D_SEARCH), dofoff(D_MV), gl, gb4);
+      if constexpr (S::is_static) spd_solve_static<S, G, true>(Mo, dofoff(D_SEARCH), dofoff(D_MV), gl);
+      else spd_solve<G>(m.nchol(), Mo, m.ldm(), nv, dofoff(D_SEARCH), dofoff(D_MV), gl, gb4);
     } else {
       if (gl < nv) dof(D_MV, gl) = dof(D_QACC, gl);
       WSYNC();
