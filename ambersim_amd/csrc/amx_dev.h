@@ -36,6 +36,7 @@ enum { BODY_S = 25, JNT_S = 13, DOF_S = 9, ACT_S = 13, GEOM_S = 13, PAIR_S = 29,
   X(ldc) /* contact-row stride: longest pair dof list, odd */                                                              \
   X(ldm) /* row stride of M and H: >= nv, ldm/4 odd */                                                                     \
   X(nchol) X(njac) X(nhent)                                                                                                \
+  X(pcx_first) X(npcx) /* run of plane - convex pairs (<= 32 hull vertices) handled one lane per vertex; npcx = 0: none */   \
   X(iterations) X(ls_iterations) X(solver) X(disableflags)                                                                 \
   X(G)   /* lanes per environment: 16, 32 or 64 */                                                                         \
   X(wpb) /* wavefronts per workgroup (1..AMX_WAVES_PER_BLOCK), chosen to maximise resident waves per CU */                 \

@@ -648,13 +648,21 @@ struct Env {
   // static role constants of this lane
   int b_parent, b_level, b_root, b_jntadr, b_jntnum, b_childadr, b_childnum;  // body `lane`
   int d_body, d_jnt, d_kind, d_axis, d_root;                                  // dof `lane`
-  // per-row solver state of row `lane`
-  float rD, rAref, rJaref, rJv;
-  int rchain[4], rdn, rcr;  // contact row `gl`: its pair's dof list (<=16 dofs, one byte each), its length, its contact-row index
-  float rJ1, rJ2;  // equality / limit row `gl`: Jacobian entries on dofs rd1, rd2 (contact rows live in LDS, chain-compressed)
+  // Constraint rows: a lane owns TWO row slots, so that a group of G lanes carries up to 2 G rows -
+  //   slot A: equality / limit row `gl` (gl < nA = neq + nlim): one or two Jacobian entries, kept in registers;
+  //   slot B: contact pyramid row `gl` (gl < nB = 4 ncon): its Jacobian row lives in LDS, chain-compressed.
+  // (One slot per lane made the 56 rows of the biped - 24 limits, 32 contact rows - need a 64-lane group for a 30-dof model.)
+  // Row r of the reference's row table is A row r, or B row r - nA.
+  float aD, aAref, aJaref, aJv;  // slot A solver state
+  float cD, cAref, cJaref, cJv;  // slot B solver state
+  int rchain[4], rdn;  // contact row `gl`: its pair's dof list (<=16 dofs, one byte each) and its length
+  float rJ1, rJ2;      // equality / limit row `gl`: Jacobian entries on dofs rd1, rd2
   int rd1, rd2;
-  bool ract;  // row role: the row is active at the current iterate (set by constraint_force_and_grad)
+  bool aact, cact;  // the slot's row is active at the current iterate (set by constraint_force_and_grad)
   PROF_DECL
+
+  DEV int nA() const { return m.nefc() == 0 ? 0 : m.neq() + m.nlim(); }  // nefc == 0: constraints disabled
+  DEV int nB() const { return m.nefc() == 0 ? 0 : 4 * m.ncon(); }
 
   DEV Env(const MV<S> &m_, int eb_, int gl_, int gb4_) : m(m_), eb(eb_), gl(gl_), gb4(gb4_) {
     const int lane = gl;
@@ -663,15 +671,14 @@ struct Env {
     b_childadr = CI(br + 5); b_childnum = CI(br + 6);
     const int dr = m.c_dof() + (lane < m.nv() ? lane : 0) * DOF_S;
     d_body = CI(dr); d_jnt = CI(dr + 1); d_kind = CI(dr + 2); d_axis = CI(dr + 3); d_root = CI(dr + 8);
-    rD = rAref = rJaref = rJv = rJ1 = rJ2 = 0.0f;
-    ract = false;
+    aD = aAref = aJaref = aJv = cD = cAref = cJaref = cJv = rJ1 = rJ2 = 0.0f;
+    aact = cact = false;
     rd1 = 0; rd2 = -1;
     if (lane < m.neq()) { const int er = m.c_eq() + lane * EQ_S; rd1 = CI(er + 1); rd2 = CI(er + 3); }
     else if (lane < m.neq() + m.nlim()) rd1 = CI(m.c_lim() + (lane - m.neq()) * LIM_S + 1);
-    rchain[0] = rchain[1] = rchain[2] = rchain[3] = 0; rdn = 0; rcr = 0;
-    if (lane >= m.neq() + m.nlim() && lane < m.nefc()) {
-      rcr = lane - m.neq() - m.nlim();
-      const int prec = m.c_pair() + CI(m.c_conpair() + (rcr >> 2)) * PAIR_S, d0 = CI(prec + 9);
+    rchain[0] = rchain[1] = rchain[2] = rchain[3] = 0; rdn = 0;
+    if (lane < 4 * m.ncon()) {
+      const int prec = m.c_pair() + CI(m.c_conpair() + (lane >> 2)) * PAIR_S, d0 = CI(prec + 9);
       rdn = CI(prec + 10);
 #pragma unroll
       for (int w = 0; w < 4; ++w) {  // static register indices only (a runtime-indexed array would live in scratch)
@@ -1053,23 +1060,11 @@ struct Env {
   DEV void st_contact(int c, float d, f3 cp) const { con(0, c) = d; con(1, c) = cp.x; con(2, c) = cp.y; con(3, c) = cp.z; }
   DEV void collision() {
     const int np = m.npair();
-    // plane-convex pairs with at most 32 hull vertices go to the vertex-parallel routine when they form one contiguous run of
-    // pair indices (pairs are grouped by function, so they do unless a larger hull sits among them); found with a ballot
-    // over the pair lanes rather than carried in the model descriptor, which has no scalar registers to spare
-    // (64-lane groups only: in the 32-lane kernel the extra code cost the quadruped 1 % without a model to gain from it)
-    int cx_first = 0, cx_num = 0;
-    if (G >= 64) {
-      const int rec0 = m.c_pair() + (gl < np ? gl : 0) * PAIR_S;
-      const bool is_cx = gl < np && CI(rec0 + 2) == 2 && CI(rec0 + 6) <= 32;
-      const unsigned long long bal = __ballot(is_cx) >> ((gb4 >> 2) & 63);
-      const unsigned long long mine = G == 32 ? (bal & 0xFFFFFFFFull) : bal;
-      if (mine != 0ull) {
-        const int lo = __builtin_ctzll(mine), hi = 63 - __builtin_clzll(mine);
-        if (__builtin_popcountll(mine) == hi - lo + 1) { cx_first = lo; cx_num = hi - lo + 1; }
-      }
-    }
-    const bool par_cx = G >= 64 && cx_num > 0;  // one group per wave: uniform
-    if (par_cx) plane_convex_parallel<G>(cx_first, cx_num, m.c_pair(), m.c_vert(), eb + m.e_geom(), eb + m.e_con(), eb + m.e_frame(), gl, gb4);
+    // plane - convex pairs with at most 32 hull vertices: one lane per hull vertex (plane_convex_parallel), on groups of 32
+    // lanes (one pair per pass) and 64 lanes (two).  The planner found the run of such pairs (pcx_first, npcx).
+    const int cx_first = G >= 32 ? m.pcx_first() : 0, cx_num = G >= 32 ? m.npcx() : 0;
+    if (G >= 32 && cx_num > 0)  // uniform: a property of the model
+      plane_convex_parallel<G>(cx_first, cx_num, m.c_pair(), m.c_vert(), eb + m.e_geom(), eb + m.e_con(), eb + m.e_frame(), gl, gb4);
     if (gl < np && !(gl >= cx_first && gl < cx_first + cx_num)) {
       const int pr = gl, rec = m.c_pair() + pr * PAIR_S;
       const int g1 = CI(rec), g2 = CI(rec + 1), fn = CI(rec + 2), c0 = CI(rec + 3);
@@ -1198,8 +1193,9 @@ struct Env {
         [&](int, const JEnt &r) { lds[r.at] = r.r0; lds[r.at + ldc] = r.r1; lds[r.at + 2 * ldc] = r.r2; lds[r.at + 3 * ldc] = r.r3; });
     }
     WSYNC();
+    // slot A: equality / limit row gl
     float dd = 0, ar = 0;
-    if (con_on && gl < m.nefc()) {
+    if (con_on && gl < nA()) {
       const int r = gl;
       float pos = 0, invw = 0, jv = 0;
       bool active = false;
@@ -1225,37 +1221,16 @@ struct Env {
           }
           rec = er + 9;
         }
-      } else if (r < row0) {
-        if (!(m.disableflags() & DIS_LIMIT)) {
-          const int lr = m.c_lim() + (r - m.neq()) * LIM_S;
-          const float q = lds[qp + CI(lr)];
-          const float dmin = q - CF(lr + 2), dmax = CF(lr + 3) - q;
-          pos = fminf(dmin, dmax) - CF(lr + 4);
-          active = pos < 0;
-          rJ1 = dmin < dmax ? 1.0f : -1.0f;
-          jv = rJ1 * lds[qv + rd1];
-          invw = CF(lr + 14);
-          rec = lr + 5;
-        }
-      } else if (!(m.disableflags() & DIS_CONTACT)) {
-        const int cr = r - row0, c = cr >> 2, k = cr & 3;
-        const int pr = CI(m.c_conpair() + c), prec = m.c_pair() + pr * PAIR_S;
-        const float margin = CF(prec + 21), dist = con(0, c);
-        active = dist < margin;
-        pos = dist - margin;
-        const float mu = CF(prec + 11), tw = CF(prec + 22);
-        const float f = (k & 1) ? -mu : mu;
-        invw = (tw + f * f * tw) * 2 * f * f / m.impratio();
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          const int pk = rchain[w];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int t = 4 * w + q;
-            if (t < rdn) jv += lds[Jo + cr * ldc + t] * lds[qv + ((pk >> (8 * q)) & 255)];
-          }
-        }
-        rec = prec + 12;
+      } else if (!(m.disableflags() & DIS_LIMIT)) {
+        const int lr = m.c_lim() + (r - m.neq()) * LIM_S;
+        const float q = lds[qp + CI(lr)];
+        const float dmin = q - CF(lr + 2), dmax = CF(lr + 3) - q;
+        pos = fminf(dmin, dmax) - CF(lr + 4);
+        active = pos < 0;
+        rJ1 = dmin < dmax ? 1.0f : -1.0f;
+        jv = rJ1 * lds[qv + rd1];
+        invw = CF(lr + 14);
+        rec = lr + 5;
       }
       if (active) {
         const float imp = row_impedance(rec, pos);
@@ -1264,8 +1239,38 @@ struct Env {
         ar = -CF(rec + 1) * jv - CF(rec) * imp * pos;
       }
     }
-    rD = dd;
-    rAref = ar;
+    aD = dd;
+    aAref = ar;
+    // slot B: contact pyramid row gl
+    dd = 0; ar = 0;
+    if (con_on && gl < nB() && !(m.disableflags() & DIS_CONTACT)) {
+      const int cr = gl, c = cr >> 2, k = cr & 3;
+      const int pr = CI(m.c_conpair() + c), prec = m.c_pair() + pr * PAIR_S;
+      const float margin = CF(prec + 21), dist = con(0, c);
+      const float pos = dist - margin;
+      const float mu = CF(prec + 11), tw = CF(prec + 22);
+      const float f = (k & 1) ? -mu : mu;
+      const float invw = (tw + f * f * tw) * 2 * f * f / m.impratio();
+      float jv = 0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const int pk = rchain[w];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int t = 4 * w + q;
+          if (t < rdn) jv += lds[Jo + cr * ldc + t] * lds[qv + ((pk >> (8 * q)) & 255)];
+        }
+      }
+      if (dist < margin) {
+        const int rec = prec + 12;
+        const float imp = row_impedance(rec, pos);
+        const float rr = fmaxf(invw * (1 - imp) / imp, MINVAL);
+        dd = 1.0f / rr;
+        ar = -CF(rec + 1) * jv - CF(rec) * imp * pos;
+      }
+    }
+    cD = dd;
+    cAref = ar;
   }
 
   // ------------------------------------------------------------------ A9.13 solver
@@ -1285,15 +1290,18 @@ struct Env {
     }
     return acc0 + acc1;
   }
-  DEV float row_dot(int vf) const {  // J[gl,:] . v over the row's static support
-    const int r = gl, vo = dofoff(vf);
-    if (r >= m.nefc()) return 0.0f;
-    if (r < m.neq() + m.nlim()) {
-      float a = rJ1 * lds[vo + rd1 * DOF_E];
-      if (rd2 >= 0) a += rJ2 * lds[vo + rd2 * DOF_E];
-      return a;
-    }
-    const int Jr = eb + m.e_J() + rcr * m.ldc();
+  // J[row,:] . v over the row's static support, for the lane's two row slots
+  DEV float row_dot_A(int vf) const {
+    const int vo = dofoff(vf);
+    if (gl >= nA()) return 0.0f;
+    float a = rJ1 * lds[vo + rd1 * DOF_E];
+    if (rd2 >= 0) a += rJ2 * lds[vo + rd2 * DOF_E];
+    return a;
+  }
+  DEV float row_dot_B(int vf) const {
+    const int vo = dofoff(vf);
+    if (gl >= nB()) return 0.0f;
+    const int Jr = eb + m.e_J() + gl * m.ldc();
     float a = 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {  // dof list from registers: no metadata loads on this path
@@ -1310,12 +1318,13 @@ struct Env {
   DEV void init_context(int vf) {
     const float ma = mul_M_row(vf);
     if (gl < m.nv()) dof(D_MA, gl) = ma;
-    rJaref = row_dot(vf) - rAref;
+    aJaref = row_dot_A(vf) - aAref;
+    cJaref = row_dot_B(vf) - cAref;
     WSYNC();
   }
   DEV float constraint_cost(int vf, float *gauss_out) const {
-    const bool act = gl < m.nefc() && (rJaref < 0 || gl < m.neq());
-    float c = act ? 0.5f * rD * rJaref * rJaref : 0.0f;
+    const bool actA = gl < nA() && (aJaref < 0 || gl < m.neq()), actB = gl < nB() && cJaref < 0;
+    float c = (actA ? 0.5f * aD * aJaref * aJaref : 0.0f) + (actB ? 0.5f * cD * cJaref * cJaref : 0.0f);
     float g = gl < m.nv() ? (dof(D_MA, gl) - dof(D_FSMOOTH, gl)) * (dof(vf, gl) - dof(D_ASMOOTH, gl)) : 0.0f;
     c = gsum<G>(c);
     g = 0.5f * gsum<G>(g);
@@ -1326,10 +1335,11 @@ struct Env {
   // also publishes D*active per row for the Hessian assembly.
   DEV void constraint_force_and_grad() {
     const int Jo = eb + m.e_J(), ldc = m.ldc(), row0 = m.neq() + m.nlim();
-    const bool act = gl < m.nefc() && (rJaref < 0 || gl < m.neq()) && rD > 0;
-    ract = act;
-    const float f = act ? -rD * rJaref : 0.0f;
-    if (gl < m.nefc()) { row(0, gl) = act ? rD : 0.0f; row(1, gl) = f; }
+    aact = gl < nA() && (aJaref < 0 || gl < m.neq()) && aD > 0;
+    cact = gl < nB() && cJaref < 0 && cD > 0;
+    const float f = aact ? -aD * aJaref : 0.0f, fc = cact ? -cD * cJaref : 0.0f;
+    if (gl < nA()) { row(0, gl) = aact ? aD : 0.0f; row(1, gl) = f; }
+    if (gl < nB()) { row(0, row0 + gl) = cact ? cD : 0.0f; row(1, row0 + gl) = fc; }
     WSYNC();
     // contact rows: dof lane i gathers over the (pair, slot) memberships of its dof
     if (gl < m.nv()) {
@@ -1372,10 +1382,10 @@ struct Env {
     const int row0 = m.neq() + m.nlim();
     bool scalar_rows = true;  // wave-uniform: some equality / limit row is active
     if (G >= 32) {
-      const unsigned long long act = __ballot(ract);
-      const unsigned long long rows = G == 32 ? ((act | (act >> 32)) & 0xFFFFFFFFull) : act;  // row active in any environment of the wave
-      scalar_rows = (rows & (row0 >= 64 ? ~0ull : (1ull << row0) - 1ull)) != 0ull;
-      build_H_mfma<G>(Mo, Ho, ldm, nv, row0 < 64 ? rows >> row0 : 0ull, m.ncon(), eb + m.e_row() + row0 * ROW_E, Jo, ldc, m.c_slot(), gl);
+      const unsigned long long act = __ballot(cact);
+      const unsigned long long rows = G == 32 ? ((act | (act >> 32)) & 0xFFFFFFFFull) : act;  // contact row active in any environment of the wave
+      scalar_rows = wave_any(aact);
+      build_H_mfma<G>(Mo, Ho, ldm, nv, rows, m.ncon(), eb + m.e_row() + row0 * ROW_E, Jo, ldc, m.c_slot(), gl);
     } else {
       lds_copy<G>(Ho, Mo, nv * ldm, gl);
       WSYNC();
@@ -1417,10 +1427,11 @@ struct Env {
     else spd_solve<G>(m.nchol(), Ho, ldm, nv, dofoff(D_GRAD), dofoff(D_MGRAD), gl, gb4);
   }
 
-  DEV LSPoint ls_point(float alpha, bool valid, bool iseq, float g0, float g1, float g2) const {
-    const float x = rJaref + alpha * rJv;
-    const bool act = valid && (x < 0 || iseq);
-    float q0 = act ? 0.5f * rJaref * rJaref * rD : 0.0f, q1 = act ? rJv * rJaref * rD : 0.0f, q2 = act ? 0.5f * rJv * rJv * rD : 0.0f;
+  DEV LSPoint ls_point(float alpha, bool validA, bool validB, bool iseq, float g0, float g1, float g2) const {
+    const bool actA = validA && (aJaref + alpha * aJv < 0 || iseq), actB = validB && (cJaref + alpha * cJv < 0);
+    float q0 = (actA ? 0.5f * aJaref * aJaref * aD : 0.0f) + (actB ? 0.5f * cJaref * cJaref * cD : 0.0f);
+    float q1 = (actA ? aJv * aJaref * aD : 0.0f) + (actB ? cJv * cJaref * cD : 0.0f);
+    float q2 = (actA ? 0.5f * aJv * aJv * aD : 0.0f) + (actB ? 0.5f * cJv * cJv * cD : 0.0f);
     q0 = gsum<G>(q0) + g0; q1 = gsum<G>(q1) + g1; q2 = gsum<G>(q2) + g2;
     LSPoint r;
     r.alpha = alpha;
@@ -1434,7 +1445,8 @@ struct Env {
   DEV void linesearch(float gauss, bool alive) {
     const int nv = m.nv();
     const float mv = mul_M_row(D_SEARCH);
-    rJv = row_dot(D_SEARCH);
+    aJv = row_dot_A(D_SEARCH);
+    cJv = row_dot_B(D_SEARCH);
     float sn = 0, g1 = 0, g2 = 0;
     if (gl < nv) {
       const float si = dof(D_SEARCH, gl);
@@ -1445,8 +1457,8 @@ struct Env {
     sn = gsum<G>(sn); g1 = gsum<G>(g1); g2 = gsum<G>(g2);
     PROF(21);
     const float gtol = m.tolerance() * m.ls_tolerance() * sqrtf(sn) * m.scale();
-    const bool valid = gl < m.nefc(), iseq = gl < m.neq();
-#define POINT(al) ls_point((al), valid, iseq, gauss, g1, g2)
+    const bool validA = gl < nA(), validB = gl < nB(), iseq = gl < m.neq();
+#define POINT(al) ls_point((al), validA, validB, iseq, gauss, g1, g2)
 #define PICK(c, a, b) { (c) ? (a).alpha : (b).alpha, (c) ? (a).cost : (b).cost, (c) ? (a).d0 : (b).d0, (c) ? (a).d1 : (b).d1 }
     const LSPoint p0 = POINT(0.0f);
     const LSPoint p1 = POINT(p0.alpha - p0.d0 / p0.d1);
@@ -1482,7 +1494,8 @@ struct Env {
     const float alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
     if (improved) {
       if (gl < nv) { dof(D_QACC, gl) += alpha * dof(D_SEARCH, gl); dof(D_MA, gl) += alpha * mv; }
-      rJaref += alpha * rJv;
+      aJaref += alpha * aJv;
+      cJaref += alpha * cJv;
     }
     WSYNC();
   }
@@ -1491,13 +1504,14 @@ struct Env {
     const int nv = m.nv();
     float gauss, cost, prev_cost;
     bool use_warm = false;
-    float ma_warm = 0, ja_warm = 0;
+    float ma_warm = 0, ja_warm = 0, jc_warm = 0;
     if (!(m.disableflags() & DIS_WARMSTART)) {
       float gw, gs;
       init_context(D_WARM);
       const float cw = constraint_cost(D_WARM, &gw);
       ma_warm = gl < nv ? dof(D_MA, gl) : 0.0f;
-      ja_warm = rJaref;
+      ja_warm = aJaref;
+      jc_warm = cJaref;
       WSYNC();
       init_context(D_ASMOOTH);
       const float cs = constraint_cost(D_ASMOOTH, &gs);
@@ -1509,7 +1523,7 @@ struct Env {
       dof(D_QACC, gl) = use_warm ? dof(D_WARM, gl) : dof(D_ASMOOTH, gl);
       if (use_warm) dof(D_MA, gl) = ma_warm;  // context of the chosen start: M*qacc and J*qacc - aref
     }
-    if (use_warm) rJaref = ja_warm;
+    if (use_warm) { aJaref = ja_warm; cJaref = jc_warm; }
     WSYNC();
     if (m.disableflags() & DIS_WARMSTART) {
       init_context(D_QACC);
@@ -1780,7 +1794,9 @@ amx_forward_kernel(const DevModel m_in, int nenv, const float *__restrict__ qpos
   }
   WSYNC();
   env.forward();
-  const int nactive = __popcll(__ballot(gl < m.nefc() && env.rD > 0) >> (lane & ~(G - 1)) & (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1)));
+  const unsigned long long gmask = G == 64 ? ~0ull : ((1ull << (G & 63)) - 1);
+  const int nactive = __popcll((__ballot(gl < env.nA() && env.aD > 0) >> (lane & ~(G - 1))) & gmask) +
+                      __popcll((__ballot(gl < env.nB() && env.cD > 0) >> (lane & ~(G - 1))) & gmask);
   if (!live) return;
   if (gl < nv) {
     if (o.qacc) o.qacc[(size_t)e * nv + gl] = env.dof(Env<G, S>::D_QACC, gl);

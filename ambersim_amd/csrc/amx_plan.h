@@ -1,0 +1,409 @@
+// amx_plan.h - host-only planner of the engine: amx_model_desc -> constant image + launch plan (DevModel).
+// No HIP in here.  Included by amx_api.cpp (the product library) and built on its own as libamx_plan.so (Makefile), which
+// tools/gen_specs.py loads to write amx_specs_gen.h - so the specialisation header can be regenerated before the kernels
+// that include it are compiled.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/amx.h"
+#include "amx_dev.h"
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+namespace {
+// Builder of the constant image: floats, with ints stored bit-cast.
+struct Image {
+  std::vector<float> v;
+  int size() const { return (int)v.size(); }
+  void f(double x) { v.push_back((float)x); }
+  void i(int x) { float t; memcpy(&t, &x, 4); v.push_back(t); }
+  int reserve(int n) { int o = size(); v.resize(v.size() + (n > 0 ? n : 1), 0.f); return o; }
+  void seti(int off, int x) { memcpy(&v[off], &x, 4); }
+  int geti(int off) const { int x; memcpy(&x, &v[off], 4); return x; }
+  void setf(int off, double x) { v[off] = (float)x; }
+};
+const int PAIR_NCON[6] = {1, 2, 4, 1, 1, 1};
+
+// {k, b, dmin, dmax, width, mid, power, ca, cb}: the position-independent part of MuJoCo's solref/solimp
+// mapping (reference physics: constraint._kbi), evaluated once on the host in double precision.
+void write_kbi(Image &im, int off, const double *solref, const double *solimp, double dt, bool refsafe) {
+  const double MINIMP = 0.0001, MAXIMP = 0.9999, MINV = 1e-15;
+  double timeconst = solref[0], dampratio = solref[1];
+  if (refsafe) timeconst = std::max(timeconst, 2 * dt);
+  auto clip = [](double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); };
+  double dmin = clip(solimp[0], MINIMP, MAXIMP), dmax = clip(solimp[1], MINIMP, MAXIMP);
+  double width = std::max(MINV, solimp[2]), mid = clip(solimp[3], MINIMP, MAXIMP), power = std::max(1.0, solimp[4]);
+  double k = 1.0 / (dmax * dmax * timeconst * timeconst * dampratio * dampratio), b = 2.0 / (dmax * timeconst);
+  if (solref[0] <= 0) k = -solref[0] / (dmax * dmax);
+  if (solref[1] <= 0) b = -solref[1] / dmax;
+  im.setf(off, k); im.setf(off + 1, b); im.setf(off + 2, dmin); im.setf(off + 3, dmax); im.setf(off + 4, width);
+  im.setf(off + 5, mid); im.setf(off + 6, power);
+  im.setf(off + 7, 1.0 / pow(mid, power - 1)); im.setf(off + 8, 1.0 / pow(1 - mid, power - 1));
+}
+}  // namespace
+
+
+// True when J' D J has the sparsity of the dof tree: every contact pair's dof list and every two-joint equality couple dofs
+// that lie on ONE ancestor chain (plane - body contacts do; contacts between two branches and mimic joints across fingers do
+// not).  Then H = M + J'DJ is eliminated leaves-first without fill-in, like M (static sparse Gauss-Jordan of a spec).
+static bool plan_tree_H(const amx_model_desc *d, const DevModel &m, const Image &im) {
+  auto is_anc = [&](int a, int i) { for (int k = i; k >= 0; k = d->dof_parentid[k]) if (k == a) return true; return false; };
+  for (int p = 0; p < m.npair; p++) {
+    const int o = m.c_pair + p * PAIR_S, d0 = im.geti(o + 9), dn = im.geti(o + 10);
+    for (int a = 0; a < dn; a++)
+      for (int b = 0; b < a; b++) {
+        const int i = im.geti(m.c_pairdof + d0 + a) & 255, j = im.geti(m.c_pairdof + d0 + b) & 255;
+        if (!is_anc(j, i) && !is_anc(i, j)) return false;
+      }
+  }
+  for (int r = 0; r < m.neq; r++) {
+    const int o = m.c_eq + r * EQ_S, d1 = im.geti(o + 1), d2 = im.geti(o + 3);
+    if (d2 >= 0 && !is_anc(d1, d2) && !is_anc(d2, d1)) return false;
+  }
+  return true;
+}
+
+// Host-only part of amx_model_create: validates the descriptor and builds the constant image and the launch plan.
+// No HIP call in here (tools/gen_specs.py runs it without a GPU through amx_model_plan_describe).
+static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
+  if (!d) return fail(AMX_EINVAL, "null argument");
+  if (d->version != AMX_VERSION) return fail(AMX_EINVAL, "amx_model_desc version %d, library %d", d->version, AMX_VERSION);
+  if (d->nbody < 1 || d->nq < 0 || d->nv < 0) return fail(AMX_EINVAL, "bad sizes");
+  if (d->integrator != 0) return fail(AMX_EUNSUPPORTED, "only the Euler integrator is supported (integrator=%d)", d->integrator);
+  if (d->solver != 1 && d->solver != 2) return fail(AMX_EUNSUPPORTED, "solver must be CG (1) or Newton (2), got %d", d->solver);
+  if (d->nv < 1) return fail(AMX_EUNSUPPORTED, "model has no degrees of freedom");
+  if (d->nv > AMX_MAX_NV) return fail(AMX_ECAPACITY, "nv=%d exceeds the register-row factorisation capacity %d", d->nv, AMX_MAX_NV);
+  const int nb = d->nbody, nv = d->nv, nq = d->nq, nu = d->nu, nj = d->njnt, np = d->npair;
+  if (nb > AMX_WAVE || nj > AMX_WAVE || np > AMX_WAVE)
+    return fail(AMX_ECAPACITY, "lane-role capacity: nbody=%d njnt=%d npair=%d must each be <= %d", nb, nj, np, AMX_WAVE);
+
+  // ---- the descriptor comes across a public ABI: every index is range-checked before it is used as one
+  {
+    auto bad = [&](const char *field, int idx, int val, int lo, int hi) {
+      return fail(AMX_EINVAL, "amx_model_desc: %s[%d] = %d outside [%d, %d)", field, idx, val, lo, hi);
+    };
+#define AMX_CHK(field, idx, lo, hi) do { const int v_ = d->field[idx]; if (v_ < (lo) || v_ >= (hi)) return bad(#field, idx, v_, lo, hi); } while (0)
+    if (d->nu < 0 || d->njnt < 0 || d->ngeom < 0 || d->neq < 0 || d->npair < 0 || d->nconvexvert < 0) return fail(AMX_EINVAL, "negative size in amx_model_desc");
+    for (int b = 0; b < nb; b++) {
+      if (b > 0) AMX_CHK(body_parentid, b, 0, b);
+      if (d->body_jntnum[b] < 0 || d->body_dofnum[b] < 0) return fail(AMX_EINVAL, "body %d: negative joint/dof count", b);
+      if (d->body_jntnum[b] > 0 && (d->body_jntadr[b] < 0 || d->body_jntadr[b] + d->body_jntnum[b] > nj)) return bad("body_jntadr", b, d->body_jntadr[b], 0, nj);
+      if (d->body_dofnum[b] > 0 && (d->body_dofadr[b] < 0 || d->body_dofadr[b] + d->body_dofnum[b] > nv)) return bad("body_dofadr", b, d->body_dofadr[b], 0, nv);
+    }
+    static const int QW[4] = {7, 4, 1, 1}, DW[4] = {6, 3, 1, 1};
+    for (int j = 0; j < nj; j++) {
+      AMX_CHK(jnt_type, j, 0, 4);
+      AMX_CHK(jnt_bodyid, j, 1, nb);
+      const int t = d->jnt_type[j];
+      if (d->jnt_qposadr[j] < 0 || d->jnt_qposadr[j] + QW[t] > nq) return bad("jnt_qposadr", j, d->jnt_qposadr[j], 0, nq - QW[t] + 1);
+      if (d->jnt_dofadr[j] < 0 || d->jnt_dofadr[j] + DW[t] > nv) return bad("jnt_dofadr", j, d->jnt_dofadr[j], 0, nv - DW[t] + 1);
+    }
+    for (int i = 0; i < nv; i++) {
+      AMX_CHK(dof_bodyid, i, 1, nb);
+      AMX_CHK(dof_jntid, i, 0, nj);
+      AMX_CHK(dof_parentid, i, -1, i);
+      const int j = d->dof_jntid[i];
+      if (i < d->jnt_dofadr[j] || i >= d->jnt_dofadr[j] + DW[d->jnt_type[j]]) return fail(AMX_EINVAL, "dof %d does not belong to its joint %d", i, j);
+    }
+    for (int g = 0; g < d->ngeom; g++) AMX_CHK(geom_bodyid, g, 0, nb);
+    for (int p = 0; p < np; p++) {
+      AMX_CHK(pair_geom1, p, 0, d->ngeom);
+      AMX_CHK(pair_geom2, p, 0, d->ngeom);
+    }
+    for (int e = 0; e < d->neq; e++) {
+      AMX_CHK(eq_obj1id, e, 0, nj);
+      AMX_CHK(eq_obj2id, e, -1, nj);
+    }
+#undef AMX_CHK
+  }
+
+  memset(&m, 0, sizeof(m));
+  m.nq = nq; m.nv = nv; m.nu = nu; m.nb = nb; m.njnt = nj; m.npair = np;
+  m.iterations = d->iterations; m.ls_iterations = d->ls_iterations; m.solver = d->solver; m.disableflags = d->disableflags;
+  m.dt = (float)d->timestep; m.gx = (float)d->gravity[0]; m.gy = (float)d->gravity[1]; m.gz = (float)d->gravity[2];
+  m.tolerance = (float)d->tolerance; m.ls_tolerance = (float)d->ls_tolerance; m.impratio = (float)d->impratio;
+  m.scale = (float)(d->meaninertia * (nv > 1 ? nv : 1));
+  m.nchol = nv;
+  const bool refsafe = !(d->disableflags & 2048);
+
+  // ---- tree structure
+  std::vector<int> depth(nb, 0), root_slot(nb, 0), roots;
+  for (int b = 1; b < nb; b++) {
+    int p = d->body_parentid[b];
+    if (p < 0 || p >= b) return fail(AMX_EINVAL, "body %d: parent %d must precede it", b, p);
+    depth[b] = depth[p] + 1;
+    if (p == 0) { root_slot[b] = (int)roots.size(); roots.push_back(b); }
+    else root_slot[b] = root_slot[p];
+  }
+  m.nlevel = *std::max_element(depth.begin(), depth.end()) + 1;
+  m.nroot = (int)roots.size();
+  std::vector<int> child_adr(nb, 0), child_num(nb, 0), child_list;
+  for (int b = 1; b < nb; b++) {
+    child_adr[b] = (int)child_list.size();
+    for (int c = b + 1; c < nb; c++) if (d->body_parentid[c] == b) child_list.push_back(c);
+    child_num[b] = (int)child_list.size() - child_adr[b];
+  }
+
+  // bodies
+  m.c_body = im.reserve(nb * BODY_S);
+  for (int b = 0; b < nb; b++) {
+    int o = m.c_body + b * BODY_S;
+    im.seti(o, d->body_parentid[b]); im.seti(o + 1, depth[b]); im.seti(o + 2, root_slot[b]);
+    im.seti(o + 3, d->body_jntadr[b] < 0 ? 0 : d->body_jntadr[b]); im.seti(o + 4, d->body_jntnum[b]);
+    im.seti(o + 5, child_adr[b]); im.seti(o + 6, child_num[b]);
+    for (int k = 0; k < 3; k++) { im.setf(o + 7 + k, d->body_pos[3 * b + k]); im.setf(o + 14 + k, d->body_ipos[3 * b + k]); im.setf(o + 22 + k, d->body_inertia[3 * b + k]); }
+    for (int k = 0; k < 4; k++) { im.setf(o + 10 + k, d->body_quat[4 * b + k]); im.setf(o + 17 + k, d->body_iquat[4 * b + k]); }
+    im.setf(o + 21, d->body_mass[b]);
+  }
+  // joints
+  m.c_jnt = im.reserve(nj * JNT_S);
+  for (int j = 0; j < nj; j++) {
+    int o = m.c_jnt + j * JNT_S, t = d->jnt_type[j], qa = d->jnt_qposadr[j];
+    if (t <= 1 && d->jnt_stiffness[j] != 0) return fail(AMX_EUNSUPPORTED, "spring on free/ball joint %d", j);
+    if (t <= 1 && d->jnt_limited[j]) return fail(AMX_EUNSUPPORTED, "limits on free/ball joint %d", j);
+    im.seti(o, t); im.seti(o + 1, qa); im.seti(o + 2, d->jnt_dofadr[j]); im.seti(o + 3, d->jnt_bodyid[j]);
+    for (int k = 0; k < 3; k++) { im.setf(o + 4 + k, d->jnt_pos[3 * j + k]); im.setf(o + 7 + k, d->jnt_axis[3 * j + k]); }
+    im.setf(o + 10, d->qpos0[qa]); im.setf(o + 11, d->jnt_stiffness[j]); im.setf(o + 12, d->qpos_spring[qa]);
+  }
+  // actuators (+ per-dof lists)
+  std::vector<int> act_dadr(nu);
+  m.c_act = im.reserve(nu * ACT_S);
+  for (int u = 0; u < nu; u++) {
+    int j = d->actuator_trnid[u], o = m.c_act + u * ACT_S;
+    if (j < 0 || j >= nj || d->jnt_type[j] < 2) return fail(AMX_EUNSUPPORTED, "actuator %d must drive a hinge or slide joint", u);
+    act_dadr[u] = d->jnt_dofadr[j];
+    im.seti(o, d->jnt_qposadr[j]); im.seti(o + 1, act_dadr[u]);
+    im.seti(o + 2, (d->actuator_ctrllimited[u] ? 1 : 0) | (d->actuator_forcelimited[u] ? 2 : 0) | (d->actuator_biastype[u] == 1 ? 4 : 0));
+    im.setf(o + 3, d->actuator_gear[u]); im.setf(o + 4, d->actuator_gainprm[3 * u]);
+    for (int k = 0; k < 3; k++) im.setf(o + 5 + k, d->actuator_biasprm[3 * u + k]);
+    for (int k = 0; k < 2; k++) { im.setf(o + 8 + k, d->actuator_ctrlrange[2 * u + k]); im.setf(o + 10 + k, d->actuator_forcerange[2 * u + k]); }
+  }
+  std::vector<int> dofact_adr(nv), dofact_num(nv), dofact;
+  for (int i = 0; i < nv; i++) {
+    dofact_adr[i] = (int)dofact.size();
+    for (int u = 0; u < nu; u++) if (act_dadr[u] == i) dofact.push_back(u);
+    dofact_num[i] = (int)dofact.size() - dofact_adr[i];
+  }
+  // dofs
+  m.c_dof = im.reserve(nv * DOF_S);
+  for (int i = 0; i < nv; i++) {
+    int o = m.c_dof + i * DOF_S, j = d->dof_jntid[i], k = i - d->jnt_dofadr[j], t = d->jnt_type[j];
+    int kind = t == 0 ? (k < 3 ? 0 : 1) : (t == 1 ? 1 : (t == 3 ? 2 : 3)), axis = t == 0 ? k % 3 : (t == 1 ? k : 0);
+    im.seti(o, d->dof_bodyid[i]); im.seti(o + 1, j); im.seti(o + 2, kind); im.seti(o + 3, axis);
+    im.setf(o + 4, d->dof_armature[i]); im.setf(o + 5, d->dof_damping[i]);
+    im.seti(o + 6, dofact_adr[i]); im.seti(o + 7, dofact_num[i]); im.seti(o + 8, root_slot[d->dof_bodyid[i]]);
+  }
+  // collision geoms (only those that appear in a pair)
+  std::vector<int> gmap(d->ngeom > 0 ? d->ngeom : 1, -1), gc_src;
+  auto use_geom = [&](int g) { if (gmap[g] < 0) { gmap[g] = (int)gc_src.size(); gc_src.push_back(g); } return gmap[g]; };
+  for (int p = 0; p < np; p++) { use_geom(d->pair_geom1[p]); use_geom(d->pair_geom2[p]); }
+  m.ngc = (int)gc_src.size();
+  if (m.ngc > AMX_WAVE) return fail(AMX_ECAPACITY, "%d collision geoms exceed the lane-role capacity %d", m.ngc, AMX_WAVE);
+  m.c_geom = im.reserve(m.ngc * GEOM_S);
+  for (int g = 0; g < m.ngc; g++) {
+    int o = m.c_geom + g * GEOM_S, s = gc_src[g];
+    im.seti(o, d->geom_bodyid[s]); im.seti(o + 1, d->geom_type[s]);
+    for (int k = 0; k < 3; k++) { im.setf(o + 2 + k, d->geom_pos[3 * s + k]); im.setf(o + 9 + k, d->geom_size[3 * s + k]); }
+    for (int k = 0; k < 4; k++) im.setf(o + 5 + k, d->geom_quat[4 * s + k]);
+  }
+  // pairs, contact slots, per-pair dof lists, Jacobian work items, Hessian work items
+  m.c_pair = im.reserve(np * PAIR_S);
+  std::vector<int> con_pair, pairdof, jac_items, hent;
+  std::vector<std::vector<int>> dofmem(nv), hmembers(nv * (nv + 1) / 2);
+  int maxchain = 1;
+  int ncon = 0;
+  for (int p = 0; p < np; p++) {
+    int g1 = d->pair_geom1[p], g2 = d->pair_geom2[p], fn = d->pair_fn[p], o = m.c_pair + p * PAIR_S;
+    if (fn < 0 || fn > 5) return fail(AMX_EUNSUPPORTED, "pair %d: unknown collision function %d", p, fn);
+    if (fn == 2 && (d->pair_vertnum[p] < 1 || d->pair_vertadr[p] < 0 || d->pair_vertadr[p] + d->pair_vertnum[p] > d->nconvexvert))
+      return fail(AMX_EINVAL, "pair %d: bad convex vertex range", p);
+    int b1 = d->geom_bodyid[g1], b2 = d->geom_bodyid[g2];
+    im.seti(o, gmap[g1]); im.seti(o + 1, gmap[g2]); im.seti(o + 2, fn); im.seti(o + 3, ncon); im.seti(o + 4, PAIR_NCON[fn]);
+    im.seti(o + 5, fn == 2 ? d->pair_vertadr[p] : 0); im.seti(o + 6, fn == 2 ? d->pair_vertnum[p] : 0);
+    im.seti(o + 7, root_slot[b1]); im.seti(o + 8, root_slot[b2]);
+    im.setf(o + 11, d->pair_friction[3 * p]);
+    write_kbi(im, o + 12, d->pair_solref + 2 * p, d->pair_solimp + 5 * p, d->timestep, refsafe);
+    im.setf(o + 21, d->pair_margin[p]);
+    im.setf(o + 22, d->body_invweight0[2 * b1] + d->body_invweight0[2 * b2]);
+    // union of the ancestor dof chains of both bodies
+    std::vector<int> sign(nv, 0);
+    for (int side = 0; side < 2; side++) {
+      int b = side == 0 ? b2 : b1;
+      while (b > 0 && d->body_dofnum[b] == 0) b = d->body_parentid[b];
+      if (b == 0) continue;
+      for (int i = d->body_dofadr[b] + d->body_dofnum[b] - 1; i >= 0; i = d->dof_parentid[i]) sign[i] |= (side == 0 ? 1 : 2);
+    }
+    int d0 = (int)pairdof.size();
+    for (int i = 0; i < nv; i++) if (sign[i]) pairdof.push_back(i | (sign[i] << 8));
+    int dn = (int)pairdof.size() - d0;
+    im.seti(o + 9, d0); im.seti(o + 10, dn);
+    if (dn > 16) return fail(AMX_ECAPACITY, "pair %d couples %d dofs (limit 16: the row lanes keep the dof list in registers)", p, dn);
+    maxchain = std::max(maxchain, dn);
+    for (int a = 0; a < dn; a++) {
+      for (int k = 0; k < PAIR_NCON[fn]; k++) dofmem[pairdof[d0 + a] & 255].push_back((4 * (ncon + k)) | (a << 8));
+      for (int b = 0; b <= a; b++) {  // dof list ascending, so (dof_a, dof_b) is a lower-triangle entry of H
+        const int di = pairdof[d0 + a] & 255, dj = pairdof[d0 + b] & 255;
+        for (int k = 0; k < PAIR_NCON[fn]; k++) hmembers[di * (di + 1) / 2 + dj].push_back(di | (dj << 5) | ((4 * (ncon + k)) << 10) | (a << 18) | (b << 23));
+      }
+    }
+    for (int k = 0; k < PAIR_NCON[fn]; k++) {
+      for (int t = 0; t < dn; t++)  // contact | slot<<6 | dof<<11 | chain sign<<16 | pair<<18
+        jac_items.push_back((ncon + k) | (t << 6) | ((pairdof[d0 + t] & 255) << 11) | ((pairdof[d0 + t] >> 8) << 16) | (p << 18));
+      con_pair.push_back(p);
+    }
+    ncon += PAIR_NCON[fn];
+  }
+  for (int t = 0; t < nv * (nv + 1) / 2; t++)
+    for (int w : hmembers[t]) hent.push_back(w);  // one term per (H entry, contact)
+  m.ncon = ncon; m.njac = (int)jac_items.size(); m.nhent = (int)hent.size();
+  if (ncon > 16) return fail(AMX_ECAPACITY, "%d contact slots exceed 16 (4 pyramid rows each, one row per lane of a 64-lane group)", ncon);
+  // plane - convex pairs with at most 32 hull vertices go to the vertex-parallel routine when they form one contiguous run of
+  // pair indices (pairs come grouped by function, so they do unless a larger hull sits among them)
+  {
+    int first = -1, last = -1, cnt = 0;
+    for (int p = 0; p < np; p++)
+      if (d->pair_fn[p] == 2 && d->pair_vertnum[p] <= 32) { if (first < 0) first = p; last = p; cnt++; }
+    if (cnt > 0 && last - first + 1 == cnt) { m.pcx_first = first; m.npcx = cnt; }
+  }
+  // limit rows, equality rows
+  std::vector<int> lim_j;
+  for (int j = 0; j < nj; j++) if (d->jnt_limited[j]) lim_j.push_back(j);
+  m.nlim = (int)lim_j.size();
+  m.c_lim = im.reserve(m.nlim * LIM_S);
+  for (int l = 0; l < m.nlim; l++) {
+    int j = lim_j[l], o = m.c_lim + l * LIM_S;
+    im.seti(o, d->jnt_qposadr[j]); im.seti(o + 1, d->jnt_dofadr[j]);
+    im.setf(o + 2, d->jnt_range[2 * j]); im.setf(o + 3, d->jnt_range[2 * j + 1]); im.setf(o + 4, d->jnt_margin[j]);
+    write_kbi(im, o + 5, d->jnt_solref + 2 * j, d->jnt_solimp + 5 * j, d->timestep, refsafe);
+    im.setf(o + 14, d->dof_invweight0[d->jnt_dofadr[j]]);
+  }
+  std::vector<int> eq_e;
+  for (int e = 0; e < d->neq; e++) if (d->eq_active[e]) eq_e.push_back(e);
+  m.neq = (int)eq_e.size();
+  m.c_eq = im.reserve(m.neq * EQ_S);
+  for (int r = 0; r < m.neq; r++) {
+    int e = eq_e[r], o = m.c_eq + r * EQ_S, j1 = d->eq_obj1id[e], j2 = d->eq_obj2id[e];
+    if (j1 < 0 || j1 >= nj || d->jnt_type[j1] < 2 || (j2 >= 0 && (j2 >= nj || d->jnt_type[j2] < 2)))
+      return fail(AMX_EUNSUPPORTED, "equality %d must couple hinge/slide joints", e);
+    im.seti(o, d->jnt_qposadr[j1]); im.seti(o + 1, d->jnt_dofadr[j1]);
+    im.seti(o + 2, j2 >= 0 ? d->jnt_qposadr[j2] : -1); im.seti(o + 3, j2 >= 0 ? d->jnt_dofadr[j2] : -1);
+    for (int k = 0; k < 5; k++) im.setf(o + 4 + k, d->eq_data[5 * e + k]);
+    write_kbi(im, o + 9, d->eq_solref + 2 * e, d->eq_solimp + 5 * e, d->timestep, refsafe);
+    im.setf(o + 18, d->dof_invweight0[d->jnt_dofadr[j1]] + (j2 >= 0 ? d->dof_invweight0[d->jnt_dofadr[j2]] : 0.0));
+    im.setf(o + 19, d->qpos0[d->jnt_qposadr[j1]]); im.setf(o + 20, j2 >= 0 ? d->qpos0[d->jnt_qposadr[j2]] : 0.0);
+  }
+  const bool con_off = d->disableflags & 1;
+  m.nefc = con_off ? 0 : m.neq + m.nlim + 4 * m.ncon;
+  if (m.neq + m.nlim > AMX_WAVE) return fail(AMX_ECAPACITY, "%d equality + limit rows exceed the lane-role capacity %d", m.neq + m.nlim, AMX_WAVE);
+  // lanes per environment: the smallest group that holds every lane-role index set.  A lane carries two constraint rows:
+  // one equality / limit row and one contact row (amx_kernels.hip, Env), so the rows ask for max(neq + nlim, 4 ncon) lanes.
+  {
+    const int need = std::max({nb, nj, nv, np, m.ngc, con_off ? 0 : m.neq + m.nlim, con_off ? 0 : 4 * m.ncon, 1});
+    m.G = need <= 16 ? 16 : (need <= 32 ? 32 : 64);
+    if (const char *force = getenv("AMX_FORCE_G")) { int g = atoi(force); if ((g == 16 || g == 32 || g == 64) && g >= m.G) m.G = g; }
+  }
+  // lists
+  auto add_ints = [&](const std::vector<int> &v) { int o = im.reserve((int)v.size()); for (size_t k = 0; k < v.size(); k++) im.seti(o + (int)k, v[k]); return o; };
+  m.c_child = add_ints(child_list);
+  std::vector<int> Mlist;
+  for (int i = 0; i < nv; i++) for (int j = i; j >= 0; j = d->dof_parentid[j]) Mlist.push_back(i | (j << 8));
+  m.nM = (int)Mlist.size(); m.c_M = add_ints(Mlist);
+  if (m.G >= 32) { hent.clear(); m.nhent = 0; }  // wide groups build the Hessian on the matrix cores; only 16-lane groups walk the term list
+  m.c_dofact = add_ints(dofact); m.c_pairdof = add_ints(pairdof); m.c_jac = add_ints(jac_items); m.c_hent = add_ints(hent);
+  m.c_conpair = add_ints(con_pair); m.c_rootbody = add_ints(roots);
+  {
+    std::vector<int> slotmap((size_t)32 * std::max(ncon, 1), -1);
+    for (int c = 0; c < ncon; c++) {
+      const int o = m.c_pair + con_pair[c] * PAIR_S, d0 = im.geti(o + 9), dn = im.geti(o + 10);
+      for (int t = 0; t < dn; t++) slotmap[(size_t)32 * c + (pairdof[d0 + t] & 255)] = t;
+    }
+    m.c_slot = add_ints(slotmap);
+  }
+  {
+    std::vector<int> adr(nv + 1, 0), flat;
+    for (int i = 0; i < nv; i++) { adr[i] = (int)flat.size(); flat.insert(flat.end(), dofmem[i].begin(), dofmem[i].end()); }
+    adr[nv] = (int)flat.size();
+    m.c_dofmemadr = add_ints(adr); m.c_dofmem = add_ints(flat);
+  }
+  m.ldc = maxchain | 1;
+  m.ldm = ((nv + 3) / 4) * 4;
+  if ((m.ldm / 4) % 2 == 0) m.ldm += 4;  // rows 16-byte aligned, ldm/4 odd: 8 lanes reading their rows as b128 cover all 32 banks
+  m.c_qpos0 = im.reserve(nq);
+  for (int k = 0; k < nq; k++) im.setf(m.c_qpos0 + k, d->qpos0[k]);
+  m.c_vert = im.reserve(3 * d->nconvexvert);
+  for (int k = 0; k < 3 * d->nconvexvert; k++) im.setf(m.c_vert + k, d->convex_vert[k]);
+  while (im.size() & 3) im.reserve(1);  // environment slabs start 16-byte aligned
+  m.nconst = im.size();
+
+  // ---- environment slab plan (floats)
+  int off = 0;
+  auto take = [&](int n) { int o = off; off += (n > 0 ? n : 1); return o; };
+  m.e_qpos = take(nq); m.e_qvel = take(nv); m.e_ctrl = take(nu);
+  m.e_body = take(BODY_E * nb); m.e_dof = take(DOF_E * nv);
+  m.e_com = take(3 * m.nroot); m.e_actf = take(nu);
+  const int ntri = nv * (nv + 1) / 2;
+  // joint anchors/axes (kinematics -> cdof) are dead before H is first written: they share its space
+  off = (off + 3) & ~3;  // M and H are full symmetric [nv][ldm] with 16-byte aligned rows (row loads and M*v use ds_read_b128)
+  m.e_M = take(nv * m.ldm);
+  m.e_H = take(std::max(std::max(nv * m.ldm, JNT_E * nj), nv + 8)); m.e_jnt = m.e_H; m.e_Lb = d->solver == 1 ? take(ntri) : m.e_H;
+  m.e_row = take(ROW_E * m.nefc);
+  // collision geom poses (com_pos -> collision) are dead before the contact rows are written: they share their space
+  m.e_J = take(std::max(4 * m.ncon * m.ldc, GEO_E * m.ngc)); m.e_geom = m.e_J;
+  m.e_con = take(CON_E * m.ncon); m.e_frame = take(9 * np);
+#ifdef AMX_PROFILE
+  m.e_prof = take(24);
+#endif
+  m.env_floats = (off + 3) & ~3;  // slabs keep 16-byte alignment
+  // waves per workgroup: each workgroup carries one copy of the constants, so pick the size that keeps the most
+  // waves resident per CU (160 KiB of LDS, at most AMX_MIN_WAVES_PER_SIMD*4 waves by registers); ties go to the larger
+  int best_w = 0;  // largest workgroup (in waves) whose LDS fits; each launch picks 1..best_w (choose_wpb)
+  for (int w = 1; w <= AMX_WAVES_PER_BLOCK; w++)
+    if ((m.nconst + w * (AMX_WAVE / m.G) * m.env_floats) * (int)sizeof(float) <= 160 * 1024) best_w = w;
+  if (best_w == 0)
+    return fail(AMX_ECAPACITY, "model needs %d bytes of LDS for one wave (limit 163840)", (m.nconst + (AMX_WAVE / m.G) * m.env_floats) * 4);
+  m.wpb = best_w;
+  const int envs_per_block = m.wpb * (AMX_WAVE / m.G);
+  const int lds_bytes = (m.nconst + envs_per_block * m.env_floats) * (int)sizeof(float);
+  if (lds_bytes > 160 * 1024)
+    return fail(AMX_ECAPACITY, "model needs %d bytes of LDS per workgroup (%d constants + %d x %d per environment; limit 163840)",
+                lds_bytes, m.nconst * 4, envs_per_block, m.env_floats * 4);
+
+  return AMX_OK;
+}
+
+// Tooling (not part of include/amx.h): the launch plan of a descriptor as "name=value" lines - every AMX_MODEL_INTS
+// field, then the dof tree (dof_parent) and whether each contact / equality row couples dofs of one ancestor chain only.
+// tools/gen_specs.py writes amx_specs_gen.h from this; tests/test_abi.py checks the committed header is current.
+extern "C" int amx_model_plan_describe(const amx_model_desc *d, char *out, size_t cap) {
+  if (!d || !out || cap == 0) return fail(AMX_EINVAL, "null argument");
+  DevModel m;
+  Image im;
+  if (int rc = plan_model(d, m, im)) return rc;
+  std::string t;
+  char line[128];
+#define X(f) snprintf(line, sizeof(line), #f "=%d\n", m.f); t += line;
+  AMX_MODEL_INTS(X)
+#undef X
+  t += "dof_parent=";
+  for (int i = 0; i < m.nv; i++) { snprintf(line, sizeof(line), "%d%s", d->dof_parentid[i], i + 1 < m.nv ? "," : ""); t += line; }
+  t += "\n";
+  snprintf(line, sizeof(line), "tree_H=%d\n", plan_tree_H(d, m, im) ? 1 : 0);
+  t += line;
+  if (t.size() + 1 > cap) return fail(AMX_EINVAL, "amx_model_plan_describe: buffer of %zu bytes, %zu needed", cap, t.size() + 1);
+  memcpy(out, t.c_str(), t.size() + 1);
+  return AMX_OK;
+}
+

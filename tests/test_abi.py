@@ -115,3 +115,11 @@ def test_generated_c_descriptor_is_current(tmp_path):
                    capture_output=True, cwd=root)
     strip = lambda s: "\n".join(l for l in s.splitlines() if not l.startswith("/* Generated"))
     assert strip(out.read_text()) == strip(open(os.path.join(root, "examples", "c_host", "pendulum_desc.h")).read())
+
+
+def test_generated_spec_header_is_current():
+    """ambersim_amd/csrc/amx_specs_gen.h (compile-time records of the shipped models' launch plans) is what tools/gen_specs.py
+    writes from the planner in this tree; the kernels specialised on it would otherwise not match their models."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert subprocess.run([sys.executable, os.path.join(root, "tools", "gen_specs.py"), "--check"], cwd=root).returncode == 0

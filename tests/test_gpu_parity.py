@@ -53,7 +53,7 @@ def test_native_library_is_loaded(cases):
     maps = open("/proc/self/maps").read()
     assert "ambersim_amd/csrc/libamx.so" in maps
     assert cases["pendulum"][1]._h.query("lanes_per_env") == 16 and cases["quadruped"][1]._h.query("lanes_per_env") == 32
-    assert cases["biped"][1]._h.query("lanes_per_env") == 64
+    assert cases["biped"][1]._h.query("lanes_per_env") == 32  # 24 limit rows and 32 contact rows: two row slots per lane
 
 
 def test_pendulum_c1_closed_form(cases, golden):
