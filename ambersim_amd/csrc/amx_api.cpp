@@ -154,21 +154,26 @@ extern "C" int amx_model_query(const amx_model *m, const char *name, int *out) {
   return AMX_OK;
 }
 
-// Waves per workgroup for this launch.  Every workgroup carries one copy of the constants, so fewer, larger
-// workgroups keep more environments resident per CU; but a batch that does not fill a whole number of residency
-// rounds leaves the last round partly empty.  Pick the size with the best fill of its rounds, then the most resident waves.
+// Waves per workgroup for this launch.  Every workgroup carries one copy of the constants, so fewer, larger workgroups keep
+// more environments resident per CU; a batch that does not fill a whole number of residency rounds leaves the last round
+// partly empty; and a small batch runs faster spread thinly over all CUs than packed onto a few (a wave-step is latency
+// bound, but co-resident waves still share the SIMD's issue slots: 8 waves per CU cost 1.26x the step time of 2, measured on
+// the 1024-rollout gradient launch).  Cost model: sum over residency rounds of 1 + 0.05 * (waves per CU in that round);
+// ties go to the larger workgroup.
 static int choose_wpb(const amx_model *m, int nenv) {
   if (const char *force = getenv("AMX_FORCE_WPB")) { int w = atoi(force); if (w >= 1 && w <= m->dev.wpb) return w; }
   const int epw = AMX_WAVE / m->dev.G, nwaves = (nenv + epw - 1) / epw, ncu = m->ncu > 0 ? m->ncu : 256;
-  int best = 1; double best_fill = -1; int best_res = 0;
+  int best = 1;
+  double best_cost = 1e30;
   for (int w = 1; w <= m->dev.wpb; w++) {
     const int bytes = (m->dev.nconst + w * epw * m->dev.env_floats) * (int)sizeof(float);
-    const int per_cu = std::min((160 * 1024 / bytes) * w, AMX_MIN_WAVES_PER_SIMD * 4);
-    if (per_cu < w) continue;
-    const long res = (long)(per_cu / w) * w * ncu;
-    const long rounds = (nwaves + res - 1) / res;
-    const double fill = (double)nwaves / (double)(rounds * res);
-    if (fill > best_fill + 1e-9 || (fill > best_fill - 1e-9 && per_cu >= best_res)) { best_fill = fill; best = w; best_res = per_cu; }
+    const int wg_per_cu = std::min(160 * 1024 / bytes, AMX_MIN_WAVES_PER_SIMD * 4 / w);  // LDS and register residency
+    if (wg_per_cu < 1) continue;
+    const long nwg = (nwaves + w - 1) / w, per_round = (long)wg_per_cu * ncu;
+    const long full = nwg / per_round, rest = nwg % per_round;
+    double cost = full * (1.0 + 0.05 * wg_per_cu * w);
+    if (rest) cost += 1.0 + 0.05 * w * (double)((rest + ncu - 1) / ncu);
+    if (cost <= best_cost + 1e-9) { best_cost = cost; best = w; }
   }
   return best;
 }

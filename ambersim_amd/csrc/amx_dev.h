@@ -5,7 +5,7 @@
 
 #define AMX_WAVE 64
 #ifndef AMX_WAVES_PER_BLOCK
-#define AMX_WAVES_PER_BLOCK 4  // wavefronts per workgroup; they share one LDS copy of the model constants
+#define AMX_WAVES_PER_BLOCK 8  // largest workgroup in wavefronts; they share one LDS copy of the model constants
 #endif
 #ifndef AMX_MIN_WAVES_PER_SIMD
 #define AMX_MIN_WAVES_PER_SIMD 2  // launch bound: 256 VGPRs.  4096 envs give at most 2 waves/SIMD at G=32 and LDS allows no more at G=64, and 168/128 spill
@@ -15,10 +15,11 @@
 // Record strides (floats) of the constant image.  All odd, so lane-per-record LDS reads are conflict free.
 // Record strides (floats) of the per-environment slab, also odd.
 enum { BODY_E = 29, JNT_E = 7, DOF_E = 17, ROW_E = 3, CON_E = 5, GEO_E = 13 };
-enum { BODY_S = 25, JNT_S = 13, DOF_S = 9, ACT_S = 13, GEOM_S = 13, PAIR_S = 29, LIM_S = 15, EQ_S = 21 };
+enum { BODY_S = 25, JNT_S = 13, DOF_S = 11, ACT_S = 13, GEOM_S = 13, PAIR_S = 29, LIM_S = 15, EQ_S = 21 };
 // BodyRec: 0 parent 1 level 2 rootslot 3 jntadr 4 jntnum 5 childadr 6 childnum 7-9 pos 10-13 quat 14-16 ipos 17-20 iquat 21 mass 22-24 inertia
 // JntRec : 0 type 1 qadr 2 dadr 3 body 4-6 pos 7-9 axis 10 qpos0 11 stiffness 12 springref
 // DofRec : 0 body 1 jnt 2 kind(0 free-trans,1 free/ball-rot,2 hinge,3 slide) 3 axis 4 armature 5 damping 6 actadr 7 actnum 8 rootslot
+//          9 first dof of the joint 10 lane of the limit row on this dof (-1: none)
 // ActRec : 0 qadr 1 dadr 2 flags(1 ctrllimited,2 forcelimited,4 affine bias) 3 gear 4 gain 5-7 bias 8-9 ctrlrange 10-11 forcerange 12 pad
 // GeomRec: 0 body 1 type 2-4 pos 5-8 quat 9-11 size 12 pad
 // PairRec: 0 g1 1 g2 2 fn 3 conadr 4 ncon 5 vertadr 6 vertnum 7 root1 8 root2 9 dofadr 10 dofnum 11 mu 12 k 13 b 14 dmin 15 dmax
@@ -34,7 +35,9 @@ enum { BODY_S = 25, JNT_S = 13, DOF_S = 9, ACT_S = 13, GEOM_S = 13, PAIR_S = 29,
   X(nconst)                                                                                                                \
   X(nq) X(nv) X(nu) X(nb) X(njnt) X(ngc) X(npair) X(ncon) X(neq) X(nlim) X(nefc) X(nlevel) X(nM) X(nroot)                    \
   X(ldc) /* contact-row stride: longest pair dof list, odd */                                                              \
-  X(ldm) /* row stride of M and H: >= nv, ldm/4 odd */                                                                     \
+  X(ldm) /* row stride of M and H: >= nv, a multiple of 4 */                                                                \
+  X(mrot) /* 1: row i of M stores chunk c at position (c + i) mod ldm/4 (fused path with an even chunk count) */          \
+  X(fusedH) /* 1: Newton eliminates H in registers, no H buffer (G >= 32, no equality rows) */                            \
   X(nchol) X(njac) X(nhent)                                                                                                \
   X(pcx_first) X(npcx) /* run of plane - convex pairs (<= 32 hull vertices) handled one lane per vertex; npcx = 0: none */   \
   X(iterations) X(ls_iterations) X(solver) X(disableflags)                                                                 \
@@ -42,7 +45,7 @@ enum { BODY_S = 25, JNT_S = 13, DOF_S = 9, ACT_S = 13, GEOM_S = 13, PAIR_S = 29,
   X(wpb) /* wavefronts per workgroup (1..AMX_WAVES_PER_BLOCK), chosen to maximise resident waves per CU */                 \
   /* bases inside the constant image (float offsets) */                                                                    \
   X(c_body) X(c_jnt) X(c_dof) X(c_act) X(c_geom) X(c_pair) X(c_lim) X(c_eq)                                                \
-  X(c_qpos0) /* [nq] */ X(c_child) X(c_M) /* packed i|j<<8 */ X(c_dofact) X(c_pairdof) /* packed dof|sign<<8 */            \
+  X(c_qpos0) /* [nq] */ X(c_child) X(c_M) /* packed offset of M[i][j] | offset of M[j][i]<<11 | i<<22 | j<<27 */ X(c_dofact) X(c_pairdof) /* packed dof|sign<<8 */            \
   X(c_jac) /* packed contact|slot<<6|dof<<11|chain sign<<16|pair<<18 */                                                    \
   X(c_hent) /* [nhent] terms: packed dof_i|dof_j<<5|first contact row<<10|slot_i<<18|slot_j<<23 (dof_j <= dof_i) */         \
   X(c_dofmemadr) /* [nv+1] */ X(c_dofmem) /* terms: packed first contact row|slot<<8 */ X(c_conpair) /* [ncon] */           \
@@ -50,10 +53,9 @@ enum { BODY_S = 25, JNT_S = 13, DOF_S = 9, ACT_S = 13, GEOM_S = 13, PAIR_S = 29,
   /* bases inside one environment slab (float offsets from the slab start) */                                              \
   X(e_qpos) X(e_qvel) X(e_ctrl)                                                                                            \
   X(e_body) /* records [nb][BODY_E]: xpos 0-2 xquat 3-6 cinert 7-16 (then cfrc 7-12) crb 17-26 (then cvel 17-22 cacc 23-28) */ \
-  X(e_jnt)  /* records [njnt][JNT_E]: xanchor 0-2 xaxis 3-5 */                                                             \
-  X(e_dof)  /* records [nv][DOF_E]: cdof 0-5 fcrb 6-11 (then Ma grad Mgrad search mv fcon) fsmooth 12 asmooth 13 qacc 14 warm 15 fbias 16 */ \
+  X(e_dof)  /* records [nv][DOF_E]: cdof 0-5 | joint anchor+axis 6-11 in the joint's first dof, then fcrb, then Ma grad Mgrad search mv fcon | fsmooth 12 asmooth 13 qacc 14 warm 15 fbias 16 */ \
   X(e_com) X(e_actf)                                                                                                       \
-  X(e_M) X(e_H) /* full symmetric [nv][ldm], 16-byte aligned rows */                                                       \
+  X(e_M) /* full symmetric [nv][ldm], 16-byte aligned rows */ X(e_H) /* the same for H when it is stored; else the M*v staging vector */                                                       \
   X(e_Lb) /* packed lower-triangular Cholesky factor, only allocated for the CG solver */                                  \
   X(e_row) /* records [nefc][ROW_E]: Dact 0 frow 1 */                                                                      \
   X(e_J) /* contact rows only, chain-compressed: [4*ncon][ldc] */                                                          \

@@ -306,24 +306,13 @@ typedef float v32f __attribute__((ext_vector_type(32)));
 //   crows: active contact rows (bit 4c+r), OR-ed over the environments of the wave; an inactive row has D = 0 anyway,
 //          the mask only skips contacts that are inactive everywhere.
 typedef float v16f __attribute__((ext_vector_type(16)));
+// The matrix-core part: on return lane (b, j) holds row j of its environment's J'DJ as sixteen-byte chunks,
+// lo[q][r] = (J'DJ)[j][8q+r], hi[q][r] = (J'DJ)[j][8q+4+r].  crows, ldc, slot_base are wave-uniform scalars.
 template <int G>
-__device__ __noinline__ void build_H_mfma(int M_off, int H_off, int ld_, int n_, unsigned long long crows_, int ncon, int row_base, int J_base, int ldc_,
-                                          int slot_base_, int gl) {
-  // arguments of an out-of-line function arrive in vector registers; these are wave-uniform, and saying so keeps the
-  // loops and the chunk guards below on the scalar unit
-  const int ld = __builtin_amdgcn_readfirstlane(ld_), n = __builtin_amdgcn_readfirstlane(n_), ldc = __builtin_amdgcn_readfirstlane(ldc_);
-  const int slot_base = __builtin_amdgcn_readfirstlane(slot_base_);
-  const unsigned long long crows = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(crows_ >> 32)) << 32) |
-                                   (unsigned)__builtin_amdgcn_readfirstlane((int)crows_);
+DEV void jtdj_rows_mfma(unsigned long long crows, int row_base, int J_base, int ldc, int slot_base, int gl, unsigned (&lo)[4][4], unsigned (&hi)[4][4]) {
   const int j = gl & 31, h = gl >> 5;
   // one bit per contact that is active in some environment of the wave (wave-uniform scalar loop over the set bits)
   unsigned long long cm = (crows | (crows >> 1) | (crows >> 2) | (crows >> 3)) & 0x1111111111111111ull;
-  unsigned lo[4][4], hi[4][4];  // after the swaps: lo[q][r] = H[j][8q+r], hi[q][r] = H[j][8q+4+r] of the lane's environment
-  const bool writer = (G == 32 || gl < 32) && j < n;
-  const int jr = (writer ? j : 0) * ld;
-  const float4 *mrow = reinterpret_cast<const float4 *>(lds + M_off + jr);
-  float4 *hrow = reinterpret_cast<float4 *>(lds + H_off + jr);
-  const int nch = ld >> 2;  // 16-byte chunks per row
   if (G == 32) {
     v32f C = {};
     while (cm != 0ull) {
@@ -378,6 +367,25 @@ __device__ __noinline__ void build_H_mfma(int M_off, int H_off, int ld_, int n_,
         lo[q][r] = sw[0]; hi[q][r] = sw[1];
       }
   }
+}
+
+template <int G>
+__device__ __noinline__ void build_H_mfma(int M_off, int H_off, int ld_, int n_, unsigned long long crows_, int ncon, int row_base, int J_base, int ldc_,
+                                          int slot_base_, int gl) {
+  // arguments of an out-of-line function arrive in vector registers; these are wave-uniform, and saying so keeps the
+  // loops and the chunk guards below on the scalar unit
+  const int ld = __builtin_amdgcn_readfirstlane(ld_), n = __builtin_amdgcn_readfirstlane(n_), ldc = __builtin_amdgcn_readfirstlane(ldc_);
+  const int slot_base = __builtin_amdgcn_readfirstlane(slot_base_);
+  const unsigned long long crows = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(crows_ >> 32)) << 32) |
+                                   (unsigned)__builtin_amdgcn_readfirstlane((int)crows_);
+  const int j = gl & 31;
+  unsigned lo[4][4], hi[4][4];  // after the swaps: lo[q][r] = H[j][8q+r], hi[q][r] = H[j][8q+4+r] of the lane's environment
+  const bool writer = (G == 32 || gl < 32) && j < n;
+  const int jr = (writer ? j : 0) * ld;
+  const float4 *mrow = reinterpret_cast<const float4 *>(lds + M_off + jr);
+  float4 *hrow = reinterpret_cast<float4 *>(lds + H_off + jr);
+  const int nch = ld >> 2;  // 16-byte chunks per row
+  jtdj_rows_mfma<G>(crows, row_base, J_base, ldc, slot_base, gl, lo, hi);
   // H row = M row + J'DJ row, two halves of four chunks: the four loads of a half are in flight together
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
@@ -398,15 +406,18 @@ __device__ __noinline__ void build_H_mfma(int M_off, int H_off, int ld_, int n_,
 }
 
 template <int N, int G>
-__device__ __noinline__ void spd_solve_rows(int A_off, int ld, int n, int rhs_off, int x_off, int vstride, int gl, int gb4) {
+__device__ __noinline__ void spd_solve_rows(int A_off, int ld, int n, int rhs_off, int x_off, int vstride, int gl, int gb4, int rot) {
   float a[N];
-  const int li = gl < n ? gl : 0;
-  // row li of the full symmetric matrix: 16-byte aligned, ld >= ceil4(n) floats long, so whole b128 chunks are in bounds
+  const int li = gl < n ? gl : 0, nch = ld >> 2;
+  // row li of the full symmetric matrix: 16-byte aligned, ld >= ceil4(n) floats long, so whole b128 chunks are in bounds;
+  // chunk c sits at position (c + rot) mod nch (rot = 0 unless the rows are stored rotated)
   const float4 *rowp = reinterpret_cast<const float4 *>(lds + A_off + li * ld);
 #pragma unroll
   for (int c = 0; c < (N + 3) / 4; ++c) {
     float4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (4 * c < ld) v = rowp[4 * c < ld ? c : 0];
+    int pc = c + rot;
+    pc -= pc >= nch ? nch : 0;
+    if (4 * c < ld) v = rowp[4 * c < ld ? pc : 0];
     const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -453,14 +464,16 @@ template <class S, int G, int J> struct GJTree {
 template <class S, int G> struct GJTree<S, G, -1> { static DEV void run(float (&)[S::nv], float &, int) {} };
 
 template <class S, int G, bool TREE>
-__device__ __noinline__ void spd_solve_static(int A_off, int rhs_off, int x_off, int gl) {
-  constexpr int N = S::nv, ld = S::ldm;
+__device__ __noinline__ void spd_solve_static(int A_off, int rhs_off, int x_off, int gl, int rot) {
+  constexpr int N = S::nv, ld = S::ldm, nch = ld / 4;
   float a[N];
   const int li = gl < N ? gl : 0;
   const float4 *rowp = reinterpret_cast<const float4 *>(lds + A_off + li * ld);
 #pragma unroll
   for (int c = 0; c < (N + 3) / 4; ++c) {
-    const float4 v = rowp[c];
+    int pc = c + (S::mrot ? rot : 0);  // chunk c of the row sits at position (c + rot) mod nch
+    pc -= pc >= nch ? nch : 0;
+    const float4 v = rowp[pc];
     const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -479,13 +492,64 @@ __device__ __noinline__ void spd_solve_static(int A_off, int rhs_off, int x_off,
   WSYNC();
 }
 
+// Newton direction without an H buffer (planner: fusedH - 32- and 64-lane groups, no equality rows): the matrix cores' J'DJ rows
+// arrive in registers (jtdj_rows_mfma), the lane adds its row of M (stored chunk-rotated when MV::mrot) and the diagonal
+// term of the limit row on its dof (dlim, fetched by the caller through the crossbar), and the elimination starts from
+// those registers: H never touches LDS.  S static: N = nv, tree-sparse elimination when TREE; S = DynSpec: N is the padded size.
+template <class S, int N, int G, bool TREE>
+__device__ __noinline__ void newton_solve_fused(int M_off, int ld_, int n_, unsigned long long crows_, int row_base, int J_base, int ldc_, int slot_base_,
+                                                int rhs_off, int x_off, float dlim, int gl, int gb4, int rot) {
+  const int ld = S::is_static ? S::ldm : __builtin_amdgcn_readfirstlane(ld_), n = S::is_static ? S::nv : __builtin_amdgcn_readfirstlane(n_);
+  const int ldc = S::is_static ? S::ldc : __builtin_amdgcn_readfirstlane(ldc_), slot_base = S::is_static ? S::c_slot : __builtin_amdgcn_readfirstlane(slot_base_);
+  const unsigned long long crows = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(crows_ >> 32)) << 32) |
+                                   (unsigned)__builtin_amdgcn_readfirstlane((int)crows_);
+  unsigned lo[4][4], hi[4][4];
+  jtdj_rows_mfma<G>(crows, row_base, J_base, ldc, slot_base, gl, lo, hi);
+  const bool owner = gl < n;  // row gl of the lane's environment (64-lane groups: lanes 32..63 own padding rows)
+  const int li = owner ? gl : 0, nch = ld >> 2;
+  const float4 *rowp = reinterpret_cast<const float4 *>(lds + M_off + li * ld);
+  float a[N];
+#pragma unroll
+  for (int c = 0; c < (N + 3) / 4; ++c) {
+    float4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    int pc = c + rot;
+    pc -= pc >= nch ? nch : 0;
+    if (4 * c < ld) v = rowp[4 * c < ld ? pc : 0];
+    const unsigned *src = (c & 1) ? hi[c >> 1] : lo[c >> 1];
+    const float e[4] = {v.x + __uint_as_float(src[0]), v.y + __uint_as_float(src[1]), v.z + __uint_as_float(src[2]), v.w + __uint_as_float(src[3])};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = 4 * c + q;
+      if (k < N) a[k] = (owner && k < n) ? e[q] + (k == gl ? dlim : 0.0f) : (k == gl ? 1.0f : 0.0f);
+    }
+  }
+  float b = lds[rhs_off + li * DOF_E];
+  b = owner ? b : 0.0f;
+  if constexpr (S::is_static && TREE) GJTree<S, G, N - 1>::run(a, b, gl);
+  else GJ<N, G, 0>::run(a, b, gl, gb4);
+  float d = 1.0f;
+#pragma unroll
+  for (int k = 0; k < N; ++k) d = (k == gl) ? a[k] : d;
+  if (owner) lds[x_off + gl * DOF_E] = b / d;
+  WSYNC();
+}
 template <int G>
-__device__ __noinline__ void spd_solve(int nchol, int A_off, int ld, int n, int rhs_off, int x_off, int gl, int gb4) {
+__device__ __noinline__ void newton_fused_dyn(int nchol, int M_off, int ld, int n, unsigned long long crows, int row_base, int J_base, int ldc, int slot_base,
+                                              int rhs_off, int x_off, float dlim, int gl, int gb4, int rot) {
+#define AMX_NF_CASE(NN) else if (nchol <= NN) newton_solve_fused<DynSpec, NN, G, false>(M_off, ld, n, crows, row_base, J_base, ldc, slot_base, rhs_off, x_off, dlim, gl, gb4, rot);
+  if (nchol <= 4) newton_solve_fused<DynSpec, 4, G, false>(M_off, ld, n, crows, row_base, J_base, ldc, slot_base, rhs_off, x_off, dlim, gl, gb4, rot);
+  AMX_NF_CASE(6) AMX_NF_CASE(8) AMX_NF_CASE(10) AMX_NF_CASE(12) AMX_NF_CASE(14) AMX_NF_CASE(16) AMX_NF_CASE(18)
+  AMX_NF_CASE(20) AMX_NF_CASE(22) AMX_NF_CASE(24) AMX_NF_CASE(26) AMX_NF_CASE(28) AMX_NF_CASE(30) AMX_NF_CASE(32)
+#undef AMX_NF_CASE
+}
+
+template <int G>
+__device__ __noinline__ void spd_solve(int nchol, int A_off, int ld, int n, int rhs_off, int x_off, int gl, int gb4, int rot) {
   const int vstride = DOF_E;
   // one instantiation per even size (a pivot costs a crossbar round trip, so padding rows are not free);
   // a group of G lanes holds at most G rows
-#define AMX_SPD_CASE(NN) else if (nchol <= NN && NN <= G) spd_solve_rows<(NN <= G ? NN : 4), G>(A_off, ld, n, rhs_off, x_off, vstride, gl, gb4);
-  if (nchol <= 4) spd_solve_rows<4, G>(A_off, ld, n, rhs_off, x_off, vstride, gl, gb4);
+#define AMX_SPD_CASE(NN) else if (nchol <= NN && NN <= G) spd_solve_rows<(NN <= G ? NN : 4), G>(A_off, ld, n, rhs_off, x_off, vstride, gl, gb4, rot);
+  if (nchol <= 4) spd_solve_rows<4, G>(A_off, ld, n, rhs_off, x_off, vstride, gl, gb4, rot);
   AMX_SPD_CASE(6) AMX_SPD_CASE(8) AMX_SPD_CASE(10) AMX_SPD_CASE(12) AMX_SPD_CASE(14) AMX_SPD_CASE(16) AMX_SPD_CASE(18)
   AMX_SPD_CASE(20) AMX_SPD_CASE(22) AMX_SPD_CASE(24) AMX_SPD_CASE(26) AMX_SPD_CASE(28) AMX_SPD_CASE(30) AMX_SPD_CASE(32)
 #undef AMX_SPD_CASE
@@ -647,7 +711,8 @@ struct Env {
   const int eb, gl, gb4;  // slab base, lane-in-group, 4 * first lane of the group (crossbar address base)
   // static role constants of this lane
   int b_parent, b_level, b_root, b_jntadr, b_jntnum, b_childadr, b_childnum;  // body `lane`
-  int d_body, d_jnt, d_kind, d_axis, d_root;                                  // dof `lane`
+  int d_body, d_jnt, d_kind, d_axis, d_root, d_jadr, d_limrow;                // dof `lane` (d_jadr: first dof of its joint; d_limrow: lane of its limit row)
+  int m_rot, m_diag;  // row `lane` of M: chunk rotation of the row (0 unless MV::mrot), float offset of its diagonal entry inside M
   // Constraint rows: a lane owns TWO row slots, so that a group of G lanes carries up to 2 G rows -
   //   slot A: equality / limit row `gl` (gl < nA = neq + nlim): one or two Jacobian entries, kept in registers;
   //   slot B: contact pyramid row `gl` (gl < nB = 4 ncon): its Jacobian row lives in LDS, chain-compressed.
@@ -670,7 +735,12 @@ struct Env {
     b_parent = CI(br); b_level = lane < m.nb() ? CI(br + 1) : -1; b_root = CI(br + 2); b_jntadr = CI(br + 3); b_jntnum = CI(br + 4);
     b_childadr = CI(br + 5); b_childnum = CI(br + 6);
     const int dr = m.c_dof() + (lane < m.nv() ? lane : 0) * DOF_S;
-    d_body = CI(dr); d_jnt = CI(dr + 1); d_kind = CI(dr + 2); d_axis = CI(dr + 3); d_root = CI(dr + 8);
+    d_body = CI(dr); d_jnt = CI(dr + 1); d_kind = CI(dr + 2); d_axis = CI(dr + 3); d_root = CI(dr + 8); d_jadr = CI(dr + 9); d_limrow = CI(dr + 10);
+    {
+      const int nch = m.ldm() >> 2, i = lane < m.nv() ? lane : 0;
+      m_rot = m.mrot() ? i % nch : 0;
+      m_diag = moff(i, i);
+    }
     aD = aAref = aJaref = aJv = cD = cAref = cJaref = cJv = rJ1 = rJ2 = 0.0f;
     aact = cact = false;
     rd1 = 0; rd2 = -1;
@@ -697,7 +767,14 @@ struct Env {
   // Records with odd compile-time strides: gl-per-record access is bank-conflict free and every field
   // is an immediate offset from one base address (no per-field address registers).
   DEV float &body(int f, int b) const { return lds[eb + m.e_body() + b * BODY_E + f]; }
-  DEV float &jnt(int f, int j) const { return lds[eb + m.e_jnt() + j * JNT_E + f]; }
+  // joint anchor (0-2) and axis (3-5), world frame: fields 6..11 of the record of the joint's first dof `da` (dead solver vectors
+  // of the previous step; crb*cdof overwrites them once the motion axes are formed)
+  DEV float &jnt(int f, int da) const { return lds[eb + m.e_dof() + da * DOF_E + 6 + f]; }
+  // float offset of M[i][j] inside the matrix block (rows may store their 16-byte chunks rotated, see amx_plan.h)
+  DEV int moff(int i, int j) const {
+    const int nch = m.ldm() >> 2, rot = m.mrot() ? i % nch : 0;
+    return i * m.ldm() + 4 * (((j >> 2) + rot) % nch) + (j & 3);
+  }
   DEV float &dof(int f, int i) const { return lds[eb + m.e_dof() + i * DOF_E + f]; }
   DEV float &row(int f, int r) const { return lds[eb + m.e_row() + r * ROW_E + f]; }
   DEV float &con(int f, int c) const { return lds[eb + m.e_con() + c * CON_E + f]; }
@@ -743,7 +820,7 @@ struct Env {
       f4 quat = {CF(br + 10), CF(br + 11), CF(br + 12), CF(br + 13)};
       for (int k = 0; k < b_jntnum; ++k) {
         const int j = b_jntadr + k, jr = m.c_jnt() + j * JNT_S;
-        const int t_ = CI(jr), qa = eb + m.e_qpos() + CI(jr + 1);
+        const int t_ = CI(jr), qa = eb + m.e_qpos() + CI(jr + 1), jd = CI(jr + 2);
         const f3 jpos = mk3(CF(jr + 4), CF(jr + 5), CF(jr + 6)), jax = mk3(CF(jr + 7), CF(jr + 8), CF(jr + 9));
         f3 anchor, axis;
         if (t_ == JFREE) {
@@ -770,8 +847,8 @@ struct Env {
             pos = pos + axis * (lds[qa] - CF(jr + 10));
           }
         }
-        jnt(0, j) = anchor.x; jnt(1, j) = anchor.y; jnt(2, j) = anchor.z;
-        jnt(3, j) = axis.x; jnt(4, j) = axis.y; jnt(5, j) = axis.z;
+        jnt(0, jd) = anchor.x; jnt(1, jd) = anchor.y; jnt(2, jd) = anchor.z;
+        jnt(3, jd) = axis.x; jnt(4, jd) = axis.y; jnt(5, jd) = axis.z;
       }
       body(0, b) = pos.x; body(1, b) = pos.y; body(2, b) = pos.z;
       body(3, b) = quat.w; body(4, b) = quat.x; body(5, b) = quat.y; body(6, b) = quat.z;
@@ -788,13 +865,14 @@ struct Env {
       WSYNC();
     }
     if (gl < m.njnt()) {
-      const int p = CI(m.c_body() + CI(m.c_jnt() + gl * JNT_S + 3) * BODY_S);  // parent of the joint's body
+      const int jr = m.c_jnt() + gl * JNT_S, jd = CI(jr + 2);
+      const int p = CI(m.c_body() + CI(jr + 3) * BODY_S);  // parent of the joint's body
       if (p > 0) {  // the world's frame is the identity
         const f4 pq = ld_xquat(p);
-        const f3 anchor = ld_xpos(p) + qrot(pq, mk3(jnt(0, gl), jnt(1, gl), jnt(2, gl)));
-        const f3 axis = qrot(pq, mk3(jnt(3, gl), jnt(4, gl), jnt(5, gl)));
-        jnt(0, gl) = anchor.x; jnt(1, gl) = anchor.y; jnt(2, gl) = anchor.z;
-        jnt(3, gl) = axis.x; jnt(4, gl) = axis.y; jnt(5, gl) = axis.z;
+        const f3 anchor = ld_xpos(p) + qrot(pq, mk3(jnt(0, jd), jnt(1, jd), jnt(2, jd)));
+        const f3 axis = qrot(pq, mk3(jnt(3, jd), jnt(4, jd), jnt(5, jd)));
+        jnt(0, jd) = anchor.x; jnt(1, jd) = anchor.y; jnt(2, jd) = anchor.z;
+        jnt(3, jd) = axis.x; jnt(4, jd) = axis.y; jnt(5, jd) = axis.z;
       }
     }
     WSYNC();
@@ -848,7 +926,7 @@ struct Env {
       for (int k = 0; k < 10; ++k) body(F_CINERT + k, b) = r[k];
     }
     if (gl < m.nv()) {
-      const int i = gl, j = d_jnt;
+      const int i = gl, j = d_jadr;
       const f3 off = ld_com(d_root) - mk3(jnt(0, j), jnt(1, j), jnt(2, j));
       f3 w = mk3(0, 0, 0), l = mk3(0, 0, 0);
       if (d_kind == 0) {
@@ -903,16 +981,17 @@ struct Env {
       st_dsv(D_FCRB, gl, inert_mul(I, ld_dsv(D_CDOF, gl)));
     }
     WSYNC();
-    const int Mo = eb + m.e_M(), ldm = m.ldm();
+    const int Mo = eb + m.e_M();
     struct MEnt { int at, at2; float v; };
     item_loop2<G>(m.nM(), gl,
       [&](int e) {
-        const int pk = CI(m.c_M() + e), i = pk & 255, j = pk >> 8;
+        const unsigned pk = (unsigned)CI(m.c_M() + e);  // offsets of M[i][j] and M[j][i] resolved on the host (rows may be chunk-rotated)
+        const int i = (pk >> 22) & 31, j = pk >> 27;
         const sv f = ld_dsv(D_FCRB, i), c = ld_dsv(D_CDOF, j);
         const float arm = CF(m.c_dof() + i * DOF_S + 4);
         float v = (c.v[0] * f.v[0] + c.v[1] * f.v[1]) + (c.v[2] * f.v[2] + c.v[3] * f.v[3]) + (c.v[4] * f.v[4] + c.v[5] * f.v[5]);
         if (i == j) v += arm;
-        return MEnt{Mo + i * ldm + j, Mo + j * ldm + i, v};  // j is an ancestor of i: j <= i; both triangles are stored
+        return MEnt{Mo + (int)(pk & 2047u), Mo + (int)((pk >> 11) & 2047u), v};  // j is an ancestor of i: both triangles are stored
       },
       [&](int, const MEnt &r) { lds[r.at] = r.v; lds[r.at2] = r.v; });
     WSYNC();
@@ -1282,9 +1361,12 @@ struct Env {
     WSYNC();
     const float4 *mr = reinterpret_cast<const float4 *>(lds + eb + m.e_M() + i * ldm), *vv = reinterpret_cast<const float4 *>(lds + Vo);
     float acc0 = 0, acc1 = 0;
+    const int nch = ldm >> 2;
 #pragma unroll 5
-    for (int c = 0; c < (ldm >> 2); ++c) {
-      const float4 a = mr[c], v = vv[c];
+    for (int c = 0; c < nch; ++c) {
+      int pc = c + m_rot;  // chunk c of the row sits at position (c + rot) mod nch; v is staged unrotated: one address per group
+      pc -= pc >= nch ? nch : 0;
+      const float4 a = mr[pc], v = vv[c];
       acc0 = __builtin_fmaf(a.x, v.x, __builtin_fmaf(a.y, v.y, acc0));
       acc1 = __builtin_fmaf(a.z, v.z, __builtin_fmaf(a.w, v.w, acc1));
     }
@@ -1380,6 +1462,23 @@ struct Env {
   DEV void newton_direction() {
     const int nv = m.nv(), Mo = eb + m.e_M(), Ho = eb + m.e_H(), Jo = eb + m.e_J(), ldc = m.ldc(), ldm = m.ldm();
     const int row0 = m.neq() + m.nlim();
+    if constexpr (G >= 32) {
+      if (m.fusedH()) {
+        const unsigned long long act = __ballot(cact);
+        const unsigned long long rows = G == 32 ? ((act | (act >> 32)) & 0xFFFFFFFFull) : act;  // contact row active in any environment of the wave
+        // diagonal term of the limit row on this lane's dof: D of that row if it is active (J = +-1), through the crossbar
+        const float dsrc = aact ? aD : 0.0f;
+        float dlim = __int_as_float(__builtin_amdgcn_ds_bpermute(gb4 + 4 * (d_limrow < 0 ? 0 : d_limrow), __float_as_int(dsrc)));
+        dlim = (gl < nv && d_limrow >= 0 && nA() > 0) ? dlim : 0.0f;
+        PROF(19);
+        if constexpr (S::is_static)
+          newton_solve_fused<S, S::nv, G, S::tree_H>(Mo, ldm, nv, rows, eb + m.e_row() + row0 * ROW_E, Jo, ldc, m.c_slot(), dofoff(D_GRAD), dofoff(D_MGRAD), dlim, gl, gb4, m_rot);
+        else
+          newton_fused_dyn<G>(m.nchol(), Mo, ldm, nv, rows, eb + m.e_row() + row0 * ROW_E, Jo, ldc, m.c_slot(), dofoff(D_GRAD), dofoff(D_MGRAD), dlim, gl, gb4, m_rot);
+        PROF(14);
+        return;
+      }
+    }
     bool scalar_rows = true;  // wave-uniform: some equality / limit row is active
     if (G >= 32) {
       const unsigned long long act = __ballot(cact);
@@ -1423,8 +1522,8 @@ struct Env {
       WSYNC();
     }
     PROF(14);
-    if constexpr (S::is_static) spd_solve_static<S, G, S::tree_H>(Ho, dofoff(D_GRAD), dofoff(D_MGRAD), gl);
-    else spd_solve<G>(m.nchol(), Ho, ldm, nv, dofoff(D_GRAD), dofoff(D_MGRAD), gl, gb4);
+    if constexpr (S::is_static) spd_solve_static<S, G, S::tree_H>(Ho, dofoff(D_GRAD), dofoff(D_MGRAD), gl, m_rot);
+    else spd_solve<G>(m.nchol(), Ho, ldm, nv, dofoff(D_GRAD), dofoff(D_MGRAD), gl, gb4, m_rot);
   }
 
   DEV LSPoint ls_point(float alpha, bool validA, bool validB, bool iseq, float g0, float g1, float g2) const {
@@ -1583,28 +1682,34 @@ struct Env {
   }
 
   // ------------------------------------------------------------------ forward (A9.1-A9.13)
-  DEV void forward() {
+  // `after_poses` runs once the body poses are final and before their storage is reused (mjx.forward's xpos / xquat outputs).
+  // Phase order: the collision pass precedes crb + M and the constraint rows are assembled last, after the smooth forces -
+  // the body records (poses, cinert / cfrc, crb / cvel / cacc) are dead by then and the contact Jacobian rows, the per-row
+  // records and the M*v staging vector take over their space (amx_plan.h, region R1).
+  DEV void forward() { forward([] {}); }
+  template <class Hook> DEV void forward(Hook after_poses) {
     const int nv = m.nv();
     PROF(0);
     kinematics();
     PROF(1);
     com_pos();
     PROF(2);
-    crb_and_M();
-    PROF(3);
     if (m.ncon() > 0 && !(m.disableflags() & (DIS_CONTACT | DIS_CONSTRAINT))) collision();
     PROF(4);
-    if (m.nefc() > 0) make_constraint();
-    PROF(5);
+    crb_and_M();
+    PROF(3);
     velocity_and_bias();
     PROF(6);
     smooth_forces();
     PROF(7);
+    after_poses();
+    if (m.nefc() > 0) make_constraint();
+    PROF(5);
     // qacc_smooth = M^-1 qfrc_smooth.  Newton never reuses the factor: one-shot Gauss-Jordan solve;
     // CG keeps a Cholesky factor in Lb as its preconditioner.
     if (m.solver() == 2) {
-      if constexpr (S::is_static) spd_solve_static<S, G, true>(eb + m.e_M(), dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), gl);
-      else spd_solve<G>(m.nchol(), eb + m.e_M(), m.ldm(), nv, dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), gl, gb4);
+      if constexpr (S::is_static) spd_solve_static<S, G, true>(eb + m.e_M(), dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), gl, m_rot);
+      else spd_solve<G>(m.nchol(), eb + m.e_M(), m.ldm(), nv, dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), gl, gb4, m_rot);
     }
     else chol_solve<G>(m.nchol(), eb + m.e_M(), m.ldm(), nv, eb + m.e_Lb(), dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), true, gl, gb4);
     PROF(8);
@@ -1625,10 +1730,10 @@ struct Env {
     const int qp = eb + m.e_qpos(), qv = eb + m.e_qvel();
     if (!(m.disableflags() & DIS_EULERDAMP)) {
       // M + dt*diag(damping) in place: this is the last reader of M in the step and the crb pass rewrites it
-      if (gl < nv) { dof(D_SEARCH, gl) = dof(D_FSMOOTH, gl) + dof(D_FCON, gl); lds[Mo + gl * m.ldm() + gl] += m.dt() * CF(m.c_dof() + gl * DOF_S + 5); }
+      if (gl < nv) { dof(D_SEARCH, gl) = dof(D_FSMOOTH, gl) + dof(D_FCON, gl); lds[Mo + m_diag] += m.dt() * CF(m.c_dof() + gl * DOF_S + 5); }
       WSYNC();
-      if constexpr (S::is_static) spd_solve_static<S, G, true>(Mo, dofoff(D_SEARCH), dofoff(D_MV), gl);
-      else spd_solve<G>(m.nchol(), Mo, m.ldm(), nv, dofoff(D_SEARCH), dofoff(D_MV), gl, gb4);
+      if constexpr (S::is_static) spd_solve_static<S, G, true>(Mo, dofoff(D_SEARCH), dofoff(D_MV), gl, m_rot);
+      else spd_solve<G>(m.nchol(), Mo, m.ldm(), nv, dofoff(D_SEARCH), dofoff(D_MV), gl, gb4, m_rot);
     } else {
       if (gl < nv) dof(D_MV, gl) = dof(D_QACC, gl);
       WSYNC();
@@ -1793,7 +1898,13 @@ amx_forward_kernel(const DevModel m_in, int nenv, const float *__restrict__ qpos
     for (int i = gl; i < nu; i += G) lds[eb + m.e_ctrl() + i] = ctrl[(size_t)e * nu + i];
   }
   WSYNC();
-  env.forward();
+  env.forward([&] {
+    if (live && o.xpos)
+      for (int k = gl; k < m.nb() * 3; k += G) o.xpos[(size_t)e * m.nb() * 3 + k] = env.body(k % 3, k / 3);
+    if (live && o.xquat)
+      for (int k = gl; k < m.nb() * 4; k += G) o.xquat[(size_t)e * m.nb() * 4 + k] = env.body(3 + k % 4, k / 4);
+    WSYNC();
+  });
   const unsigned long long gmask = G == 64 ? ~0ull : ((1ull << (G & 63)) - 1);
   const int nactive = __popcll((__ballot(gl < env.nA() && env.aD > 0) >> (lane & ~(G - 1))) & gmask) +
                       __popcll((__ballot(gl < env.nB() && env.cD > 0) >> (lane & ~(G - 1))) & gmask);
@@ -1807,12 +1918,8 @@ amx_forward_kernel(const DevModel m_in, int nenv, const float *__restrict__ qpos
   if (o.qM)
     for (int k = gl; k < nv * nv; k += G) {
       const int r = k / nv, c = k % nv, hi = r > c ? r : c, lo = r > c ? c : r;
-      o.qM[(size_t)e * nv * nv + k] = lds[eb + m.e_M() + hi * m.ldm() + lo];
+      o.qM[(size_t)e * nv * nv + k] = lds[eb + m.e_M() + env.moff(hi, lo)];
     }
-  if (o.xpos)
-    for (int k = gl; k < m.nb() * 3; k += G) o.xpos[(size_t)e * m.nb() * 3 + k] = env.body(k % 3, k / 3);
-  if (o.xquat)
-    for (int k = gl; k < m.nb() * 4; k += G) o.xquat[(size_t)e * m.nb() * 4 + k] = env.body(3 + k % 4, k / 4);
   if (o.cdist)
     for (int k = gl; k < m.ncon(); k += G) o.cdist[(size_t)e * m.ncon() + k] = env.con(0, k);
   if (o.nefc && gl == 0) o.nefc[e] = nactive;

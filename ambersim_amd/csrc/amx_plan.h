@@ -205,6 +205,8 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
     im.seti(o, d->dof_bodyid[i]); im.seti(o + 1, j); im.seti(o + 2, kind); im.seti(o + 3, axis);
     im.setf(o + 4, d->dof_armature[i]); im.setf(o + 5, d->dof_damping[i]);
     im.seti(o + 6, dofact_adr[i]); im.seti(o + 7, dofact_num[i]); im.seti(o + 8, root_slot[d->dof_bodyid[i]]);
+    im.seti(o + 9, d->jnt_dofadr[j]);  // first dof of the dof's joint: its record holds the joint's anchor and axis
+    im.seti(o + 10, -1);               // lane of the limit row on this dof (filled below), -1: none
   }
   // collision geoms (only those that appear in a pair)
   std::vector<int> gmap(d->ngeom > 0 ? d->ngeom : 1, -1), gc_src;
@@ -290,6 +292,11 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
     write_kbi(im, o + 5, d->jnt_solref + 2 * j, d->jnt_solimp + 5 * j, d->timestep, refsafe);
     im.setf(o + 14, d->dof_invweight0[d->jnt_dofadr[j]]);
   }
+  {
+    int neq_active = 0;
+    for (int e = 0; e < d->neq; e++) if (d->eq_active[e]) neq_active++;
+    for (int l = 0; l < m.nlim; l++) im.seti(m.c_dof + d->jnt_dofadr[lim_j[l]] * DOF_S + 10, neq_active + l);
+  }
   std::vector<int> eq_e;
   for (int e = 0; e < d->neq; e++) if (d->eq_active[e]) eq_e.push_back(e);
   m.neq = (int)eq_e.size();
@@ -318,9 +325,6 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
   // lists
   auto add_ints = [&](const std::vector<int> &v) { int o = im.reserve((int)v.size()); for (size_t k = 0; k < v.size(); k++) im.seti(o + (int)k, v[k]); return o; };
   m.c_child = add_ints(child_list);
-  std::vector<int> Mlist;
-  for (int i = 0; i < nv; i++) for (int j = i; j >= 0; j = d->dof_parentid[j]) Mlist.push_back(i | (j << 8));
-  m.nM = (int)Mlist.size(); m.c_M = add_ints(Mlist);
   if (m.G >= 32) { hent.clear(); m.nhent = 0; }  // wide groups build the Hessian on the matrix cores; only 16-lane groups walk the term list
   m.c_dofact = add_ints(dofact); m.c_pairdof = add_ints(pairdof); m.c_jac = add_ints(jac_items); m.c_hent = add_ints(hent);
   m.c_conpair = add_ints(con_pair); m.c_rootbody = add_ints(roots);
@@ -339,8 +343,26 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
     m.c_dofmemadr = add_ints(adr); m.c_dofmem = add_ints(flat);
   }
   m.ldc = maxchain | 1;
+  // Newton on 32- and 64-lane groups without equality rows never stores H: the matrix cores' J'DJ, the lane's row of M and the
+  // limit rows' diagonal terms meet in registers and are eliminated there (amx_kernels.hip, newton_solve_fused).
+  m.fusedH = (m.G >= 32 && d->solver == 2 && m.neq == 0) ? 1 : 0;
+  // M (and H where it is stored): full symmetric [nv][ldm], rows 16-byte aligned for ds_read_b128.  Eight lanes reading their
+  // rows' chunk c must cover all 32 banks: either ldm/4 is odd (the row stride does it), or - fused path only, where no other
+  // code indexes the matrix - ldm = 4 ceil(nv/4) and row i stores its chunks rotated by i (chunk c at position (c + i) mod
+  // ldm/4): a 30-dof model keeps 32-float rows instead of 36.
   m.ldm = ((nv + 3) / 4) * 4;
-  if ((m.ldm / 4) % 2 == 0) m.ldm += 4;  // rows 16-byte aligned, ldm/4 odd: 8 lanes reading their rows as b128 cover all 32 banks
+  m.mrot = 0;
+  if ((m.ldm / 4) % 2 == 0) { if (m.fusedH) m.mrot = 1; else m.ldm += 4; }
+  auto moff = [&](int i, int j) {  // float offset of M[i][j] inside the matrix block
+    const int nch = m.ldm / 4, rot = m.mrot ? i % nch : 0;
+    return i * m.ldm + 4 * ((j / 4 + rot) % nch) + (j & 3);
+  };
+  {
+    std::vector<int> Mlist;  // one item per (dof i, ancestor-or-self j): offsets of M[i][j] and M[j][i], and the pair itself
+    for (int i = 0; i < nv; i++)
+      for (int j = i; j >= 0; j = d->dof_parentid[j]) Mlist.push_back((int)((unsigned)moff(i, j) | ((unsigned)moff(j, i) << 11) | ((unsigned)i << 22) | ((unsigned)j << 27)));
+    m.nM = (int)Mlist.size(); m.c_M = add_ints(Mlist);
+  }
   m.c_qpos0 = im.reserve(nq);
   for (int k = 0; k < nq; k++) im.setf(m.c_qpos0 + k, d->qpos0[k]);
   m.c_vert = im.reserve(3 * d->nconvexvert);
@@ -348,21 +370,36 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
   while (im.size() & 3) im.reserve(1);  // environment slabs start 16-byte aligned
   m.nconst = im.size();
 
-  // ---- environment slab plan (floats)
+  // ---- environment slab plan (floats).  Phase order of a step (amx_kernels.hip, Env::forward): kinematics, com_pos,
+  // collision, crb + M, velocity + bias, smooth forces, make_constraint, solves.  Storage with disjoint lifetimes is shared:
+  //   * joint anchors / axes (kinematics -> cdof) live in fields 6..11 of the joint's first dof record (crb*cdof, then the
+  //     solver vectors, take them over afterwards);
+  //   * region R1 holds the body records (poses, cinert -> cfrc, crb -> cvel/cacc) until the smooth forces are formed, and from
+  //     make_constraint on the contact Jacobian rows, the per-row records and the 16-byte aligned staging vector of M*v.
   int off = 0;
   auto take = [&](int n) { int o = off; off += (n > 0 ? n : 1); return o; };
   m.e_qpos = take(nq); m.e_qvel = take(nv); m.e_ctrl = take(nu);
-  m.e_body = take(BODY_E * nb); m.e_dof = take(DOF_E * nv);
+  m.e_dof = take(DOF_E * nv);
   m.e_com = take(3 * m.nroot); m.e_actf = take(nu);
-  const int ntri = nv * (nv + 1) / 2;
-  // joint anchors/axes (kinematics -> cdof) are dead before H is first written: they share its space
-  off = (off + 3) & ~3;  // M and H are full symmetric [nv][ldm] with 16-byte aligned rows (row loads and M*v use ds_read_b128)
-  m.e_M = take(nv * m.ldm);
-  m.e_H = take(std::max(std::max(nv * m.ldm, JNT_E * nj), nv + 8)); m.e_jnt = m.e_H; m.e_Lb = d->solver == 1 ? take(ntri) : m.e_H;
-  m.e_row = take(ROW_E * m.nefc);
-  // collision geom poses (com_pos -> collision) are dead before the contact rows are written: they share their space
-  m.e_J = take(std::max(4 * m.ncon * m.ldc, GEO_E * m.ngc)); m.e_geom = m.e_J;
   m.e_con = take(CON_E * m.ncon); m.e_frame = take(9 * np);
+  m.e_geom = take(GEO_E * m.ngc);
+  const int ntri = nv * (nv + 1) / 2;
+  off = (off + 3) & ~3;
+  m.e_M = take(nv * m.ldm);
+  {
+    const int r1 = off;
+    m.e_body = r1;
+    m.e_J = r1;
+    int o2 = r1 + std::max(4 * m.ncon * m.ldc, 1);
+    m.e_row = o2; o2 += std::max(ROW_E * m.nefc, 1);
+    o2 = (o2 + 3) & ~3;
+    const int vstage = o2; o2 += std::max(m.ldm, nv + 8);
+    off = std::max(r1 + BODY_E * nb, o2);
+    off = (off + 3) & ~3;
+    // H: stored only when it is not eliminated in registers; it doubles as the staging vector and as CG scratch
+    m.e_H = m.fusedH ? vstage : take(std::max(nv * m.ldm, nv + 8));
+  }
+  m.e_Lb = d->solver == 1 ? take(ntri) : m.e_H;
 #ifdef AMX_PROFILE
   m.e_prof = take(24);
 #endif
