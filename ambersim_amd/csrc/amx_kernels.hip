@@ -178,8 +178,12 @@ template <int G> DEV float gsum(float x) {  // every lane gets the sum over its 
   x += dpp_f<0x4E>(x);
   x += dpp_f<0x141>(x);
   x += dpp_f<0x140>(x);  // 16-lane row total in every lane of the row
+  // (Measured alternative, r02: rows exchanged on the VALU with v_permlane16_swap / v_permlane32_swap instead - 1 % slower on
+  // both models: at 2 waves/SIMD the VALU is 55-65 % busy and the crossbar is not the scarcer unit, profiles/r02_ab_*.)
   if (G >= 32) x += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x401F));  // lane ^ 16 (crossbar, no LDS memory)
   if (G >= 64) x += __shfl_xor(x, 32);
+  return x;
+}
   return x;
 }
 // value of lane `j` of my group (j compile-time or wave-uniform); gb4 = 4 * (first lane of my group)
@@ -452,6 +456,8 @@ template <class S, int G, int J, int K> struct GJAnc {  // K walks J's ancestor 
 template <class S, int G, int J> struct GJAnc<S, G, J, -1> { static DEV void run(float (&)[S::nv], float) {} };
 template <class S, int G, int J> struct GJTree {
   static DEV void run(float (&a)[S::nv], float &b, int gl) {
+    // (Measured alternative, r02: every lane scales its row by the reciprocal of its own entry J before the hop, so the pivot
+    // itself never travels - one crossbar operation less per pivot, one multiply more per entry: -1.7 % quadruped, +0.4 % biped.)
     const float piv = gbcast_s<G, J>(a[J]);
     const float bj = gbcast_s<G, J>(b);
     float f = a[J] * __builtin_amdgcn_rcpf(fmaxf(piv, MINVAL));

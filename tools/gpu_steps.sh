@@ -21,7 +21,9 @@ for step in "$@"; do
     bench)   run 600 gpurun_out/r02_bench_n1.log python bench.py ;;
     configs) run 600 gpurun_out/r02_configs_throughput.txt python tools/configs_bench.py ;;
     stats)   (cd /tmp && export TMPDIR=/tmp && run 600 $REPO/gpurun_out/r02_stats.log rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/r02_stats -o stats -- python3 $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary) ;;
-    pmc)     run 900 gpurun_out/r02_pmc.log bash tools/pmc_collect.sh ;;
+    pmc)     mkdir -p gpurun_out/pmc_quadruped gpurun_out/pmc_biped
+             run 900 gpurun_out/r02_pmc_quadruped.log bash tools/pmc_collect.sh quadruped
+             run 900 gpurun_out/r02_pmc_biped.log bash tools/pmc_collect.sh biped --model models/biped/biped.xml ;;
     phase)   AMX_LIBRARY=ambersim_amd/csrc/libamx_prof.so run 300 gpurun_out/r02_phase_quadruped.txt python tools/phase_profile.py
              AMX_LIBRARY=ambersim_amd/csrc/libamx_prof.so run 300 gpurun_out/r02_phase_biped.txt python tools/phase_profile.py models/biped/biped.xml 4096 100 ;;
     *) echo "unknown step $step"; exit 2 ;;
