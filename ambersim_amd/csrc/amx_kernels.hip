@@ -184,8 +184,6 @@ template <int G> DEV float gsum(float x) {  // every lane gets the sum over its 
   if (G >= 64) x += __shfl_xor(x, 32);
   return x;
 }
-  return x;
-}
 // value of lane `j` of my group (j compile-time or wave-uniform); gb4 = 4 * (first lane of my group)
 template <int G> DEV float gbcast(float x, int j, int gb4) {
   if (G == 64) return readlane_f(x, j);
