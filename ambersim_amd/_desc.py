@@ -18,6 +18,9 @@ _INT_FIELDS_4 = ["geom_type", "geom_bodyid"]
 _DBL_FIELDS_4 = ["geom_pos", "geom_quat", "geom_size"]
 _INT_FIELDS_5 = ["pair_geom1", "pair_geom2", "pair_fn", "pair_vertadr", "pair_vertnum"]
 _DBL_FIELDS_5 = ["pair_friction", "pair_solref", "pair_solimp", "pair_margin", "convex_vert"]
+_INT_FIELDS_5B = ["pair_hull1", "pair_hull2", "hull_vertadr", "hull_vertnum", "hull_faceadr", "hull_facenum", "hull_edgeadr", "hull_edgenum"]
+_DBL_FIELDS_5B = ["hull_vert", "hull_face_normal"]
+_INT_FIELDS_5C = ["hull_face_vertadr", "hull_face_vertnum", "hull_facevert", "hull_edge"]
 _INT_FIELDS_6 = ["actuator_trnid", "actuator_biastype", "actuator_ctrllimited", "actuator_forcelimited"]
 _DBL_FIELDS_6 = ["actuator_gear", "actuator_gainprm", "actuator_biasprm", "actuator_ctrlrange", "actuator_forcerange"]
 _INT_FIELDS_7 = ["eq_obj1id", "eq_obj2id", "eq_active"]
@@ -27,7 +30,8 @@ _DBL_FIELDS_7 = ["eq_data", "eq_solref", "eq_solimp"]
 def _ptr_fields():
     out = []
     for ints, dbls in [(_INT_FIELDS_1, _DBL_FIELDS_1), (_INT_FIELDS_2, _DBL_FIELDS_2), (_INT_FIELDS_3, _DBL_FIELDS_3),
-                       (_INT_FIELDS_4, _DBL_FIELDS_4), (_INT_FIELDS_5, _DBL_FIELDS_5), (_INT_FIELDS_6, _DBL_FIELDS_6),
+                       (_INT_FIELDS_4, _DBL_FIELDS_4), (_INT_FIELDS_5, _DBL_FIELDS_5), (_INT_FIELDS_5B, _DBL_FIELDS_5B), (_INT_FIELDS_5C, []),
+                       (_INT_FIELDS_6, _DBL_FIELDS_6),
                        (_INT_FIELDS_7, _DBL_FIELDS_7)]:
         out += [(n, _I) for n in ints] + [(n, _D) for n in dbls]
     return out
@@ -36,7 +40,8 @@ def _ptr_fields():
 class AmxModelDesc(C.Structure):
     _fields_ = (
         [("version", C.c_int)]
-        + [(n, C.c_int) for n in ["nq", "nv", "nu", "nbody", "njnt", "ngeom", "neq", "npair", "nconvexvert"]]
+        + [(n, C.c_int) for n in ["nq", "nv", "nu", "nbody", "njnt", "ngeom", "neq", "npair", "nconvexvert",
+                                  "nhull", "nhullvert", "nhullface", "nhullfacevert", "nhulledge"]]
         + [("timestep", C.c_double), ("gravity", C.c_double * 3), ("tolerance", C.c_double),
            ("ls_tolerance", C.c_double), ("impratio", C.c_double), ("meaninertia", C.c_double)]
         + [(n, C.c_int) for n in ["iterations", "ls_iterations", "solver", "integrator", "disableflags"]]
@@ -44,7 +49,7 @@ class AmxModelDesc(C.Structure):
     )
 
 
-AMX_VERSION = 1
+AMX_VERSION = 2
 
 
 def build_desc(m) -> AmxModelDesc:
@@ -55,6 +60,8 @@ def build_desc(m) -> AmxModelDesc:
     d.version = AMX_VERSION
     d.nq, d.nv, d.nu, d.nbody, d.njnt, d.ngeom, d.neq, d.npair = m.nq, m.nv, m.nu, m.nbody, m.njnt, m.ngeom, m.neq, m.npair
     d.nconvexvert = int(m.convex_vert.shape[0])
+    d.nhull, d.nhullvert, d.nhullface = int(len(m.hull_vertadr)), int(m.hull_vert.shape[0]), int(len(m.hull_face_vertadr))
+    d.nhullfacevert, d.nhulledge = int(len(m.hull_facevert)), int(np.asarray(m.hull_edge).reshape(-1, 2).shape[0])
     o = m.opt
     d.timestep, d.tolerance, d.ls_tolerance, d.impratio = float(o.timestep), float(o.tolerance), float(o.ls_tolerance), float(o.impratio)
     d.gravity = (C.c_double * 3)(*[float(x) for x in o.gravity])

@@ -15,7 +15,9 @@
 // Record strides (floats) of the constant image.  All odd, so lane-per-record LDS reads are conflict free.
 // Record strides (floats) of the per-environment slab, also odd.
 enum { BODY_E = 29, JNT_E = 7, DOF_E = 17, ROW_E = 3, CON_E = 5, GEO_E = 13 };
-enum { BODY_S = 25, JNT_S = 13, DOF_S = 11, ACT_S = 13, GEOM_S = 13, PAIR_S = 29, LIM_S = 15, EQ_S = 21 };
+enum { BODY_S = 25, JNT_S = 13, DOF_S = 11, ACT_S = 13, GEOM_S = 13, PAIR_S = 29, LIM_S = 15, EQ_S = 21, HULL_S = 7 };
+// convex-convex scratch per environment (floats): world vertices of both hulls [2][32][3], two clip polygons [2][16][3]
+enum { CX_MAXV = 32, CX_MAXP = 16, CX_VA = 0, CX_VB = 96, CX_POLY = 192, CX_SCRATCH = 289 };
 // BodyRec: 0 parent 1 level 2 rootslot 3 jntadr 4 jntnum 5 childadr 6 childnum 7-9 pos 10-13 quat 14-16 ipos 17-20 iquat 21 mass 22-24 inertia
 // JntRec : 0 type 1 qadr 2 dadr 3 body 4-6 pos 7-9 axis 10 qpos0 11 stiffness 12 springref
 // DofRec : 0 body 1 jnt 2 kind(0 free-trans,1 free/ball-rot,2 hinge,3 slide) 3 axis 4 armature 5 damping 6 actadr 7 actnum 8 rootslot
@@ -23,7 +25,8 @@ enum { BODY_S = 25, JNT_S = 13, DOF_S = 11, ACT_S = 13, GEOM_S = 13, PAIR_S = 29
 // ActRec : 0 qadr 1 dadr 2 flags(1 ctrllimited,2 forcelimited,4 affine bias) 3 gear 4 gain 5-7 bias 8-9 ctrlrange 10-11 forcerange 12 pad
 // GeomRec: 0 body 1 type 2-4 pos 5-8 quat 9-11 size 12 pad
 // PairRec: 0 g1 1 g2 2 fn 3 conadr 4 ncon 5 vertadr 6 vertnum 7 root1 8 root2 9 dofadr 10 dofnum 11 mu 12 k 13 b 14 dmin 15 dmax
-//          16 width 17 mid 18 power 19 ca 20 cb 21 margin 22 invw 23 hadr 24 hnum 25-28 pad
+//          16 width 17 mid 18 power 19 ca 20 cb 21 margin 22 invw 23 hadr 24 hnum 25 hull record of geom1 26 of geom2 (fn 6) 27-28 pad
+// HullRec: 0 nvert 1 vertices [nvert][3] 2 nface 3 face normals [nface][3] 4 face polygons [nface][9] (count, 8 vertex ids) 5 nedge 6 edges [nedge][2]
 // LimRec : 0 qadr 1 dadr 2 range0 3 range1 4 margin 5 k 6 b 7 dmin 8 dmax 9 width 10 mid 11 power 12 ca 13 cb 14 invw
 // EqRec  : 0 q1 1 d1 2 q2 3 d2 4-8 polycoef 9 k 10 b 11 dmin 12 dmax 13 width 14 mid 15 power 16 ca 17 cb 18 invw 19 qref1 20 qref2
 
@@ -39,6 +42,7 @@ enum { BODY_S = 25, JNT_S = 13, DOF_S = 11, ACT_S = 13, GEOM_S = 13, PAIR_S = 29
   X(mrot) /* 1: row i of M stores chunk c at position (c + i) mod ldm/4 (fused path with an even chunk count) */          \
   X(fusedH) /* 1: Newton eliminates H in registers, no H buffer (G >= 32, no equality rows) */                            \
   X(nchol) X(njac) X(nhent)                                                                                                \
+  X(cx_first) X(ncx) /* run of convex-convex pairs (fn 6), processed one after the other by the whole lane group */         \
   X(pcx_first) X(npcx) /* run of plane - convex pairs (<= 32 hull vertices) handled one lane per vertex; npcx = 0: none */   \
   X(iterations) X(ls_iterations) X(solver) X(disableflags)                                                                 \
   X(G)   /* lanes per environment: 16, 32 or 64 */                                                                         \
@@ -61,6 +65,7 @@ enum { BODY_S = 25, JNT_S = 13, DOF_S = 11, ACT_S = 13, GEOM_S = 13, PAIR_S = 29
   X(e_J) /* contact rows only, chain-compressed: [4*ncon][ldc] */                                                          \
   X(e_con) /* records [ncon][CON_E]: dist 0 pos 1-3 */ X(e_frame) /* [npair][9] */                                         \
   X(e_geom) /* records [ngc][GEO_E]: pos 0-2 mat 3-11 */                                                                   \
+  X(e_cx) /* convex-convex scratch [CX_SCRATCH], only when ncx > 0 */                                                                   \
   X(e_prof)                                                                                                                \
   X(env_floats) /* floats per environment slab */
 #define AMX_MODEL_FLOATS(X) X(dt) X(gx) X(gy) X(gz) X(tolerance) X(ls_tolerance) X(impratio) X(scale) /* scale = meaninertia*max(1,nv) */

@@ -705,6 +705,248 @@ __device__ __noinline__ void plane_convex_parallel(int pcx_first, int pcx_num, i
   WSYNC();
 }
 
+// ---- group max / min with the value in every lane (same network as gsum)
+template <int G> DEV float gmaxf(float x) {
+  x = fmaxf(x, dpp_f<0xB1>(x)); x = fmaxf(x, dpp_f<0x4E>(x)); x = fmaxf(x, dpp_f<0x141>(x)); x = fmaxf(x, dpp_f<0x140>(x));
+  if (G >= 32) x = fmaxf(x, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x401F)));
+  if (G >= 64) x = fmaxf(x, __shfl_xor(x, 32));
+  return x;
+}
+template <int G> DEV float gminf(float x) { return -gmaxf<G>(-x); }
+// bits of a wave ballot that belong to my group, shifted down to bit 0
+template <int G> DEV unsigned long long gballot(bool p, int gb4) {
+  const unsigned long long b = __ballot(p) >> ((gb4 >> 2) & 63);
+  return G == 64 ? b : (b & ((1ull << (G & 63)) - 1ull));
+}
+template <int G> DEV f3 gfetch3(f3 v, int lane_in_group, int gb4) {  // v of lane `lane_in_group` of my group (per-lane source: crossbar)
+  const int a = gb4 + 4 * lane_in_group;
+  return mk3(__int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(v.x))), __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(v.y))),
+             __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(v.z))));
+}
+
+// A9.5c convex - convex (box / mesh hulls): separating-axis test over the face normals of both hulls and the cross products
+// of their edge pairs (an edge pair counts only if both edges are supporting edges along its axis), axis of least penetration,
+// then either the face contact - reference face, incident face, Sutherland-Hodgman clipping against the reference face's side
+// planes, 4-point manifold like plane_convex's - or the edge-edge contact.  Same decisions and tie rules as the oracle
+// (oracle/amx_oracle.c, convex_convex).  The whole lane group works on one pair at a time: lanes over hull vertices for the
+// world transform, over axes for the SAT (the argmin is a group reduction, ties to the lowest axis index), over faces for the
+// reference / incident choice, over polygon edges for the clipping (ballot prefix counts compact the output in order) and
+// over polygon points for the manifold picks.  Scratch (world vertices, two clip polygons) lives in the slab (e_cx).
+template <int G>
+__device__ __noinline__ void convex_convex_pairs(int cx_first, int ncx, int c_pair, int geom_off, int con_off, int frame_off, int scr, int gl, int gb4) {
+#define GEO(f, g) lds[geom_off + (g) * GEO_E + (f)]
+#define HV(base, i) mk3(lds[(base) + 3 * (i)], lds[(base) + 3 * (i) + 1], lds[(base) + 3 * (i) + 2])
+  const int VA = scr + CX_VA, VB = scr + CX_VB;
+  for (int pp = 0; pp < ncx; ++pp) {
+    const int pr = cx_first + pp, rec = c_pair + pr * PAIR_S;
+    const int g1 = CI(rec), g2 = CI(rec + 1), c0 = CI(rec + 3), hA = CI(rec + 25), hB = CI(rec + 26);
+    const int nvA = CI(hA), vA = CI(hA + 1), nfA = CI(hA + 2), nA_ = CI(hA + 3), pA = CI(hA + 4), neA = CI(hA + 5), eA = CI(hA + 6);
+    const int nvB = CI(hB), vB = CI(hB + 1), nfB = CI(hB + 2), nB_ = CI(hB + 3), pB = CI(hB + 4), neB = CI(hB + 5), eB = CI(hB + 6);
+    const f3 pos1 = mk3(GEO(0, g1), GEO(1, g1), GEO(2, g1)), pos2 = mk3(GEO(0, g2), GEO(1, g2), GEO(2, g2));
+    m33 R1, R2;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { R1.a[k] = GEO(3 + k, g1); R2.a[k] = GEO(3 + k, g2); }
+    // 1. world vertices
+    for (int v = gl; v < nvA; v += G) { const f3 w = pos1 + mulv(R1, HV(vA, v)); lds[VA + 3 * v] = w.x; lds[VA + 3 * v + 1] = w.y; lds[VA + 3 * v + 2] = w.z; }
+    for (int v = gl; v < nvB; v += G) { const f3 w = pos2 + mulv(R2, HV(vB, v)); lds[VB + 3 * v] = w.x; lds[VB + 3 * v + 1] = w.y; lds[VB + 3 * v + 2] = w.z; }
+    WSYNC();
+    // 2. separating axes, lane-strided.  Selection rule (as in the oracle): the lowest axis index whose penetration is within
+    // a tolerance of the least one - exact ties (parallel faces) must not be left to rounding.  Pass 1: the least penetration
+    // (group min); pass 2: every lane's lowest index within tolerance, then the group's lowest.
+    const int nface = nfA + nfB, naxes = nface + neA * neB;
+    struct Axis { bool ok; float pen, sg; f3 n; };
+    auto eval_axis = [&](int t) {
+      const bool valid = t < naxes;
+      const int tc = valid ? t : 0;
+      f3 n;
+      bool ok = valid;
+      int ea = 0, eb = 0;
+      if (tc < nfA) n = mulv(R1, HV(nA_, tc));
+      else if (tc < nface) n = mulv(R2, HV(nB_, tc - nfA));
+      else {
+        ea = (tc - nface) / neB; eb = (tc - nface) - ea * neB;
+        float l;
+        const f3 da = normalize3(HV(VA, CI(eA + 2 * ea + 1)) - HV(VA, CI(eA + 2 * ea)), &l);
+        const f3 db = normalize3(HV(VB, CI(eB + 2 * eb + 1)) - HV(VB, CI(eB + 2 * eb)), &l);
+        n = cross(da, db);
+        const float c2 = dot(n, n);
+        ok = ok && !(c2 < 1e-6f);
+        n = n * (1.0f / sqrtf(fmaxf(c2, 1e-30f)));
+      }
+      float loA = 1e30f, hiA = -1e30f, loB = 1e30f, hiB = -1e30f;
+      for (int i = 0; i < nvA; ++i) { const float sdot = dot(HV(VA, i), n); loA = fminf(loA, sdot); hiA = fmaxf(hiA, sdot); }
+      for (int i = 0; i < nvB; ++i) { const float sdot = dot(HV(VB, i), n); loB = fminf(loB, sdot); hiB = fmaxf(hiB, sdot); }
+      const float d1 = hiA - loB, d2 = hiB - loA;
+      const float pen = d1 < d2 ? d1 : d2, sg = d1 > d2 ? -1.0f : 1.0f;
+      if (tc >= nface) {
+        const float sa = dot(HV(VA, CI(eA + 2 * ea)), n), sb = dot(HV(VB, CI(eB + 2 * eb)), n);
+        const float supA = sg > 0 ? hiA : loA, supB = sg > 0 ? loB : hiB;
+        ok = ok && !(fabsf(sa - supA) > 1e-5f || fabsf(sb - supB) > 1e-5f);
+      }
+      return Axis{ok, pen, sg, n};
+    };
+#define CX_TOL(x) (1e-4f * fabsf(x) + 1e-7f)
+    float mybest = 1e30f;
+    for (int t0 = 0; t0 < naxes; t0 += G) {
+      const Axis ax = eval_axis(t0 + gl);
+      if (ax.ok && ax.pen < mybest) mybest = ax.pen;
+    }
+    const float best = gminf<G>(mybest);
+    const float lim = best + CX_TOL(best);
+    float mysg = 1.0f;
+    int myt = 0x7fffff;
+    f3 myn = mk3(0, 0, 1);
+    for (int t0 = 0; t0 < naxes; t0 += G) {
+      const Axis ax = eval_axis(t0 + gl);
+      if (ax.ok && ax.pen <= lim && myt == 0x7fffff) { myt = t0 + gl; mysg = ax.sg; myn = ax.n; }
+    }
+    const float tbest = gminf<G>((float)myt);  // axis indices are exact in fp32
+    const unsigned long long own = gballot<G>((float)myt == tbest, gb4);
+    const int owner = own ? __builtin_ctzll(own) : 0;
+    const int bt = (int)tbest;
+    const f3 bn = gfetch3<G>(myn, owner, gb4);
+    const float bsg = __int_as_float(__builtin_amdgcn_ds_bpermute(gb4 + 4 * owner, __float_as_int(mysg)));
+    const f3 N = bn * bsg;  // from geom1 to geom2
+    float cd[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+    const f3 mid = (pos1 + pos2) * 0.5f;
+    f3 cpos[4] = {mid, mid, mid, mid};
+    f3 fn_ = N;
+    if (bt >= nface) {
+      // 3a. edge - edge: closest points of the two segments (computed by every lane of the group alike)
+      const int ea = (bt - nface) / neB, eb = (bt - nface) - ea * neB;
+      const f3 a0 = HV(VA, CI(eA + 2 * ea)), a1 = HV(VA, CI(eA + 2 * ea + 1)), b0 = HV(VB, CI(eB + 2 * eb)), b1 = HV(VB, CI(eB + 2 * eb + 1));
+      const f3 u = a1 - a0, v = b1 - b0, r = a0 - b0;
+      const float a = dot(u, u), e = dot(v, v), f = dot(v, r), c = dot(u, r), b = dot(u, v), den = a * e - b * b;
+      float s_ = den > 1e-12f * a * e ? fminf(fmaxf((b * f - c * e) / den, 0.0f), 1.0f) : 0.0f;
+      float t_ = (b * s_ + f) / e;
+      if (t_ < 0) { t_ = 0; s_ = fminf(fmaxf(-c / a, 0.0f), 1.0f); }
+      else if (t_ > 1) { t_ = 1; s_ = fminf(fmaxf((b - c) / a, 0.0f), 1.0f); }
+      const f3 pa = a0 + u * s_, pb = b0 + v * t_;
+      cd[0] = dot(pb - pa, N);
+      cpos[0] = (pa + pb) * 0.5f;
+    } else {
+      // 3b. face contact.  Reference face: best aligned with the axis among both hulls (hull 1 along +N, hull 2 along -N)
+      float sA = -1e30f, sB = -1e30f;
+      int fA = 0x7fffff, fB = 0x7fffff;
+      for (int f = gl; f < nfA; f += G) { const float sdot = dot(mulv(R1, HV(nA_, f)), N); if (sdot > sA) { sA = sdot; fA = f; } }
+      for (int f = gl; f < nfB; f += G) { const float sdot = -dot(mulv(R2, HV(nB_, f)), N); if (sdot > sB) { sB = sdot; fB = f; } }
+      const float da = gmaxf<G>(sA), db = gmaxf<G>(sB);
+      const int fa = (int)gminf<G>(sA == da ? (float)fA : 1e9f), fb = (int)gminf<G>(sB == db ? (float)fB : 1e9f);
+      const bool refA = da >= db - 1e-6f;
+      const int rf = refA ? fa : fb;
+      const f3 nr = refA ? mulv(R1, HV(nA_, rf)) : mulv(R2, HV(nB_, rf));
+      // incident face on the other hull: most anti-parallel to the reference normal
+      const int nfI = refA ? nfB : nfA, nI_ = refA ? nB_ : nA_;
+      float sI = 1e30f;
+      int fI = 0x7fffff;
+      for (int f = gl; f < nfI; f += G) { const float sdot = dot(refA ? mulv(R2, HV(nI_, f)) : mulv(R1, HV(nI_, f)), nr); if (sdot < sI) { sI = sdot; fI = f; } }
+      const float dmin = gminf<G>(sI);
+      const int fi = (int)gminf<G>(sI == dmin ? (float)fI : 1e9f);
+      const int polyI = (refA ? pB : pA) + 9 * fi, polyR = (refA ? pA : pB) + 9 * rf, VI = refA ? VB : VA, VR = refA ? VA : VB;
+      int np_ = CI(polyI);
+      const int nr_ = CI(polyR);
+      int cur = scr + CX_POLY, oth = scr + CX_POLY + 3 * CX_MAXP;
+      if (gl < np_) { const f3 w = HV(VI, CI(polyI + 1 + gl)); lds[cur + 3 * gl] = w.x; lds[cur + 3 * gl + 1] = w.y; lds[cur + 3 * gl + 2] = w.z; }
+      WSYNC();
+      for (int k = 0; k < 8; ++k) {  // Sutherland-Hodgman against the side plane through reference edge k (lane = polygon edge)
+        const bool on = k < nr_ && np_ > 0;
+        if (!wave_any(on)) break;
+        const f3 r0 = HV(VR, CI(polyR + 1 + (on ? k : 0))), r1 = HV(VR, CI(polyR + 1 + (on && k + 1 < nr_ ? k + 1 : 0)));
+        const f3 mk = cross(r1 - r0, nr);  // outward of the reference polygon
+        const bool mine = on && gl < np_;
+        const int i0 = mine ? gl : 0, i1 = (mine && gl + 1 < np_) ? gl + 1 : 0;
+        const f3 pc = HV(cur, i0), pn = HV(cur, i1);
+        const float sc = dot(pc - r0, mk), sn = dot(pn - r0, mk);
+        const bool emitA = mine && sc <= 0, emitB = mine && ((sc <= 0) != (sn <= 0));
+        const unsigned long long bA = gballot<G>(emitA, gb4), bB = gballot<G>(emitB, gb4);
+        const unsigned long long below = (1ull << gl) - 1ull;
+        int off = __popcll(bA & below) + __popcll(bB & below);
+        if (emitA && off < CX_MAXP) { lds[oth + 3 * off] = pc.x; lds[oth + 3 * off + 1] = pc.y; lds[oth + 3 * off + 2] = pc.z; }
+        off += emitA ? 1 : 0;
+        if (emitB && off < CX_MAXP) {
+          const float tt = sc / (sc - sn);
+          const f3 q = pc + (pn - pc) * tt;
+          lds[oth + 3 * off] = q.x; lds[oth + 3 * off + 1] = q.y; lds[oth + 3 * off + 2] = q.z;
+        }
+        if (on) {
+          const int cnt = __popcll(bA) + __popcll(bB);
+          np_ = cnt < CX_MAXP ? cnt : CX_MAXP;
+          const int tmp = cur; cur = oth; oth = tmp;
+        }
+        WSYNC();
+      }
+      if (np_ > 0) {
+        const bool on = gl < np_;
+        const f3 me = HV(cur, on ? gl : 0);
+        const f3 r0 = HV(VR, CI(polyR + 1));
+        const float depth = dot(r0 - me, nr);
+        const float dmax = gmaxf<G>(on ? depth : -1e30f);
+        const float mask = (dmax >= 0 ? depth >= 0 : depth == dmax) ? 0.0f : -1e6f;
+        // lowest lane of my group whose score equals the group's maximum; returns that point and its depth
+        auto pick = [&](float sc_, int *idx, float *dep) {
+          const float s2 = on ? sc_ : -1e30f;
+          const float bst = gmaxf<G>(s2);
+          const unsigned long long bal = gballot<G>(on && s2 >= bst - CX_TOL(bst), gb4);  // lowest index within tolerance of the maximum
+          const int w = bal ? __builtin_ctzll(bal) : 0;
+          *idx = w;
+          *dep = __int_as_float(__builtin_amdgcn_ds_bpermute(gb4 + 4 * w, __float_as_int(depth)));
+          return gfetch3<G>(me, w, gb4);
+        };
+        int idx[4];
+        float dep[4];
+        const f3 a = pick(mask, &idx[0], &dep[0]);
+        const f3 dq = a - me;
+        const f3 bb = pick(dot(dq, dq) + mask, &idx[1], &dep[1]);
+        const f3 ab = cross(nr, a - bb);
+        const f3 cc = pick(fabsf(dot(a - me, ab)) + mask, &idx[2], &dep[2]);
+        const f3 ac = cross(nr, a - cc), bc = cross(nr, bb - cc);
+        const float s1 = fabsf(dot(bb - me, bc)) + mask, s2 = fabsf(dot(a - me, ac)) + mask;
+        const float m1 = gmaxf<G>(on ? s1 : -1e30f), m2 = gmaxf<G>(on ? s2 : -1e30f);
+        const f3 dd = pick(m2 > m1 + CX_TOL(m1) ? s2 : s1, &idx[3], &dep[3]);  // farthest from edge bc, or - clearly farther - from edge ac
+        const f3 sel[4] = {a, bb, cc, dd};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          bool unique = true;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) unique = unique && !(j < k && idx[j] == idx[k]);
+          if (unique) { cd[k] = -dep[k]; cpos[k] = sel[k] + nr * (0.5f * dep[k]); }
+        }
+#if defined(AMX_CX_DEBUG) && AMX_CX_DEBUG >= 2
+        for (int k = 0; k < 4; ++k) {
+          if (AMX_CX_DEBUG == 4) cd[k] = (float)idx[k];
+          else cd[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(gb4 + 4 * (k + (AMX_CX_DEBUG == 3 ? 4 : 0)), __float_as_int(on ? depth : -9.0f)));
+        }
+#endif
+      }
+      fn_ = refA ? nr : nr * -1.0f;
+#if defined(AMX_CX_DEBUG) && AMX_CX_DEBUG == 1
+      cd[1] = (float)((refA ? 1000 : 0) + 10 * rf + 0); cd[2] = (float)(100 * fi + np_);
+#endif
+    }
+#if defined(AMX_CX_DEBUG) && AMX_CX_DEBUG == 1
+    cd[0] = (float)bt; cd[3] = best;
+#endif
+    if (gl < 4) {
+      float dsel = cd[0];
+      f3 psel = cpos[0];
+#pragma unroll
+      for (int k = 1; k < 4; ++k) if (gl == k) { dsel = cd[k]; psel = cpos[k]; }
+      const int co = con_off + (c0 + gl) * CON_E;
+      lds[co] = dsel; lds[co + 1] = psel.x; lds[co + 2] = psel.y; lds[co + 3] = psel.z;
+    }
+    if (gl == 0) {
+      float fr[9];
+      make_frame(fn_, fr);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) lds[frame_off + pr * 9 + k] = fr[k];
+    }
+    WSYNC();
+  }
+#undef GEO
+#undef HV
+#undef CX_TOL
+}
+
 // =====================================================================================================
 // One environment's physics, run by a group of G lanes.  `eb` is the group's slab in LDS (per-lane value,
 // equal inside a group); `gl` is the lane's index inside its group; constants live at the front of LDS.
@@ -1148,7 +1390,9 @@ struct Env {
     const int cx_first = G >= 32 ? m.pcx_first() : 0, cx_num = G >= 32 ? m.npcx() : 0;
     if (G >= 32 && cx_num > 0)  // uniform: a property of the model
       plane_convex_parallel<G>(cx_first, cx_num, m.c_pair(), m.c_vert(), eb + m.e_geom(), eb + m.e_con(), eb + m.e_frame(), gl, gb4);
-    if (gl < np && !(gl >= cx_first && gl < cx_first + cx_num)) {
+    if (m.ncx() > 0)  // uniform: a property of the model
+      convex_convex_pairs<G>(m.cx_first(), m.ncx(), m.c_pair(), eb + m.e_geom(), eb + m.e_con(), eb + m.e_frame(), eb + m.e_cx(), gl, gb4);
+    if (gl < np && !(gl >= cx_first && gl < cx_first + cx_num) && !(gl >= m.cx_first() && gl < m.cx_first() + m.ncx())) {
       const int pr = gl, rec = m.c_pair() + pr * PAIR_S;
       const int g1 = CI(rec), g2 = CI(rec + 1), fn = CI(rec + 2), c0 = CI(rec + 3);
       const f3 pos1 = mk3(geo(0, g1), geo(1, g1), geo(2, g1)), pos2 = mk3(geo(0, g2), geo(1, g2), geo(2, g2));

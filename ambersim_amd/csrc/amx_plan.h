@@ -35,7 +35,7 @@ struct Image {
   int geti(int off) const { int x; memcpy(&x, &v[off], 4); return x; }
   void setf(int off, double x) { v[off] = (float)x; }
 };
-const int PAIR_NCON[6] = {1, 2, 4, 1, 1, 1};
+const int PAIR_NCON[7] = {1, 2, 4, 1, 1, 1, 4};
 
 // {k, b, dmin, dmax, width, mid, power, ca, cb}: the position-independent part of MuJoCo's solref/solimp
 // mapping (reference physics: constraint._kbi), evaluated once on the host in double precision.
@@ -221,6 +221,39 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
     for (int k = 0; k < 3; k++) { im.setf(o + 2 + k, d->geom_pos[3 * s + k]); im.setf(o + 9 + k, d->geom_size[3 * s + k]); }
     for (int k = 0; k < 4; k++) im.setf(o + 5 + k, d->geom_quat[4 * s + k]);
   }
+  // convex hulls of the convex-convex pairs: record + vertices, face normals, face polygons (count + 8 ids), edges
+  std::vector<int> hull_rec(d->nhull > 0 ? d->nhull : 1, 0);
+  for (int h = 0; h < d->nhull; h++) {
+    const int nvh = d->hull_vertnum[h], nfh = d->hull_facenum[h], neh = d->hull_edgenum[h];
+    const int va = d->hull_vertadr[h], fa = d->hull_faceadr[h], ea = d->hull_edgeadr[h];
+    if (nvh < 1 || nvh > CX_MAXV || nfh < 1 || nfh > 32 || neh < 0 || neh > 64 || va < 0 || va + nvh > d->nhullvert || fa < 0 || fa + nfh > d->nhullface ||
+        ea < 0 || ea + neh > d->nhulledge)
+      return fail(AMX_ECAPACITY, "hull %d: %d vertices, %d faces, %d edges (limits 32 / 32 / 64)", h, nvh, nfh, neh);
+    const int o = im.reserve(HULL_S);
+    hull_rec[h] = o;
+    im.seti(o, nvh); im.seti(o + 2, nfh); im.seti(o + 5, neh);
+    int q = im.reserve(3 * nvh); im.seti(o + 1, q);
+    for (int k = 0; k < 3 * nvh; k++) im.setf(q + k, d->hull_vert[3 * va + k]);
+    q = im.reserve(3 * nfh); im.seti(o + 3, q);
+    for (int k = 0; k < 3 * nfh; k++) im.setf(q + k, d->hull_face_normal[3 * fa + k]);
+    q = im.reserve(9 * nfh); im.seti(o + 4, q);
+    for (int f = 0; f < nfh; f++) {
+      const int cnt = d->hull_face_vertnum[fa + f], adr = d->hull_face_vertadr[fa + f];
+      if (cnt < 3 || cnt > 8 || adr < 0 || adr + cnt > d->nhullfacevert) return fail(AMX_ECAPACITY, "hull %d face %d: %d vertices (3..8)", h, f, cnt);
+      im.seti(q + 9 * f, cnt);
+      for (int k = 0; k < 8; k++) {
+        const int id = d->hull_facevert[adr + (k < cnt ? k : 0)];
+        if (id < 0 || id >= nvh) return fail(AMX_EINVAL, "hull %d face %d: vertex id %d outside [0, %d)", h, f, id, nvh);
+        im.seti(q + 9 * f + 1 + k, id);
+      }
+    }
+    q = im.reserve(2 * neh); im.seti(o + 6, q);
+    for (int k = 0; k < 2 * neh; k++) {
+      const int id = d->hull_edge[2 * ea + k];
+      if (id < 0 || id >= nvh) return fail(AMX_EINVAL, "hull %d edge %d: vertex id %d outside [0, %d)", h, k / 2, id, nvh);
+      im.seti(q + k, id);
+    }
+  }
   // pairs, contact slots, per-pair dof lists, Jacobian work items, Hessian work items
   m.c_pair = im.reserve(np * PAIR_S);
   std::vector<int> con_pair, pairdof, jac_items, hent;
@@ -229,13 +262,16 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
   int ncon = 0;
   for (int p = 0; p < np; p++) {
     int g1 = d->pair_geom1[p], g2 = d->pair_geom2[p], fn = d->pair_fn[p], o = m.c_pair + p * PAIR_S;
-    if (fn < 0 || fn > 5) return fail(AMX_EUNSUPPORTED, "pair %d: unknown collision function %d", p, fn);
+    if (fn < 0 || fn > 6) return fail(AMX_EUNSUPPORTED, "pair %d: unknown collision function %d", p, fn);
+    if (fn == 6 && (d->pair_hull1[p] < 0 || d->pair_hull1[p] >= d->nhull || d->pair_hull2[p] < 0 || d->pair_hull2[p] >= d->nhull))
+      return fail(AMX_EINVAL, "pair %d: convex-convex pair without hulls", p);
     if (fn == 2 && (d->pair_vertnum[p] < 1 || d->pair_vertadr[p] < 0 || d->pair_vertadr[p] + d->pair_vertnum[p] > d->nconvexvert))
       return fail(AMX_EINVAL, "pair %d: bad convex vertex range", p);
     int b1 = d->geom_bodyid[g1], b2 = d->geom_bodyid[g2];
     im.seti(o, gmap[g1]); im.seti(o + 1, gmap[g2]); im.seti(o + 2, fn); im.seti(o + 3, ncon); im.seti(o + 4, PAIR_NCON[fn]);
     im.seti(o + 5, fn == 2 ? d->pair_vertadr[p] : 0); im.seti(o + 6, fn == 2 ? d->pair_vertnum[p] : 0);
     im.seti(o + 7, root_slot[b1]); im.seti(o + 8, root_slot[b2]);
+    if (fn == 6) { im.seti(o + 25, hull_rec[d->pair_hull1[p]]); im.seti(o + 26, hull_rec[d->pair_hull2[p]]); }
     im.setf(o + 11, d->pair_friction[3 * p]);
     write_kbi(im, o + 12, d->pair_solref + 2 * p, d->pair_solimp + 5 * p, d->timestep, refsafe);
     im.setf(o + 21, d->pair_margin[p]);
@@ -272,6 +308,12 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
     for (int w : hmembers[t]) hent.push_back(w);  // one term per (H entry, contact)
   m.ncon = ncon; m.njac = (int)jac_items.size(); m.nhent = (int)hent.size();
   if (ncon > 16) return fail(AMX_ECAPACITY, "%d contact slots exceed 16 (4 pyramid rows each, one row per lane of a 64-lane group)", ncon);
+  {
+    int first = -1, last = -1, cnt = 0;
+    for (int p = 0; p < np; p++) if (d->pair_fn[p] == 6) { if (first < 0) first = p; last = p; cnt++; }
+    if (cnt > 0 && last - first + 1 != cnt) return fail(AMX_EINVAL, "convex-convex pairs must be contiguous in the pair list (pairs are sorted by function)");
+    if (cnt > 0) { m.cx_first = first; m.ncx = cnt; }
+  }
   // plane - convex pairs with at most 32 hull vertices go to the vertex-parallel routine when they form one contiguous run of
   // pair indices (pairs come grouped by function, so they do unless a larger hull sits among them)
   {
@@ -383,6 +425,7 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
   m.e_com = take(3 * m.nroot); m.e_actf = take(nu);
   m.e_con = take(CON_E * m.ncon); m.e_frame = take(9 * np);
   m.e_geom = take(GEO_E * m.ngc);
+  m.e_cx = m.ncx > 0 ? take(CX_SCRATCH) : 0;
   const int ntri = nv * (nv + 1) / 2;
   off = (off + 3) & ~3;
   m.e_M = take(nv * m.ldm);

@@ -698,6 +698,7 @@ class _Compiler:
         m.names_mesh = mesh_names
         m.mesh_vertadr, m.mesh_vertnum = I32(vertadr), I32(vertnum)
         m.mesh_vert = np.concatenate(pool, axis=0) if pool else np.zeros((0, 3))
+        m.mesh_faces = [np.asarray(self.meshes[name]["face"], dtype=int) for name in mesh_names]  # hull triangles, vertex ids local to the mesh
         m.geom_dataid = I32([mesh_names.index(g["mesh"]) if g["mesh"] is not None else -1 for g in geoms])
 
         # body inertial frames
@@ -999,9 +1000,69 @@ def _set_const(m: MjModel):
 # Pair functions the hot path implements; ids shared with oracle/ and csrc/.
 PAIR_PLANE_SPHERE, PAIR_PLANE_CAPSULE, PAIR_PLANE_CONVEX = 0, 1, 2
 PAIR_SPHERE_SPHERE, PAIR_SPHERE_CAPSULE, PAIR_CAPSULE_CAPSULE = 3, 4, 5
-PAIR_UNSUPPORTED = -1  # e.g. convex-convex (mesh/box vs mesh/box) or condim != 3: not built yet
-_PAIR_NCON = {0: 1, 1: 2, 2: 4, 3: 1, 4: 1, 5: 1, -1: 0}
+PAIR_CONVEX_CONVEX = 6  # box / mesh hull against box / mesh hull: SAT + face clipping
+PAIR_UNSUPPORTED = -1  # condim != 3, hulls beyond the size limits, sphere / capsule against a hull
+_PAIR_NCON = {0: 1, 1: 2, 2: 4, 3: 1, 4: 1, 5: 1, 6: 4, -1: 0}
+HULL_MAX_VERT, HULL_MAX_FACE, HULL_MAX_FACEVERT, HULL_MAX_EDGE = 32, 32, 8, 64
 _BOX_CORNERS = np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], dtype=float)
+
+
+_BOX_FACES = [[0, 1, 3, 2], [4, 6, 7, 5], [0, 4, 5, 1], [2, 3, 7, 6], [0, 2, 6, 4], [1, 5, 7, 3]]  # over _BOX_CORNERS, outward CCW
+
+
+def _hull_polygons(verts: np.ndarray, tris: np.ndarray):
+    """Polygon faces of a convex hull given as outward triangles: coplanar triangles are merged (as the reference physics'
+    mesh preprocessing does), each face's vertices ordered counter-clockwise seen from outside.  Returns (faces: list of
+    vertex-id lists, normals [nface,3], edges [nedge,2] unique vertex pairs)."""
+    scale = max(1e-12, np.abs(verts).max())
+    groups = []  # (normal, offset, set of vertex ids)
+    for t in tris:
+        a, b, c = verts[t[0]], verts[t[1]], verts[t[2]]
+        n = np.cross(b - a, c - a)
+        ln = np.linalg.norm(n)
+        if ln < 1e-14 * scale * scale:
+            continue
+        n = n / ln
+        off = float(n @ a)
+        for g in groups:
+            if g[0] @ n > 1 - 1e-8 and abs(g[1] - off) < 1e-7 * scale:
+                g[2].update(int(x) for x in t)
+                break
+        else:
+            groups.append([n, off, {int(x) for x in t}])
+    faces, normals = [], []
+    for n, off, ids in groups:
+        ids = sorted(ids)
+        c = verts[ids].mean(axis=0)
+        u = verts[ids[0]] - c
+        u = u / np.linalg.norm(u)
+        w = np.cross(n, u)
+        ang = [np.arctan2((verts[i] - c) @ w, (verts[i] - c) @ u) for i in ids]
+        order = [i for _, i in sorted(zip(ang, ids))]  # counter-clockwise about the outward normal
+        k = order.index(min(order))
+        faces.append(order[k:] + order[:k])  # canonical start: the lowest vertex id
+        normals.append(n)
+    edges = sorted({(min(f[k], f[(k + 1) % len(f)]), max(f[k], f[(k + 1) % len(f)])) for f in faces for k in range(len(f))})
+    return faces, np.array(normals, dtype=float).reshape(-1, 3), np.array(edges, dtype=int).reshape(-1, 2)
+
+
+def _geom_hull(m: "MjModel", g: int):
+    """(verts, faces, normals, edges) of a box or mesh geom in its own frame, or None when it exceeds the hull limits."""
+    if m.geom_type[g] == GEOM_BOX:
+        v = _BOX_CORNERS * m.geom_size[g]
+        faces = [list(f) for f in _BOX_FACES]
+        normals = np.array([np.cross(v[f[1]] - v[f[0]], v[f[2]] - v[f[0]]) for f in faces])
+        normals = normals / np.linalg.norm(normals, axis=1, keepdims=True)
+        edges = np.array(sorted({(min(f[k], f[(k + 1) % 4]), max(f[k], f[(k + 1) % 4])) for f in faces for k in range(4)}), dtype=int)
+    else:
+        mid = m.geom_dataid[g]
+        v = m.mesh_vert[m.mesh_vertadr[mid]: m.mesh_vertadr[mid] + m.mesh_vertnum[mid]]
+        if len(v) > HULL_MAX_VERT:
+            return None
+        faces, normals, edges = _hull_polygons(v, m.mesh_faces[mid])
+    if len(v) > HULL_MAX_VERT or len(faces) > HULL_MAX_FACE or len(edges) > HULL_MAX_EDGE or max(len(f) for f in faces) > HULL_MAX_FACEVERT:
+        return None
+    return v, faces, normals, edges
 
 
 def _make_collision_pairs(m: MjModel):
@@ -1011,6 +1072,15 @@ def _make_collision_pairs(m: MjModel):
     pairs = []
     box_vert_adr = {}
     extra = []
+    hulls, hull_of_geom = [], {}  # convex hulls of the geoms in convex-convex pairs
+
+    def hull_id(g):
+        if g not in hull_of_geom:
+            h = _geom_hull(m, g)
+            hull_of_geom[g] = -1 if h is None else len(hulls)
+            if h is not None:
+                hulls.append(h)
+        return hull_of_geom[g]
     nvert0 = m.mesh_vert.shape[0]
     contact_on = not (m.opt.disableflags & (DisableBit.CONTACT | DisableBit.CONSTRAINT))
     for g1 in range(m.ngeom):
@@ -1045,6 +1115,8 @@ def _make_collision_pairs(m: MjModel):
                 fn = PAIR_SPHERE_CAPSULE
             elif ta == GEOM_CAPSULE and tb == GEOM_CAPSULE:
                 fn = PAIR_CAPSULE_CAPSULE
+            elif ta in convex and tb in convex and hull_id(a) >= 0 and hull_id(b) >= 0:
+                fn = PAIR_CONVEX_CONVEX
             else:
                 # the host model still loads (as MuJoCo's compiler would); putting it on the device raises
                 # NotImplementedError, like mjx.device_put does for unsupported collisions (reference io_utils.py:228-241)
@@ -1082,8 +1154,9 @@ def _make_collision_pairs(m: MjModel):
                         box_vert_adr[b] = nvert0 + 8 * len(extra)
                         extra.append(_BOX_CORNERS * m.geom_size[b])
                     vadr, vnum = box_vert_adr[b], 8
+            h1, h2 = (hull_id(a), hull_id(b)) if fn == PAIR_CONVEX_CONVEX else (-1, -1)
             pairs.append(dict(g1=a, g2=b, fn=fn, ncon=_PAIR_NCON[fn], friction=fri[:3].copy(), solref=np.array(solref),
-                              solimp=np.array(solimp), includemargin=margin - gap, vadr=vadr, vnum=vnum))
+                              solimp=np.array(solimp), includemargin=margin - gap, vadr=vadr, vnum=vnum, h1=h1, h2=h2))
     # contacts are grouped by pair function (as the reference physics groups them), stable in geom order
     pairs.sort(key=lambda p: p["fn"])
     m.nunsupported_pairs = sum(1 for p in pairs if p["fn"] < 0)
@@ -1100,6 +1173,25 @@ def _make_collision_pairs(m: MjModel):
     m.pair_vertnum = np.array([p["vnum"] for p in pairs], dtype=np.int32).reshape(-1)
     m.convex_vert = np.concatenate([m.mesh_vert] + extra, axis=0) if extra else m.mesh_vert.copy()
     m.ncon = int(m.pair_ncon.sum())
+    # hull tables of the convex-convex pairs (amx_model_desc: pair_hull*, hull_*)
+    used = sorted({h for p in pairs for h in (p["h1"], p["h2"]) if h >= 0})
+    remap = {h: k for k, h in enumerate(used)}
+    m.pair_hull1 = np.array([remap.get(p["h1"], -1) for p in pairs], dtype=np.int32).reshape(-1)
+    m.pair_hull2 = np.array([remap.get(p["h2"], -1) for p in pairs], dtype=np.int32).reshape(-1)
+    va, vn, fa, fnum, ea, en, fva, fvn = [], [], [], [], [], [], [], []
+    hv, hn, hfv, he = [], [], [], []
+    for h in used:
+        v, faces, normals, edges = hulls[h]
+        va.append(sum(vn)); vn.append(len(v)); fa.append(sum(fnum)); fnum.append(len(faces)); ea.append(sum(en)); en.append(len(edges))
+        hv.append(v); hn.append(normals); he.append(edges)
+        for f in faces:
+            fva.append(len(hfv)); fvn.append(len(f)); hfv.extend(f)
+    I32 = lambda x: np.array(x, dtype=np.int32).reshape(-1)
+    m.hull_vertadr, m.hull_vertnum, m.hull_faceadr, m.hull_facenum, m.hull_edgeadr, m.hull_edgenum = I32(va), I32(vn), I32(fa), I32(fnum), I32(ea), I32(en)
+    m.hull_vert = np.concatenate(hv, axis=0) if hv else np.zeros((0, 3))
+    m.hull_face_normal = np.concatenate(hn, axis=0) if hn else np.zeros((0, 3))
+    m.hull_face_vertadr, m.hull_face_vertnum, m.hull_facevert = I32(fva), I32(fvn), I32(hfv)
+    m.hull_edge = np.concatenate(he, axis=0).astype(np.int32) if he else np.zeros((0, 2), dtype=np.int32)
 
 
 def recompile_options(m: MjModel) -> MjModel:

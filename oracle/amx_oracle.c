@@ -80,6 +80,10 @@ typedef struct amxo_model {
   REAL *actuator_gear, *actuator_gainprm, *actuator_biasprm, *actuator_ctrlrange, *actuator_forcerange;
   int *eq_obj1id, *eq_obj2id, *eq_active;
   REAL *eq_data, *eq_solref, *eq_solimp;
+  /* convex hulls of the convex-convex pairs */
+  int *pair_hull1, *pair_hull2, *hull_vertadr, *hull_vertnum, *hull_faceadr, *hull_facenum, *hull_edgeadr, *hull_edgenum;
+  int *hull_face_vertadr, *hull_face_vertnum, *hull_facevert, *hull_edge;
+  REAL *hull_vert, *hull_face_normal;
 } amxo_model;
 
 static int *dup_i(const int *src, size_t n) {
@@ -93,7 +97,7 @@ static REAL *dup_r(const double *src, size_t n) {
   return p;
 }
 
-static const int PAIR_NCON[6] = {1, 2, 4, 1, 1, 1};
+static const int PAIR_NCON[7] = {1, 2, 4, 1, 1, 1, 4};
 
 amxo_model *amxo_model_create(const amx_model_desc *d) {
   amxo_model *m = (amxo_model *)calloc(1, sizeof(amxo_model));
@@ -144,6 +148,16 @@ amxo_model *amxo_model_create(const amx_model_desc *d) {
   m->eq_active = dup_i(d->eq_active, ne);
   m->eq_data = dup_r(d->eq_data, ne * 5); m->eq_solref = dup_r(d->eq_solref, ne * 2);
   m->eq_solimp = dup_r(d->eq_solimp, ne * 5);
+  {
+    size_t nh = d->nhull, nf = d->nhullface;
+    m->pair_hull1 = dup_i(d->pair_hull1, np); m->pair_hull2 = dup_i(d->pair_hull2, np);
+    m->hull_vertadr = dup_i(d->hull_vertadr, nh); m->hull_vertnum = dup_i(d->hull_vertnum, nh);
+    m->hull_faceadr = dup_i(d->hull_faceadr, nh); m->hull_facenum = dup_i(d->hull_facenum, nh);
+    m->hull_edgeadr = dup_i(d->hull_edgeadr, nh); m->hull_edgenum = dup_i(d->hull_edgenum, nh);
+    m->hull_vert = dup_r(d->hull_vert, (size_t)d->nhullvert * 3); m->hull_face_normal = dup_r(d->hull_face_normal, nf * 3);
+    m->hull_face_vertadr = dup_i(d->hull_face_vertadr, nf); m->hull_face_vertnum = dup_i(d->hull_face_vertnum, nf);
+    m->hull_facevert = dup_i(d->hull_facevert, d->nhullfacevert); m->hull_edge = dup_i(d->hull_edge, (size_t)d->nhulledge * 2);
+  }
   m->pair_conadr = (int *)malloc((np ? np : 1) * sizeof(int));
   m->ncon = 0;
   for (size_t p = 0; p < np; p++) { m->pair_conadr[p] = m->ncon; m->ncon += PAIR_NCON[m->pair_fn[p]]; }
@@ -155,6 +169,9 @@ amxo_model *amxo_model_create(const amx_model_desc *d) {
 
 void amxo_model_destroy(amxo_model *m) {
   if (!m) return;
+  free(m->pair_hull1); free(m->pair_hull2); free(m->hull_vertadr); free(m->hull_vertnum); free(m->hull_faceadr); free(m->hull_facenum);
+  free(m->hull_edgeadr); free(m->hull_edgenum); free(m->hull_vert); free(m->hull_face_normal); free(m->hull_face_vertadr);
+  free(m->hull_face_vertnum); free(m->hull_facevert); free(m->hull_edge);
   void **ptrs[] = {(void **)&m->body_parentid, (void **)&m->body_rootid, (void **)&m->body_jntadr, (void **)&m->body_jntnum,
     (void **)&m->body_dofadr, (void **)&m->body_dofnum, (void **)&m->body_pos, (void **)&m->body_quat, (void **)&m->body_ipos,
     (void **)&m->body_iquat, (void **)&m->body_mass, (void **)&m->body_inertia, (void **)&m->body_invweight0,
@@ -490,6 +507,182 @@ static void plane_sphere_core(const REAL *n, const REAL *ppos, const REAL *spos,
 }
 static int argmax_r(const REAL *v, int n) { int k = 0; for (int i = 1; i < n; i++) if (v[i] > v[k]) k = i; return k; }
 
+/* ------------------------------------------------------------------ A9.5c convex-convex [mjx:collision_convex.convex_convex]
+ * Restated from the published description (mujoco-mjx is absent here): separating-axis test over the face
+ * normals of both hulls and the cross products of their edge pairs; the axis of least penetration decides between a face
+ * contact - reference face, incident face, Sutherland-Hodgman clipping of the incident polygon against the side planes of
+ * the reference face, 4-point manifold chosen like plane_convex's - and an edge-edge contact (closest points of the two
+ * edges; an edge pair is a candidate only if both edges are supporting edges along its axis).  Ties go to the lowest axis
+ * index (faces of hull 1, faces of hull 2, edge pairs edge1-major).  Four contact
+ * slots per pair; unused ones report dist = 1.  Contact normal points from geom1 to geom2. */
+#define CX_MAXV 32
+#define CX_MAXP 16
+static REAL cx_dbg[32]; /* last convex_convex call: np, idx[4], depth[16] (debugging aid for tools/dbg) */
+typedef struct { int nv, nf, ne; const REAL *vert, *normal; const int *fvadr, *fvnum, *fvert, *edge; } hull_view;
+static void hull_get(const amxo_model *m, int h, hull_view *H) {
+  H->nv = m->hull_vertnum[h]; H->nf = m->hull_facenum[h]; H->ne = m->hull_edgenum[h];
+  H->vert = m->hull_vert + 3 * m->hull_vertadr[h]; H->normal = m->hull_face_normal + 3 * m->hull_faceadr[h];
+  H->fvadr = m->hull_face_vertadr + m->hull_faceadr[h]; H->fvnum = m->hull_face_vertnum + m->hull_faceadr[h];
+  H->fvert = m->hull_facevert; H->edge = m->hull_edge + 2 * m->hull_edgeadr[h];
+}
+static void support_range(const REAL (*V)[3], int n, const REAL *ax, REAL *lo, REAL *hi) {
+  REAL a = (REAL)1e30, b = (REAL)-1e30;
+  for (int i = 0; i < n; i++) { REAL s = dot3(V[i], ax); if (s < a) a = s; if (s > b) b = s; }
+  *lo = a; *hi = b;
+}
+static void convex_convex(const amxo_model *m, amxo_data *d, int p) {
+  int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p], c0 = m->pair_conadr[p];
+  const REAL *pos1 = d->geom_xpos + 3 * g1, *mat1 = d->geom_xmat + 9 * g1, *pos2 = d->geom_xpos + 3 * g2, *mat2 = d->geom_xmat + 9 * g2;
+  hull_view A, B;
+  hull_get(m, m->pair_hull1[p], &A); hull_get(m, m->pair_hull2[p], &B);
+  REAL VA[CX_MAXV][3], VB[CX_MAXV][3];
+  for (int i = 0; i < A.nv; i++) { mat_mul_vec3(VA[i], mat1, A.vert + 3 * i); for (int k = 0; k < 3; k++) VA[i][k] += pos1[k]; }
+  for (int i = 0; i < B.nv; i++) { mat_mul_vec3(VB[i], mat2, B.vert + 3 * i); for (int k = 0; k < 3; k++) VB[i][k] += pos2[k]; }
+  /* --- separating axes.  Selections here and in the manifold are "the lowest index within a tolerance of the extreme", not
+   * "the first strict extreme": parallel faces, and the manifold heuristic on a parallelogram of clipped points, produce exact
+   * ties that rounding would otherwise break differently in every precision and instruction order. */
+#define CX_TOL(x) ((REAL)1e-4 * r_abs(x) + (REAL)1e-7)
+  int naxes = A.nf + B.nf + A.ne * B.ne, bt = 0;
+  REAL best = (REAL)1e30, bsgn = 1, bn[3] = {0, 0, 1};
+  for (int pass = 0; pass < 2; pass++) {
+    for (int t = 0; t < naxes; t++) {
+      REAL n[3];
+      if (t < A.nf) mat_mul_vec3(n, mat1, A.normal + 3 * t);
+      else if (t < A.nf + B.nf) mat_mul_vec3(n, mat2, B.normal + 3 * (t - A.nf));
+      else {
+        int ea = (t - A.nf - B.nf) / B.ne, eb = (t - A.nf - B.nf) % B.ne;
+        REAL da[3], db[3];
+        for (int k = 0; k < 3; k++) { da[k] = VA[A.edge[2 * ea + 1]][k] - VA[A.edge[2 * ea]][k]; db[k] = VB[B.edge[2 * eb + 1]][k] - VB[B.edge[2 * eb]][k]; }
+        normalize_n(da, 3); normalize_n(db, 3);
+        cross3(n, da, db);
+        REAL c2 = dot3(n, n);
+        if (c2 < (REAL)1e-6) continue; /* (nearly) parallel edges span no axis */
+        REAL inv = 1 / r_sqrt(c2);
+        for (int k = 0; k < 3; k++) n[k] *= inv;
+      }
+      REAL loA, hiA, loB, hiB;
+      support_range(VA, A.nv, n, &loA, &hiA); support_range(VB, B.nv, n, &loB, &hiB);
+      REAL d1 = hiA - loB, d2 = hiB - loA;
+      REAL pen = d1 < d2 ? d1 : d2, sg = d1 > d2 ? (REAL)-1 : (REAL)1;
+      if (t >= A.nf + B.nf) {
+        /* an edge pair counts only if both edges are supporting edges along the axis (the edges lie in planes normal to it, so
+         * one endpoint each decides): among parallel edges that singles out the pair that actually touches */
+        int ea = (t - A.nf - B.nf) / B.ne, eb = (t - A.nf - B.nf) % B.ne;
+        REAL sa = dot3(VA[A.edge[2 * ea]], n), sb = dot3(VB[B.edge[2 * eb]], n);
+        REAL supA = sg > 0 ? hiA : loA, supB = sg > 0 ? loB : hiB;
+        if (r_abs(sa - supA) > (REAL)1e-5 || r_abs(sb - supB) > (REAL)1e-5) continue;
+      }
+      if (pass == 0) { if (pen < best) best = pen; }
+      else if (pen <= best + CX_TOL(best)) { bt = t; bsgn = sg; memcpy(bn, n, sizeof(bn)); break; }
+    }
+  }
+  REAL N[3] = {bsgn * bn[0], bsgn * bn[1], bsgn * bn[2]}; /* from geom1 to geom2 */
+  REAL frame_n[3] = {N[0], N[1], N[2]};
+  for (int k = 0; k < 4; k++) { d->con_dist[c0 + k] = 1; for (int i = 0; i < 3; i++) d->con_pos[3 * (c0 + k) + i] = (REAL)0.5 * (pos1[i] + pos2[i]); }
+  if (bt >= A.nf + B.nf) { /* --- edge-edge: closest points of the two segments */
+    int ea = (bt - A.nf - B.nf) / B.ne, eb = (bt - A.nf - B.nf) % B.ne;
+    const REAL *a0 = VA[A.edge[2 * ea]], *a1 = VA[A.edge[2 * ea + 1]], *b0 = VB[B.edge[2 * eb]], *b1 = VB[B.edge[2 * eb + 1]];
+    REAL u[3], v[3], r[3];
+    for (int k = 0; k < 3; k++) { u[k] = a1[k] - a0[k]; v[k] = b1[k] - b0[k]; r[k] = a0[k] - b0[k]; }
+    REAL a = dot3(u, u), e = dot3(v, v), f = dot3(v, r), c = dot3(u, r), b = dot3(u, v), den = a * e - b * b;
+    REAL s = den > (REAL)1e-12 * a * e ? r_clip((b * f - c * e) / den, 0, 1) : 0;
+    REAL t = (b * s + f) / e;
+    if (t < 0) { t = 0; s = r_clip(-c / a, 0, 1); }
+    else if (t > 1) { t = 1; s = r_clip((b - c) / a, 0, 1); }
+    REAL pa[3], pb[3], dv[3];
+    for (int k = 0; k < 3; k++) { pa[k] = a0[k] + s * u[k]; pb[k] = b0[k] + t * v[k]; dv[k] = pb[k] - pa[k]; }
+    d->con_dist[c0] = dot3(dv, N);
+    for (int k = 0; k < 3; k++) d->con_pos[3 * c0 + k] = (REAL)0.5 * (pa[k] + pb[k]);
+  } else { /* --- face contact */
+    /* reference face: the face of either hull best aligned with the axis (hull 1 along +N, hull 2 along -N; ties: hull 1) */
+    int fa = 0, fb = 0;
+    REAL da = (REAL)-1e30, db = (REAL)-1e30, nw[3];
+    for (int f = 0; f < A.nf; f++) { mat_mul_vec3(nw, mat1, A.normal + 3 * f); REAL s = dot3(nw, N); if (s > da) { da = s; fa = f; } }
+    for (int f = 0; f < B.nf; f++) { mat_mul_vec3(nw, mat2, B.normal + 3 * f); REAL s = -dot3(nw, N); if (s > db) { db = s; fb = f; } }
+    int refA = da >= db - (REAL)1e-6;
+    const hull_view *R = refA ? &A : &B, *I = refA ? &B : &A;
+    const REAL (*VR)[3] = refA ? VA : VB, (*VI)[3] = refA ? VB : VA;
+    const REAL *matR = refA ? mat1 : mat2, *matI = refA ? mat2 : mat1;
+    int rf = refA ? fa : fb;
+    REAL nr[3];
+    mat_mul_vec3(nr, matR, R->normal + 3 * rf);
+    int fi = 0; REAL dmin = (REAL)1e30; /* incident face: most anti-parallel to the reference normal */
+    for (int f = 0; f < I->nf; f++) { mat_mul_vec3(nw, matI, I->normal + 3 * f); REAL s = dot3(nw, nr); if (s < dmin) { dmin = s; fi = f; } }
+    REAL poly[2][CX_MAXP][3];
+    int np_ = I->fvnum[fi], cur = 0;
+    for (int i = 0; i < np_; i++) memcpy(poly[0][i], VI[I->fvert[I->fvadr[fi] + i]], 3 * sizeof(REAL));
+    int nr_ = R->fvnum[rf];
+    for (int k = 0; k < nr_ && np_ > 0; k++) { /* Sutherland-Hodgman against the side plane through reference edge k */
+      const REAL *r0 = VR[R->fvert[R->fvadr[rf] + k]], *r1 = VR[R->fvert[R->fvadr[rf] + (k + 1) % nr_]];
+      REAL e[3] = {r1[0] - r0[0], r1[1] - r0[1], r1[2] - r0[2]}, mk[3];
+      cross3(mk, e, nr); /* outward of the reference polygon */
+      int no = 0;
+      for (int i = 0; i < np_; i++) {
+        const REAL *pc = poly[cur][i], *pn = poly[cur][(i + 1) % np_];
+        REAL dc[3] = {pc[0] - r0[0], pc[1] - r0[1], pc[2] - r0[2]}, dn[3] = {pn[0] - r0[0], pn[1] - r0[1], pn[2] - r0[2]};
+        REAL sc = dot3(dc, mk), sn = dot3(dn, mk);
+        if (sc <= 0 && no < CX_MAXP) { memcpy(poly[1 - cur][no], pc, 3 * sizeof(REAL)); no++; }
+        if ((sc <= 0) != (sn <= 0) && no < CX_MAXP) {
+          REAL tt = sc / (sc - sn);
+          for (int q = 0; q < 3; q++) poly[1 - cur][no][q] = pc[q] + tt * (pn[q] - pc[q]);
+          no++;
+        }
+      }
+      np_ = no; cur = 1 - cur;
+    }
+    if (np_ > 0) {
+      const REAL *r0 = VR[R->fvert[R->fvadr[rf]]];
+      REAL depth[CX_MAXP], dmax = (REAL)-1e30, msk[CX_MAXP];
+      for (int i = 0; i < np_; i++) {
+        REAL dv[3] = {r0[0] - poly[cur][i][0], r0[1] - poly[cur][i][1], r0[2] - poly[cur][i][2]};
+        depth[i] = dot3(dv, nr);
+        if (depth[i] > dmax) dmax = depth[i];
+      }
+      /* candidates: the penetrating points; none penetrates: the deepest alone (margin contacts) */
+      for (int i = 0; i < np_; i++) msk[i] = (dmax >= 0 ? depth[i] >= 0 : depth[i] == dmax) ? (REAL)0 : (REAL)-1e6;
+      const REAL (*P)[3] = (const REAL (*)[3])poly[cur];
+      int idx[4] = {0, 0, 0, 0};
+      REAL sc[CX_MAXP], sc2[CX_MAXP], bs, bs2;
+#define CX_PICK(arr, out) do { bs = (REAL)-1e30; for (int i = 0; i < np_; i++) if (arr[i] > bs) bs = arr[i]; \
+                               for (int i = 0; i < np_; i++) if (arr[i] >= bs - CX_TOL(bs)) { out = i; break; } } while (0)
+      CX_PICK(msk, idx[0]);
+      const REAL *a = P[idx[0]];
+      for (int i = 0; i < np_; i++) { REAL q[3] = {a[0] - P[i][0], a[1] - P[i][1], a[2] - P[i][2]}; sc[i] = dot3(q, q) + msk[i]; }
+      CX_PICK(sc, idx[1]);
+      const REAL *bp = P[idx[1]];
+      REAL amb[3] = {a[0] - bp[0], a[1] - bp[1], a[2] - bp[2]}, ab[3];
+      cross3(ab, nr, amb);
+      for (int i = 0; i < np_; i++) { REAL q[3] = {a[0] - P[i][0], a[1] - P[i][1], a[2] - P[i][2]}; sc[i] = r_abs(dot3(q, ab)) + msk[i]; }
+      CX_PICK(sc, idx[2]);
+      const REAL *cp = P[idx[2]];
+      REAL amc[3] = {a[0] - cp[0], a[1] - cp[1], a[2] - cp[2]}, bmc[3] = {bp[0] - cp[0], bp[1] - cp[1], bp[2] - cp[2]}, ac[3], bc[3];
+      cross3(ac, nr, amc); cross3(bc, nr, bmc);
+      bs2 = (REAL)-1e30;
+      for (int i = 0; i < np_; i++) {
+        REAL q[3] = {bp[0] - P[i][0], bp[1] - P[i][1], bp[2] - P[i][2]}, q2[3] = {a[0] - P[i][0], a[1] - P[i][1], a[2] - P[i][2]};
+        sc[i] = r_abs(dot3(q, bc)) + msk[i]; sc2[i] = r_abs(dot3(q2, ac)) + msk[i];
+      }
+      bs = (REAL)-1e30;
+      for (int i = 0; i < np_; i++) { if (sc[i] > bs) bs = sc[i]; if (sc2[i] > bs2) bs2 = sc2[i]; }
+      if (bs2 > bs + CX_TOL(bs)) CX_PICK(sc2, idx[3]); else CX_PICK(sc, idx[3]); /* farthest from edge bc, or - clearly farther - from edge ac */
+      cx_dbg[0] = (REAL)np_;
+      for (int k = 0; k < 4; k++) cx_dbg[1 + k] = (REAL)idx[k];
+      for (int i = 0; i < np_; i++) cx_dbg[5 + i] = depth[i];
+      for (int k = 0; k < 4; k++) {
+        int unique = 1;
+        for (int j = 0; j < k; j++) if (idx[j] == idx[k]) unique = 0;
+        if (!unique) continue;
+        d->con_dist[c0 + k] = -depth[idx[k]];
+        for (int q = 0; q < 3; q++) d->con_pos[3 * (c0 + k) + q] = P[idx[k]][q] + (REAL)0.5 * depth[idx[k]] * nr[q];
+      }
+    }
+    for (int q = 0; q < 3; q++) frame_n[q] = refA ? nr[q] : -nr[q];
+  }
+  REAL frame[9];
+  make_frame(frame, frame_n);
+  for (int k = 0; k < 4; k++) memcpy(d->con_frame + 9 * (c0 + k), frame, sizeof(frame));
+}
+
 static void collision(const amxo_model *m, amxo_data *d) {
   for (int p = 0; p < m->npair; p++) {
     int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p], c0 = m->pair_conadr[p], fn = m->pair_fn[p];
@@ -497,6 +690,7 @@ static void collision(const amxo_model *m, amxo_data *d) {
     const REAL *pos2 = d->geom_xpos + 3 * g2, *mat2 = d->geom_xmat + 9 * g2;
     const REAL *size1 = m->geom_size + 3 * g1, *size2 = m->geom_size + 3 * g2;
     for (int k = 0; k < PAIR_NCON[fn]; k++) d->con_pair[c0 + k] = p;
+    if (fn == 6) { convex_convex(m, d, p); continue; }
     if (fn == 0) { /* plane-sphere */
       REAL n[3] = {mat1[2], mat1[5], mat1[8]};
       plane_sphere_core(n, pos1, pos2, size2[0], d->con_dist + c0, d->con_pos + 3 * c0);
@@ -1056,6 +1250,7 @@ int amxo_get(const amxo_model *m, const amxo_data *d, const char *name, REAL *ou
   F("efc_J", d->efc_J, d->nefc * nv) F("efc_D", d->efc_D, d->nefc) F("efc_aref", d->efc_aref, d->nefc)
   F("efc_pos", d->efc_pos, d->nefc) F("efc_force", d->efc_force, d->nefc)
 #undef F
+  if (!strcmp(name, "cx_dbg")) { for (int i = 0; i < 21 && i < cap; i++) out[i] = cx_dbg[i]; return 21; }
   if (!strcmp(name, "nefc")) { if (cap > 0) out[0] = (REAL)d->nefc; return 1; }
   if (!strcmp(name, "solver_niter")) { if (cap > 0) out[0] = (REAL)d->solver_niter; return 1; }
   if (!strcmp(name, "time")) { if (cap > 0) out[0] = d->time; return 1; }

@@ -26,12 +26,12 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.lib()
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.amx_version() == 1
+    assert lib.amx_version() == 2
 
 
 def test_desc_layout_matches_c(tmp_path):
     """sizeof/offsetof of amx_model_desc as gcc sees the header vs the ctypes mirror."""
-    fields = ["version", "nq", "nconvexvert", "timestep", "gravity", "meaninertia", "iterations", "disableflags",
+    fields = ["version", "nq", "nconvexvert", "nhull", "nhulledge", "pair_hull1", "hull_vert", "hull_face_normal", "hull_edge", "timestep", "gravity", "meaninertia", "iterations", "disableflags",
               "body_parentid", "body_invweight0", "jnt_type", "qpos_spring", "dof_invweight0", "geom_size", "pair_geom1",
               "convex_vert", "actuator_trnid", "actuator_forcerange", "eq_obj1id", "eq_solimp"]
     src = tmp_path / "layout.c"

@@ -1,0 +1,177 @@
+"""Convex-convex contact (reference models/barrett_hand/bh280.xml:58-183 needs it for
+finger-finger contact): separating-axis test over face normals and edge-pair cross products, Sutherland-Hodgman clipping
+of the incident face, 4-point manifold.  CPU part: closed-form geometry and a resting two-box stack against the oracle.
+GPU part (through the C ABI): the HIP path against the oracle on seeded random configurations."""
+import numpy as np
+import pytest
+
+from ambersim_amd.mjcf import MjModel
+from oracle.oracle import Oracle
+
+TWO = """
+<mujoco><option timestep="0.002" iterations="50" ls_iterations="50" gravity="0 0 {g}"/><worldbody>
+  <body name="a" pos="0 0 0">{ja}<geom name="ga" type="box" size="0.5 0.5 0.5" mass="1"/></body>
+  <body name="b" pos="{pb}" {qb}><freejoint/><geom name="gb" {gb} mass="1"/></body>
+</worldbody>{asset}</mujoco>
+"""
+
+
+def two(pb, qb="", gb='type="box" size="0.5 0.5 0.5"', ja="<freejoint/>", g=0, asset=""):
+    return MjModel.from_xml_string(TWO.format(pb=pb, qb=qb, gb=gb, ja=ja, g=g, asset=asset))
+
+
+def contacts(mj, qpos=None):
+    o = Oracle(mj)
+    o.set_state(mj.qpos0 if qpos is None else qpos, np.zeros(mj.nv), np.zeros(mj.nu))
+    o.forward()
+    n = o.ncon
+    return o.get("con_dist"), o.get("con_pos", (n, 3)), o.get("con_frame", (n, 3, 3))
+
+
+def test_hull_tables():
+    """Host compiler: a box is 8 vertices, 6 quads (outward, counter-clockwise), 12 edges; a mesh hull's coplanar triangles merge."""
+    mj = two("0.2 0.1 0.9")
+    assert mj.npair == 1 and mj.pair_fn.tolist() == [6] and mj.ncon == 4
+    assert mj.hull_vertnum.tolist() == [8, 8] and mj.hull_facenum.tolist() == [6, 6] and mj.hull_edgenum.tolist() == [12, 12]
+    v = mj.hull_vert[:8]
+    for f in range(6):
+        ids = mj.hull_facevert[mj.hull_face_vertadr[f]: mj.hull_face_vertadr[f] + 4]
+        n = np.cross(v[ids[1]] - v[ids[0]], v[ids[2]] - v[ids[0]])
+        assert np.allclose(n / np.linalg.norm(n), mj.hull_face_normal[f]) and mj.hull_face_normal[f] @ v[ids].mean(0) > 0
+    verts = " ".join(f"{x} {y} {z}" for x in (-.3, .3) for y in (-.2, .2) for z in (-.1, .1))  # a box given as a mesh
+    mj = two("0 0 0.55", gb='type="mesh" mesh="m"', asset=f'<asset><mesh name="m" vertex="{verts}"/></asset>')
+    assert mj.hull_facenum.tolist() == [6, 6] and mj.hull_face_vertnum.tolist() == [4] * 12 and mj.hull_edgenum.tolist() == [12, 12]
+
+
+def test_face_face_overlap_rectangle():
+    """Two axis-aligned unit cubes, the upper one shifted by (0.2, 0.1) and sunk 0.1 into the lower: the manifold is the four
+    corners of the overlap rectangle [-0.3, 0.5] x [-0.4, 0.5], depth 0.1, midway between the two faces, normal +z."""
+    dist, pos, frame = contacts(two("0.2 0.1 0.9"))
+    act = dist < 0
+    # (on an exactly symmetric rectangle the manifold heuristic's last step ties between the fourth corner and the first
+    # point, as in plane_convex: a duplicate is reported inactive, dist = 1)
+    assert act.sum() >= 3 and np.allclose(dist[act], -0.1, atol=1e-12) and np.all(dist[~act] == 1.0)
+    corners = {(round(p[0], 9), round(p[1], 9)) for p in pos[act]}
+    assert len(corners) == act.sum() and corners <= {(-0.3, -0.4), (-0.3, 0.5), (0.5, -0.4), (0.5, 0.5)}
+    assert np.allclose(pos[act, 2], 0.45, atol=1e-12)
+    assert np.allclose(frame[:, 0], [0, 0, 1]) and all(np.allclose(f @ f.T, np.eye(3), atol=1e-12) for f in frame)
+    # the upper cube turned by 25 deg about z: the overlap polygon has no symmetry, four distinct manifold points of depth 0.1
+    dist, pos, frame = contacts(two("0.2 0.1 0.9", qb='euler="0 0 25"'))
+    assert (dist < 0).all() and np.allclose(dist, -0.1, atol=1e-12) and len({tuple(np.round(p, 6)) for p in pos}) == 4
+    assert np.allclose(pos[:, 2], 0.45, atol=1e-12) and (np.abs(pos[:, :2]) <= 0.5 + 1e-12).all()
+    # separated by 0.05: one inactive slot reports the gap, the others stay inactive
+    dist, pos, _ = contacts(two("0.2 0.1 1.05"))
+    assert (dist > 0).all() and np.isclose(dist.min(), 0.05, atol=1e-12)
+    # geom order does not matter for the normal convention: it always points from geom1 to geom2
+    dist, pos, frame = contacts(two("0.2 0.1 -0.9"))
+    assert np.allclose(dist[dist < 0], -0.1, atol=1e-12) and (dist < 0).sum() >= 3 and np.allclose(frame[:, 0], [0, 0, -1])
+
+
+def test_edge_edge_crossed_cubes():
+    """Lower cube rotated 45 deg about y (top edge along y at height r = 0.5 sqrt 2), upper cube rotated 45 deg about x
+    (bottom edge along x), sunk 0.05: one contact where the edges cross, depth 0.05, normal +z."""
+    r = 0.5 * np.sqrt(2)
+    s, c = np.sin(np.pi / 8), np.cos(np.pi / 8)
+    mj = two(f"0 0 {2 * r - 0.05}", qb=f'quat="{c} {s} 0 0"')
+    q = mj.qpos0.copy()
+    q[3:7] = [c, 0, s, 0]
+    dist, pos, frame = contacts(mj, q)
+    act = dist < 0
+    assert act.sum() == 1 and np.isclose(dist[act][0], -0.05, atol=1e-9)
+    assert np.allclose(pos[act][0], [0, 0, r - 0.025], atol=1e-9) and np.allclose(frame[0, 0], [0, 0, 1], atol=1e-9)
+
+
+def test_vertex_into_face():
+    """An octahedron's lower tip 0.03 inside the top face of a cube: the deepest manifold point is the tip, depth 0.03."""
+    verts = "0.2 0 0  -0.2 0 0  0 0.2 0  0 -0.2 0  0 0 0.2  0 0 -0.2"
+    mj = two("0.1 0.05 0.67", gb='type="mesh" mesh="o"', asset=f'<asset><mesh name="o" vertex="{verts}"/></asset>')
+    assert mj.hull_facenum.tolist() == [6, 8]
+    dist, pos, frame = contacts(mj)
+    k = int(np.argmin(dist))
+    assert np.isclose(dist[k], -0.03, atol=1e-12) and np.allclose(pos[k], [0.1, 0.05, 0.485], atol=1e-12)
+    assert np.allclose(frame[k, 0], [0, 0, 1])
+
+
+def test_resting_two_box_stack():
+    """A box on a box on the plane, at rest: the constraint force on the upper box's vertical translation is its weight, on
+    the lower box the upper one's weight presses down and the plane carries both (qfrc_constraint = J' f)."""
+    xml = """<mujoco><option timestep="0.002" iterations="50" ls_iterations="50"/><worldbody><geom type="plane" size="5 5 .1"/>
+      <body pos="0 0 0.1"><freejoint/><geom type="box" size=".2 .2 .1" mass="2"/></body>
+      <body pos="0.03 0.02 0.3" euler="0 0 20"><freejoint/><geom type="box" size=".1 .1 .1" mass="0.5"/></body></worldbody></mujoco>"""
+    mj = MjModel.from_xml_string(xml)  # (the upper box is yawed: an axis-aligned stack ties the manifold heuristic and chatters at 1e-2 rad/s)
+    assert sorted(mj.pair_fn.tolist()) == [2, 2, 6] and mj.ncon == 12
+    o = Oracle(mj)
+    xs = o.rollout(np.concatenate([mj.qpos0, np.zeros(12)]), np.zeros((1, 1000, 0)))[0]
+    assert np.abs(xs[-1, mj.nq:]).max() < 5e-3
+    o.set_state(xs[-1, :mj.nq], xs[-1, mj.nq:], np.zeros(0)); o.forward()
+    f = o.get("qfrc_constraint")
+    assert abs(f[8] - 0.5 * 9.81) < 0.03 * 0.5 * 9.81      # upper box: its own weight
+    assert abs(f[2] - 2.0 * 9.81) < 0.03 * 2.0 * 9.81      # lower box: plane force (2.5 g) minus the upper box's push (0.5 g)
+    assert xs[-1, 9] > 0.295 and xs[-1, 2] > 0.095          # sub-millimetre-scale penetrations only
+
+
+@pytest.mark.gpu
+def test_convex_convex_gpu_vs_oracle():
+    """The HIP path on seeded random box-box, box-mesh and mesh-mesh configurations (touching, penetrating, separated;
+    generic orientations so that no manifold choice is a tie): contact distances of the active contacts, one step and
+    five steps against the fp64 oracle (1e-5 / 5e-5, as for the other contact models), plus the two-box stack at rest."""
+    import torch
+    from ambersim_amd import mjx
+    dev = torch.device("cuda", 0)
+    octa = "0.2 0 0  -0.2 0 0  0 0.2 0  0 -0.2 0  0 0 0.25  0 0 -0.15"
+    wedge = " ".join(f"{x} {y} {z}" for x in (-.25, .25) for y in (-.15, .15) for z in (-.1,)) + " 0.25 0 0.12 -0.25 0 0.12"
+    asset = f'<asset><mesh name="o" vertex="{octa}"/><mesh name="w" vertex="{wedge}"/></asset>'
+    cases = [("box-box", 'type="box" size="0.3 0.2 0.25"', 'type="box" size="0.5 0.5 0.5"'),
+             ("box-mesh", 'type="mesh" mesh="o"', 'type="box" size="0.5 0.5 0.5"'),
+             ("mesh-mesh", 'type="mesh" mesh="o"', 'type="mesh" mesh="w"')]
+    for name, gb, ga in cases:
+        xml = TWO.format(pb="0 0 0.7", qb="", gb=gb, ja="<freejoint/>", g=-9.81, asset=asset).replace('type="box" size="0.5 0.5 0.5" mass="1"', ga + ' mass="1"', 1)
+        mj = MjModel.from_xml_string(xml.replace('iterations="50" ls_iterations="50"', 'iterations="3" ls_iterations="5"'))
+        assert mj.pair_fn.tolist() == [6], name
+        model = mjx.put_model(mj, dev)
+        rng = np.random.default_rng({"box-box": 11, "box-mesh": 12, "mesh-mesh": 13}[name])
+        nenv = 32
+        q = np.tile(mj.qpos0, (nenv, 1))
+        for k in range(nenv):
+            for a in (3, 10):
+                quat = np.array([1.0, 0, 0, 0]) + 0.5 * rng.uniform(-1, 1, 4)
+                q[k, a:a + 4] = quat / np.linalg.norm(quat)
+            zlo, zhi, xy = {"box-box": (0.6, 0.95, 0.3), "box-mesh": (0.5, 0.8, 0.3), "mesh-mesh": (0.1, 0.4, 0.1)}[name]
+            q[k, 7:10] = [xy * rng.uniform(-1, 1), xy * rng.uniform(-1, 1), rng.uniform(zlo, zhi)]
+        v = 0.3 * rng.standard_normal((nenv, mj.nv))
+        x0 = np.concatenate([q, v], axis=1).astype(np.float32)
+        us = np.zeros((nenv, 5, 0), dtype=np.float32)
+        xs = mjx.rollout(model, torch.tensor(x0), torch.tensor(us)).cpu().numpy().astype(np.float64)
+        ref = Oracle(mj, np.float64).rollout(x0, us)
+        ref32 = Oracle(mj, np.float32).rollout(x0, us).astype(np.float64)
+        nact = 0
+        o = Oracle(mj, np.float64)
+        for k in range(nenv):
+            o.set_state(x0[k, :mj.nq], x0[k, mj.nq:], np.zeros(0)); o.forward()
+            nact += int((o.get("con_dist") < 0).sum())
+        assert nact >= nenv // 2, (name, nact)  # the draw does exercise contacts
+        # per env: distance to the fp64 oracle, or - where fp32 rounding flips one of the manifold heuristic's structural ties
+        # (on a parallelogram of clipped points its last pick ties exactly between the fourth corner and the first point: the
+        # fp64 and the fp32 oracle then disagree with each other) - to the fp32 oracle, which breaks the tie as the kernel does
+        def err(t):
+            e64 = np.abs(xs[:, t] - ref[:, t]).max(axis=1) / np.maximum(1.0, np.abs(ref[:, t]).max(axis=1))
+            e32 = np.abs(xs[:, t] - ref32[:, t]).max(axis=1) / np.maximum(1.0, np.abs(ref32[:, t]).max(axis=1))
+            return np.minimum(e64, e32), e64
+        (e1, e1_64), (e5, e5_64) = err(1), err(5)
+        floor1 = (np.abs(ref32[:, 1] - ref[:, 1]).max(axis=1) / np.maximum(1.0, np.abs(ref[:, 1]).max(axis=1)))
+        floor1 = np.median(floor1) * 10  # typical fp32 distance of the CPU oracle itself (robust to envs where its own tie-breaks flip)
+        print(f"convex-convex {name}: {nact} active contacts over {nenv} envs; 1-step err {e1.max():.2e} (fp32 oracle's own scale {floor1:.2e}; "
+              f"{(e1_64 < 1e-5).mean():.2f} of the envs within 1e-5 of the fp64 oracle), 5-step err median {np.median(e5):.2e} max {e5.max():.2e}")
+        # contacts here start centimetres deep (random placement): the first step's penalty forces are large and the fp32 floor
+        # sits above 1e-5 for a few envs (3e-5 bound); most envs, and every env after five steps, are inside the usual bounds
+        assert e1.max() < 3e-5 and (e1_64 < 1e-5).mean() >= 0.75, (name, e1.max(), floor1)
+        assert e5.max() < 5e-5, (name, e5.max())
+        assert np.median(e5) < 5e-5, (name, np.median(e5))
+    xml = """<mujoco><option timestep="0.002" iterations="10" ls_iterations="10"/><worldbody><geom type="plane" size="5 5 .1"/>
+      <body pos="0 0 0.1"><freejoint/><geom type="box" size=".2 .2 .1" mass="2"/></body>
+      <body pos="0.03 0.02 0.3" euler="0 0 20"><freejoint/><geom type="box" size=".1 .1 .1" mass="0.5"/></body></worldbody></mujoco>"""
+    mj = MjModel.from_xml_string(xml)
+    model = mjx.put_model(mj, dev)
+    x0 = np.concatenate([mj.qpos0, np.zeros(12)]).astype(np.float32)
+    xs = mjx.rollout(model, torch.tensor(x0), torch.zeros((1, 1000, 0))).cpu().numpy()[0]
+    assert np.isfinite(xs).all() and np.abs(xs[-1, mj.nq:]).max() < 1e-2 and xs[-1, 9] > 0.295 and xs[-1, 2] > 0.095

@@ -160,6 +160,30 @@ def test_forward_outputs(cases, golden, name):
             assert (cd[~act] > 0).all()
 
 
+def test_specialised_and_generic_kernels(cases, golden):
+    """The shipped models run kernels compiled for exactly their launch plan (csrc/amx_specs_gen.h); AMX_NO_SPEC=1 forces the
+    generic kernels, which read the plan from the descriptor.  Both are checked against the golden fp64 trajectories (the
+    eliminations differ - tree-sparse leaves-first vs dense in dof order - so the two paths agree to rounding, not bitwise),
+    and the same model with other solver options falls back to the generic kernels by itself."""
+    from ambersim_amd import mjx
+    for name in ("quadruped", "biped", "bh280", "pendulum"):
+        mj, model, x0, us = cases[name]
+        assert model._h.query("specialised") == 1, name
+        os.environ["AMX_NO_SPEC"] = "1"
+        try:
+            generic = mjx.put_model(mj, model.device)
+        finally:
+            del os.environ["AMX_NO_SPEC"]
+        assert generic._h.query("specialised") == 0
+        ref = golden[name + "_xs"]
+        a, b = gpu_rollout(model, x0, us), gpu_rollout(generic, x0, us)
+        tol = 3e-5 if name == "bh280" else TOL
+        assert rel(a[:, 1], ref[:, 1]) < tol and rel(b[:, 1], ref[:, 1]) < tol, name
+        assert rel(a[:, 3], b[:, 3]) < 5e-5, name
+    mj, model, x0, us = cases["quadruped"]
+    assert model.replace(opt=model.opt.replace(iterations=2))._h.query("specialised") == 0
+
+
 def test_step_api_matches_rollout_bitwise(cases):
     """amx_step (state through HBM each call, warm start carried) and amx_rollout (state in LDS) run the same phases:
     identical bits after 20 steps."""
