@@ -308,6 +308,22 @@ def _convex_hull(verts: np.ndarray):
     return hv, faces
 
 
+def _farthest_subset(hv: np.ndarray, n: int) -> np.ndarray:
+    """At most n of the hull vertices, chosen greedily: the two extremes of the longest axis, then repeatedly the vertex
+    farthest from those already chosen (deterministic; an inner approximation of the hull, like qhull's early termination
+    that MuJoCo's `maxhullvert` uses)."""
+    if len(hv) <= n:
+        return hv
+    ax = int(np.argmax(hv.max(0) - hv.min(0)))
+    chosen = [int(np.argmin(hv[:, ax])), int(np.argmax(hv[:, ax]))]
+    d = np.minimum(np.linalg.norm(hv - hv[chosen[0]], axis=1), np.linalg.norm(hv - hv[chosen[1]], axis=1))
+    while len(chosen) < n:
+        k = int(np.argmax(d))
+        chosen.append(k)
+        d = np.minimum(d, np.linalg.norm(hv - hv[k], axis=1))
+    return hv[sorted(chosen)]
+
+
 def _polyhedron_mass_props(v: np.ndarray, faces: np.ndarray):
     """Volume, centre of mass and unit-density inertia about the COM of a closed triangle mesh."""
     vol, com = 0.0, np.zeros(3)
@@ -401,6 +417,11 @@ class _Compiler:
                 scale = _floats(at.get("scale", "1 1 1"), 3)
                 verts = verts * scale
                 hv, faces = _convex_hull(verts)
+                maxhull = int(at.get("maxhullvert", "-1"))  # MuJoCo's mesh attribute: cap on the hull's vertex count
+                if maxhull != -1:
+                    if maxhull < 4:
+                        raise ValueError("maxhullvert must be -1 or at least 4")
+                    hv, faces = _convex_hull(_farthest_subset(hv, maxhull))
                 self.meshes[name] = dict(vert=hv, face=faces)
 
     # -- geoms

@@ -175,3 +175,74 @@ def test_convex_convex_gpu_vs_oracle():
     x0 = np.concatenate([mj.qpos0, np.zeros(12)]).astype(np.float32)
     xs = mjx.rollout(model, torch.tensor(x0), torch.zeros((1, 1000, 0))).cpu().numpy()[0]
     assert np.isfinite(xs).all() and np.abs(xs[-1, mj.nq:]).max() < 1e-2 and xs[-1, 9] > 0.295 and xs[-1, 2] > 0.095
+
+
+TOUCH_Q = np.array([1.89136115, 0.44176919, 1.60875547, 2.28816911, 0.29384365, 1.74812746, 2.37906276, 0.68614988])  # distal links of fingers 1 and 2 interpenetrate here
+
+
+def twofingers_model():
+    import os
+    from conftest import GOLDEN
+    mj = MjModel.from_xml_path(os.path.join(GOLDEN, "bh280_twofingers.xml"))
+    mj.opt = mj.opt.replace(timestep=0.002, iterations=4, ls_iterations=8)
+    from ambersim_amd.mjcf import recompile_options
+    return recompile_options(mj)
+
+
+def test_barrett_two_fingers_touch():
+    """The reference's Barrett hand with one 16-vertex hull on each distal link of fingers 1 and 2 (fixture derived from
+    reference models/barrett_hand/bh280.xml by tests/golden/make_bh280_twofingers.py): the mesh-mesh pair is planned as
+    convex-convex, the fingertips collide in the closed pose, and the contact pushes them apart (the joint-space constraint
+    force opens the distal joints; penetration decreases over the rollout)."""
+    mj = twofingers_model()
+    assert (mj.nq, mj.nu, mj.neq) == (8, 4, 4) and mj.pair_fn.tolist() == [6] and mj.ncon == 4
+    assert mj.hull_vertnum.tolist() == [16, 16] and max(mj.hull_facenum) <= 32 and max(mj.hull_edgenum) <= 64
+    o = Oracle(mj)
+    o.set_state(TOUCH_Q, np.zeros(8), np.zeros(4)); o.forward()
+    d0 = o.get("con_dist")
+    assert d0.min() < -0.01 and o.get("nefc")[0] >= 4 + 4  # 4 equalities + at least one contact's pyramid
+    xs = o.rollout(np.concatenate([TOUCH_Q, np.zeros(8)]), np.zeros((1, 200, 4)))[0]
+    assert np.isfinite(xs).all()
+    o.set_state(xs[-1, :8], xs[-1, 8:], np.zeros(4)); o.forward()
+    assert o.get("con_dist").min() > 0.5 * d0.min()  # pushed out of the deep overlap
+
+
+def test_two_finger_fixture_is_current():
+    """tests/golden/bh280_twofingers.xml is what its generator derives from the reference model (skipped where the reference is absent)."""
+    import os, subprocess, sys, tempfile
+    from conftest import GOLDEN
+    if not os.path.exists("/root/reference/ambersim/models/barrett_hand/bh280.xml"):
+        pytest.skip("reference not present on this machine")
+    before = open(os.path.join(GOLDEN, "bh280_twofingers.xml")).read()
+    subprocess.run([sys.executable, os.path.join(GOLDEN, "make_bh280_twofingers.py")], check=True, capture_output=True)
+    assert open(os.path.join(GOLDEN, "bh280_twofingers.xml")).read() == before
+
+
+@pytest.mark.gpu
+def test_barrett_two_fingers_gpu_vs_oracle():
+    """The two-finger Barrett fixture on the GPU: poses around the touching one (some in contact, some not), one step within
+    3e-5 of the fp64 oracle (the Barrett hand's stiff equality rows, as in test_single_step_parity) and ten steps finite
+    with the same contact activity as the oracle."""
+    import torch
+    from ambersim_amd import mjx
+    mj = twofingers_model()
+    dev = torch.device("cuda", 0)
+    model = mjx.put_model(mj, dev)
+    rng = np.random.default_rng(21)
+    nenv = 32
+    q = np.clip(TOUCH_Q + 0.25 * rng.standard_normal((nenv, 8)), mj.jnt_range[:, 0] + 0.01, mj.jnt_range[:, 1] - 0.01)
+    x0 = np.concatenate([q, 0.2 * rng.standard_normal((nenv, 8))], axis=1).astype(np.float32)
+    us = rng.uniform(-1, 1, (nenv, 10, 4)).astype(np.float32)
+    xs = mjx.rollout(model, torch.tensor(x0), torch.tensor(us)).cpu().numpy().astype(np.float64)
+    ref = Oracle(mj, np.float64).rollout(x0, us)
+    ref32 = Oracle(mj, np.float32).rollout(x0, us).astype(np.float64)
+    o = Oracle(mj, np.float64)
+    nact = 0
+    for k in range(nenv):
+        o.set_state(x0[k, :8], x0[k, 8:], us[k, 0]); o.forward()
+        nact += int((o.get("con_dist") < 0).any())
+    assert 4 <= nact <= nenv - 4, nact  # both regimes are in the draw
+    e1 = np.minimum(np.abs(xs[:, 1] - ref[:, 1]).max(axis=1), np.abs(xs[:, 1] - ref32[:, 1]).max(axis=1)) / np.maximum(1.0, np.abs(ref[:, 1]).max(axis=1))
+    e10 = np.minimum(np.abs(xs[:, 10] - ref[:, 10]).max(axis=1), np.abs(xs[:, 10] - ref32[:, 10]).max(axis=1)) / np.maximum(1.0, np.abs(ref[:, 10]).max(axis=1))
+    print(f"bh280 two fingers: {nact} of {nenv} envs in contact; 1-step err {e1.max():.2e}, 10-step err median {np.median(e10):.2e} max {e10.max():.2e}")
+    assert np.isfinite(xs).all() and e1.max() < 3e-5 and np.median(e10) < 1e-4
