@@ -1774,15 +1774,24 @@ struct Env {
     else spd_solve<G>(m.nchol(), Ho, ldm, nv, dofoff(D_GRAD), dofoff(D_MGRAD), gl, gb4, m_rot);
   }
 
-  DEV LSPoint ls_point(float alpha, bool validA, bool validB, bool iseq, float g0, float g1, float g2) const {
+  // One trial step length: the quadratic model of the cost along the search direction under the active set at alpha.
+  // `derivs` fills d0, d1 (first and second derivative); `full` also the cost.  The bracketing loop below only ever compares
+  // derivatives, so it evaluates `derivs` (two group reductions instead of three, three-field selects instead of four) and
+  // the two bracket ends are evaluated in full once, after the loop - the same expressions as inside MJX's loop, evaluated
+  // at the same alphas, so the accepted step is the one the reference's search takes.
+  DEV LSPoint ls_point(float alpha, bool validA, bool validB, bool iseq, float g0, float g1, float g2, bool full) const {
     const bool actA = validA && (aJaref + alpha * aJv < 0 || iseq), actB = validB && (cJaref + alpha * cJv < 0);
-    float q0 = (actA ? 0.5f * aJaref * aJaref * aD : 0.0f) + (actB ? 0.5f * cJaref * cJaref * cD : 0.0f);
     float q1 = (actA ? aJv * aJaref * aD : 0.0f) + (actB ? cJv * cJaref * cD : 0.0f);
     float q2 = (actA ? 0.5f * aJv * aJv * aD : 0.0f) + (actB ? 0.5f * cJv * cJv * cD : 0.0f);
-    q0 = gsum<G>(q0) + g0; q1 = gsum<G>(q1) + g1; q2 = gsum<G>(q2) + g2;
+    q1 = gsum<G>(q1) + g1; q2 = gsum<G>(q2) + g2;
     LSPoint r;
     r.alpha = alpha;
-    r.cost = alpha * alpha * q2 + alpha * q1 + q0;
+    r.cost = 0.0f;
+    if (full) {
+      float q0 = (actA ? 0.5f * aJaref * aJaref * aD : 0.0f) + (actB ? 0.5f * cJaref * cJaref * cD : 0.0f);
+      q0 = gsum<G>(q0) + g0;
+      r.cost = alpha * alpha * q2 + alpha * q1 + q0;
+    }
     r.d0 = 2 * alpha * q2 + q1;
     r.d1 = 2 * q2 + (q2 == 0.0f ? MINVAL : 0.0f);
     return r;
@@ -1805,40 +1814,45 @@ struct Env {
     PROF(21);
     const float gtol = m.tolerance() * m.ls_tolerance() * sqrtf(sn) * m.scale();
     const bool validA = gl < nA(), validB = gl < nB(), iseq = gl < m.neq();
-#define POINT(al) ls_point((al), validA, validB, iseq, gauss, g1, g2)
-#define PICK(c, a, b) { (c) ? (a).alpha : (b).alpha, (c) ? (a).cost : (b).cost, (c) ? (a).d0 : (b).d0, (c) ? (a).d1 : (b).d1 }
+    struct LSD { float alpha, d0, d1; };
+#define POINT(al) ls_point((al), validA, validB, iseq, gauss, g1, g2, true)
+#define DERIV(al) [&](float a_) { const LSPoint t_ = ls_point(a_, validA, validB, iseq, gauss, g1, g2, false); return LSD{t_.alpha, t_.d0, t_.d1}; }(al)
+#define PICK(c, a, b) { (c) ? (a).alpha : (b).alpha, (c) ? (a).d0 : (b).d0, (c) ? (a).d1 : (b).d1 }
     const LSPoint p0 = POINT(0.0f);
-    const LSPoint p1 = POINT(p0.alpha - p0.d0 / p0.d1);
+    const LSD p0d = {p0.alpha, p0.d0, p0.d1};
+    const LSD p1 = DERIV(p0.alpha - p0.d0 / p0.d1);
     const bool first = p1.d0 < p0.d0;
-    LSPoint lo = PICK(first, p1, p0), hi = PICK(first, p0, p1);
+    LSD lo = PICK(first, p1, p0d), hi = PICK(first, p0d, p1);
     bool swap = true;
     for (int it = 0; it < m.ls_iterations(); ++it) {
       bool done = !swap;
       done = done || ((lo.d0 < 0) && (lo.d0 > -gtol));
       done = done || ((hi.d0 > 0) && (hi.d0 < gtol));
       if (!wave_any(!done && alive)) break;  // every group of the wave has finished its search
-      const LSPoint lo_next = POINT(lo.alpha - lo.d0 / lo.d1);
-      const LSPoint hi_next = POINT(hi.alpha - hi.d0 / hi.d1);
-      const LSPoint mid = POINT(0.5f * (lo.alpha + hi.alpha));
-      LSPoint nlo = lo, nhi = hi;
+      const LSD lo_next = DERIV(lo.alpha - lo.d0 / lo.d1);
+      const LSD hi_next = DERIV(hi.alpha - hi.d0 / hi.d1);
+      const LSD mid = DERIV(0.5f * (lo.alpha + hi.alpha));
+      LSD nlo = lo, nhi = hi;
       const bool s_lo_next = (nlo.d0 > 0) || (nlo.d0 < lo_next.d0);
-      { const LSPoint t = PICK(s_lo_next, lo_next, nlo); nlo = t; }
+      { const LSD t = PICK(s_lo_next, lo_next, nlo); nlo = t; }
       const bool s_lo_mid = (mid.d0 < 0) && (nlo.d0 < mid.d0);
-      { const LSPoint t = PICK(s_lo_mid, mid, nlo); nlo = t; }
+      { const LSD t = PICK(s_lo_mid, mid, nlo); nlo = t; }
       const bool s_hi_next = (nhi.d0 < 0) || (nhi.d0 > hi_next.d0);
-      { const LSPoint t = PICK(s_hi_next, hi_next, nhi); nhi = t; }
+      { const LSD t = PICK(s_hi_next, hi_next, nhi); nhi = t; }
       const bool s_hi_mid = (mid.d0 > 0) && (nhi.d0 > mid.d0);
-      { const LSPoint t = PICK(s_hi_mid, mid, nhi); nhi = t; }
+      { const LSD t = PICK(s_hi_mid, mid, nhi); nhi = t; }
       // a group whose search has ended keeps its bracket
-      { const LSPoint t = PICK(done, lo, nlo); lo = t; }
-      { const LSPoint t = PICK(done, hi, nhi); hi = t; }
+      { const LSD t = PICK(done, lo, nlo); lo = t; }
+      { const LSD t = PICK(done, hi, nhi); hi = t; }
       swap = done ? false : (s_lo_next || s_lo_mid || s_hi_next || s_hi_mid);
     }
-#undef POINT
-#undef PICK
     PROF(22);
-    const bool improved = alive && ((lo.cost < p0.cost) || (hi.cost < p0.cost));
-    const float alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
+    const LSPoint lo_f = POINT(lo.alpha), hi_f = POINT(hi.alpha);  // costs of the two bracket ends
+#undef POINT
+#undef DERIV
+#undef PICK
+    const bool improved = alive && ((lo_f.cost < p0.cost) || (hi_f.cost < p0.cost));
+    const float alpha = lo_f.cost < hi_f.cost ? lo.alpha : hi.alpha;
     if (improved) {
       if (gl < nv) { dof(D_QACC, gl) += alpha * dof(D_SEARCH, gl); dof(D_MA, gl) += alpha * mv; }
       aJaref += alpha * aJv;
