@@ -38,7 +38,7 @@ def test_network_wrapper_checks_sizes():
 
 def test_tanh_normal_log_prob_matches_torch():
     d = NormalTanhDistribution(2)
-    p = torch.randn(50, 4)
+    p = torch.randn(50, 4, generator=torch.Generator().manual_seed(1))  # seeded: the torch reference saturates for extreme draws (tanh(raw) = +-1)
     raw = d.sample_raw(p, torch.Generator().manual_seed(0))
     loc, scale = d._split(p)
     import torch.distributions as D
@@ -49,7 +49,7 @@ def test_tanh_normal_log_prob_matches_torch():
 
 def test_running_statistics_and_checkpoint(tmp_path):
     rs = RunningStatistics(3)
-    x = torch.randn(1000, 3) * torch.tensor([1.0, 5.0, 0.1]) + torch.tensor([0.0, 2.0, -1.0])
+    x = torch.randn(1000, 3, generator=torch.Generator().manual_seed(2)) * torch.tensor([1.0, 5.0, 0.1]) + torch.tensor([0.0, 2.0, -1.0])
     for chunk in x.split(100):
         rs.update(chunk)
     assert torch.allclose(rs.mean.float(), x.mean(0), atol=1e-5) and torch.allclose(rs.std.float(), x.std(0, unbiased=False), atol=1e-4)
