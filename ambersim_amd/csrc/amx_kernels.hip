@@ -27,6 +27,10 @@
 #include "amx_dev.h"
 
 #define DEV __device__ __forceinline__
+// The specialised kernels inline their eliminations: an out-of-line call makes the callee save and restore the caller's live
+// vector registers through scratch memory (callee-saved v40..v255), which cost the biped 24 % (r02 A/B).  The generic
+// kernels keep their size-dispatched solves out of line (fifteen instantiations per call site would not fit the I-cache).
+#define AMX_STATIC_SOLVE_ATTR __device__ __forceinline__
 #define MINVAL 1e-15f
 
 enum { JFREE = 0, JBALL = 1, JSLIDE = 2, JHINGE = 3 };
@@ -468,7 +472,7 @@ template <class S, int G, int J> struct GJTree {
 template <class S, int G> struct GJTree<S, G, -1> { static DEV void run(float (&)[S::nv], float &, int) {} };
 
 template <class S, int G, bool TREE>
-__device__ __noinline__ void spd_solve_static(int A_off, int rhs_off, int x_off, int gl, int rot) {
+AMX_STATIC_SOLVE_ATTR void spd_solve_static(int A_off, int rhs_off, int x_off, int gl, int rot) {
   constexpr int N = S::nv, ld = S::ldm, nch = ld / 4;
   float a[N];
   const int li = gl < N ? gl : 0;
@@ -501,7 +505,7 @@ __device__ __noinline__ void spd_solve_static(int A_off, int rhs_off, int x_off,
 // term of the limit row on its dof (dlim, fetched by the caller through the crossbar), and the elimination starts from
 // those registers: H never touches LDS.  S static: N = nv, tree-sparse elimination when TREE; S = DynSpec: N is the padded size.
 template <class S, int N, int G, bool TREE>
-__device__ __noinline__ void newton_solve_fused(int M_off, int ld_, int n_, unsigned long long crows_, int row_base, int J_base, int ldc_, int slot_base_,
+AMX_STATIC_SOLVE_ATTR void newton_solve_fused(int M_off, int ld_, int n_, unsigned long long crows_, int row_base, int J_base, int ldc_, int slot_base_,
                                                 int rhs_off, int x_off, float dlim, int gl, int gb4, int rot) {
   const int ld = S::is_static ? S::ldm : __builtin_amdgcn_readfirstlane(ld_), n = S::is_static ? S::nv : __builtin_amdgcn_readfirstlane(n_);
   const int ldc = S::is_static ? S::ldc : __builtin_amdgcn_readfirstlane(ldc_), slot_base = S::is_static ? S::c_slot : __builtin_amdgcn_readfirstlane(slot_base_);
@@ -636,7 +640,7 @@ DEV float umax32(float x) {
 // handles one pair per pass on a 32-lane unit).  Out of line: models without such pairs do not pay for its registers.
 //   geom_off / con_off / frame_off: LDS offsets of the lane's environment's geom poses, contacts and contact frames
 template <int G>
-__device__ __noinline__ void plane_convex_parallel(int pcx_first, int pcx_num, int c_pair, int c_vert, int geom_off, int con_off, int frame_off, int gl, int gb4) {
+DEV void plane_convex_parallel_body(int pcx_first, int pcx_num, int c_pair, int c_vert, int geom_off, int con_off, int frame_off, int gl, int gb4) {
   const int unit = G == 64 ? (gl >> 5) : 0, v = gl & 31, per_pass = G == 64 ? 2 : 1;
   const int lane0 = (gb4 >> 2) + 32 * unit;  // first wave lane of my unit
 #define GEO(f, g) lds[geom_off + (g) * GEO_E + (f)]
@@ -703,6 +707,11 @@ __device__ __noinline__ void plane_convex_parallel(int pcx_first, int pcx_num, i
   }
 #undef GEO
   WSYNC();
+}
+// out-of-line entry for the generic kernels (the specialised ones inline the body: see AMX_STATIC_SOLVE_ATTR)
+template <int G>
+__device__ __noinline__ void plane_convex_parallel(int pcx_first, int pcx_num, int c_pair, int c_vert, int geom_off, int con_off, int frame_off, int gl, int gb4) {
+  plane_convex_parallel_body<G>(pcx_first, pcx_num, c_pair, c_vert, geom_off, con_off, frame_off, gl, gb4);
 }
 
 // ---- group max / min with the value in every lane (same network as gsum)
@@ -1389,7 +1398,10 @@ struct Env {
     // lanes (one pair per pass) and 64 lanes (two).  The planner found the run of such pairs (pcx_first, npcx).
     const int cx_first = G >= 32 ? m.pcx_first() : 0, cx_num = G >= 32 ? m.npcx() : 0;
     if (G >= 32 && cx_num > 0)  // uniform: a property of the model
-      plane_convex_parallel<G>(cx_first, cx_num, m.c_pair(), m.c_vert(), eb + m.e_geom(), eb + m.e_con(), eb + m.e_frame(), gl, gb4);
+    {
+      if constexpr (S::is_static) plane_convex_parallel_body<G>(cx_first, cx_num, m.c_pair(), m.c_vert(), eb + m.e_geom(), eb + m.e_con(), eb + m.e_frame(), gl, gb4);
+      else plane_convex_parallel<G>(cx_first, cx_num, m.c_pair(), m.c_vert(), eb + m.e_geom(), eb + m.e_con(), eb + m.e_frame(), gl, gb4);
+    }
     if (m.ncx() > 0)  // uniform: a property of the model
       convex_convex_pairs<G>(m.cx_first(), m.ncx(), m.c_pair(), eb + m.e_geom(), eb + m.e_con(), eb + m.e_frame(), eb + m.e_cx(), gl, gb4);
     if (gl < np && !(gl >= cx_first && gl < cx_first + cx_num) && !(gl >= m.cx_first() && gl < m.cx_first() + m.ncx())) {
