@@ -52,30 +52,35 @@ def _load_hip_runtime():
     raise RuntimeError("no HIP runtime (libamdhip64) found for libamx.so")
 
 
+def load(path) -> C.CDLL:
+    """Loads one build of the library (the default libamx.so, or a per-model build of ambersim_amd._spec) and declares its ABI."""
+    _load_hip_runtime()
+    L = C.CDLL(str(path))
+    L.amx_version.restype = C.c_int
+    L.amx_last_error.restype = C.c_char_p
+    L.amx_model_create.argtypes = [C.POINTER(AmxModelDesc), C.c_int, C.POINTER(C.c_void_p)]
+    L.amx_model_destroy.argtypes = [C.c_void_p]
+    L.amx_model_query.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]
+    L.amx_forward.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.POINTER(AmxForwardOut), C.c_void_p]
+    L.amx_step.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_void_p]
+    L.amx_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.amx_quadcost.argtypes = [C.c_int] * 4 + [C.c_void_p] * 7 + [C.c_void_p]
+    L.amx_fd_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
+    L.amx_fd_grad.argtypes = ([C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 5 +
+                              [C.c_void_p, C.c_size_t, C.c_void_p])
+    for name in EXPORTS:
+        getattr(L, name)
+    return L
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        _load_hip_runtime()
         if not _LIB_PATH.exists():
             raise RuntimeError(
                 f"{_LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
                 "ambersim_amd has no CPU fallback for the physics path.")
-        L = C.CDLL(str(_LIB_PATH))
-        L.amx_version.restype = C.c_int
-        L.amx_last_error.restype = C.c_char_p
-        L.amx_model_create.argtypes = [C.POINTER(AmxModelDesc), C.c_int, C.POINTER(C.c_void_p)]
-        L.amx_model_destroy.argtypes = [C.c_void_p]
-        L.amx_model_query.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]
-        L.amx_forward.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.POINTER(AmxForwardOut), C.c_void_p]
-        L.amx_step.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_void_p]
-        L.amx_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.amx_quadcost.argtypes = [C.c_int] * 4 + [C.c_void_p] * 7 + [C.c_void_p]
-        L.amx_fd_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
-        L.amx_fd_grad.argtypes = ([C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 5 +
-                                  [C.c_void_p, C.c_size_t, C.c_void_p])
-        for name in EXPORTS:
-            getattr(L, name)
-        _lib = L
+        _lib = load(_LIB_PATH)
     return _lib
 
 
@@ -83,9 +88,9 @@ _EXC = {AMX_EINVAL: ValueError, AMX_EUNSUPPORTED: NotImplementedError, AMX_ENOME
         AMX_EHIP: RuntimeError, AMX_ECAPACITY: NotImplementedError}
 
 
-def check(code: int):
+def check(code: int, L: C.CDLL = None):
     """Maps a C status to the exception type the reference's callers expect
     (NotImplementedError for unsupported features: reference ambersim/utils/io_utils.py:228-241)."""
     if code != AMX_OK:
-        msg = lib().amx_last_error().decode(errors="replace")
+        msg = (L or lib()).amx_last_error().decode(errors="replace")
         raise _EXC.get(code, RuntimeError)(f"amx error {code}: {msg}")

@@ -16,7 +16,10 @@
 #include "amx_dev.h"
 #include "amx_plan.h"  // host-only planner: descriptor -> constant image + launch plan (also built alone as libamx_plan.so)
 
-#include "amx_specs_gen.h"
+#ifndef AMX_SPECS_HEADER
+#define AMX_SPECS_HEADER "amx_specs_gen.h"  // the shipped models; a per-model build (ambersim_amd/_spec.py) points this at its own record
+#endif
+#include AMX_SPECS_HEADER
 #include "amx_kernels.hip"  // single translation unit: kernels + launchers, no relocatable device code
 
 extern "C" int amx_version(void) { return AMX_VERSION; }

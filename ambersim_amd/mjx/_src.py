@@ -52,22 +52,31 @@ class Option:
 
 
 class _Handle:
-    """Owns one amx_model* (freed with the last Model that shares it)."""
+    """Owns one amx_model* (freed with the last Model that shares it) and the library build it lives in: the default
+    libamx.so, or - `specialise=True` - a build of csrc/ compiled for exactly this model's launch plan (ambersim_amd/_spec.py)."""
 
-    def __init__(self, mj: MjModel, device_index: int):
+    def __init__(self, mj: MjModel, device_index: int, specialise: bool = False):
         self.desc = build_desc(mj)
         self.ptr = C.c_void_p()
-        _lib.check(_lib.lib().amx_model_create(C.byref(self.desc), device_index, C.byref(self.ptr)))
+        self.L = _lib.lib()
+        _lib.check(self.L.amx_model_create(C.byref(self.desc), device_index, C.byref(self.ptr)), self.L)
+        if specialise and not self.query("specialised"):
+            from .._spec import build_specialised_library
+            L2 = _lib.load(build_specialised_library(mj))
+            ptr2 = C.c_void_p()
+            _lib.check(L2.amx_model_create(C.byref(self.desc), device_index, C.byref(ptr2)), L2)
+            self.L.amx_model_destroy(self.ptr)
+            self.L, self.ptr = L2, ptr2
 
     def query(self, name: str) -> int:
         out = C.c_int()
-        _lib.check(_lib.lib().amx_model_query(self.ptr, name.encode(), C.byref(out)))
+        _lib.check(self.L.amx_model_query(self.ptr, name.encode(), C.byref(out)), self.L)
         return out.value
 
     def __del__(self):
         try:
             if self.ptr:
-                _lib.lib().amx_model_destroy(self.ptr)
+                self.L.amx_model_destroy(self.ptr)
         except Exception:
             pass
 
@@ -75,8 +84,9 @@ class _Handle:
 class Model:
     """Device model.  Immutable; `replace(opt=...)` re-uploads the constant block."""
 
-    def __init__(self, mj: MjModel, device: torch.device, opt: Optional[Option] = None):
+    def __init__(self, mj: MjModel, device: torch.device, opt: Optional[Option] = None, specialise: bool = False):
         self.mj_model = mj
+        self.specialise = specialise
         self.device = device
         o = mj.opt
         self.opt = opt if opt is not None else Option(
@@ -87,7 +97,7 @@ class Model:
         self.nq, self.nv, self.nu, self.nbody, self.njnt, self.ngeom, self.neq = mj.nq, mj.nv, mj.nu, mj.nbody, mj.njnt, mj.ngeom, mj.neq
         self.actuator_ctrlrange = torch.as_tensor(np.asarray(mj.actuator_ctrlrange, dtype=np.float32).reshape(-1, 2), device=device)
         self.qpos0 = torch.as_tensor(np.asarray(mj.qpos0, dtype=np.float32), device=device)
-        self._h = _Handle(mj, device.index or 0)
+        self._h = _Handle(mj, device.index or 0, specialise)
         self.ncon = self._h.query("ncon")
         self.nefc_max = self._h.query("nefc_max")
 
@@ -102,7 +112,7 @@ class Model:
             gravity=np.asarray(opt.gravity, dtype=float), integrator=int(opt.integrator), solver=int(opt.solver),
             disableflags=int(opt.disableflags))
         mj = recompile_options(mj)
-        return Model(mj, self.device, opt)
+        return Model(mj, self.device, opt, self.specialise)
 
 
 _DATA_FIELDS = ("qpos", "qvel", "ctrl", "qacc", "qacc_warmstart", "time", "qacc_smooth", "qfrc_bias", "qfrc_constraint",
@@ -136,7 +146,10 @@ class Data:
         return self.qpos.dim() == 2
 
 
-def put_model(mj: MjModel, device=None) -> Model:
+def put_model(mj: MjModel, device=None, specialise: bool = False) -> Model:
+    """Host model -> device model.  `specialise=True`: if the library holds no kernels compiled for this model's launch plan
+    (only the shipped models have them), compile csrc/ for it with hipcc - about a minute, cached by plan - and use that build:
+    static loop bounds, immediate LDS offsets, tree-sparse eliminations, as for the shipped models."""
     if mj.opt.integrator != 0:
         raise NotImplementedError("only the Euler integrator is implemented")
     if getattr(mj, "nunsupported_pairs", 0):
@@ -144,7 +157,7 @@ def put_model(mj: MjModel, device=None) -> Model:
             f"{mj.nunsupported_pairs} collision pairs are outside the implemented pair functions (condim != 3, sphere / capsule "
             "against a box or mesh, or a convex hull beyond 32 vertices / 32 faces / 64 edges); disable contact "
             "(DisableBit.CONTACT), restrict contype/conaffinity or simplify the meshes")
-    return Model(mj, _dev(device))
+    return Model(mj, _dev(device), specialise=specialise)
 
 
 def make_data(m: Model, nenv: Optional[int] = None) -> Data:
@@ -228,8 +241,8 @@ def forward(m: Model, d: Data) -> Data:
     qacc, qs, fb, fc, xpos, xquat = new(m.nv), new(m.nv), new(m.nv), new(m.nv), new(m.nbody, 3), new(m.nbody, 4)
     out = _lib.AmxForwardOut(qacc.data_ptr(), qs.data_ptr(), fb.data_ptr(), fc.data_ptr(), None, xpos.data_ptr(), xquat.data_ptr(), None, None)
     with torch.cuda.device(dev):
-        _lib.check(_lib.lib().amx_forward(m._h.ptr, n, qpos.data_ptr(), qvel.data_ptr(), ctrl.data_ptr(), warm.data_ptr(),
-                                          C.byref(out), _stream_ptr(dev)))
+        _lib.check(m._h.L.amx_forward(m._h.ptr, n, qpos.data_ptr(), qvel.data_ptr(), ctrl.data_ptr(), warm.data_ptr(),
+                                          C.byref(out), _stream_ptr(dev)), m._h.L)
     s = (lambda t: t) if b else (lambda t: t[0])
     # the solver's result becomes the next warm start, as in the reference physics
     warm_out = qacc if m.nefc_max > 0 else warm
@@ -248,7 +261,7 @@ def step(m: Model, d: Data, nsub: int = 1) -> Data:
         raise ValueError(f"Data.time has {time.numel()} entries, the batch has {n}")
     time = time.expand(n).clone()
     with torch.cuda.device(m.device):
-        _lib.check(_lib.lib().amx_step(m._h.ptr, n, int(nsub), qpos.data_ptr(), qvel.data_ptr(), ctrl.data_ptr(), warm.data_ptr(),
+        _lib.check(m._h.L.amx_step(m._h.ptr, n, int(nsub), qpos.data_ptr(), qvel.data_ptr(), ctrl.data_ptr(), warm.data_ptr(),
                                        time.data_ptr(), _stream_ptr(m.device)))
     s = (lambda t: t) if b else (lambda t: t[0])
     return d.replace(qpos=s(qpos), qvel=s(qvel), qacc_warmstart=s(warm), qacc=s(warm) if m.nefc_max > 0 else d.qacc, time=s(time),
@@ -270,7 +283,7 @@ def rollout(m: Model, x0: torch.Tensor, us: torch.Tensor, return_traj: bool = Tr
     xs = torch.empty((S, N + 1, nx), dtype=torch.float32, device=dev) if return_traj else None
     xf = None if return_traj else torch.empty((S, nx), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(_lib.lib().amx_rollout(m._h.ptr, S, N, x0.data_ptr(), int(x0.dim() == 2), us.data_ptr(),
+        _lib.check(m._h.L.amx_rollout(m._h.ptr, S, N, x0.data_ptr(), int(x0.dim() == 2), us.data_ptr(),
                                           xs.data_ptr() if xs is not None else None, xf.data_ptr() if xf is not None else None,
                                           _stream_ptr(dev)))
     return xs if return_traj else xf

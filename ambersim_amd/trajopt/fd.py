@@ -50,9 +50,9 @@ def fd_grad_terminal_cost(m: mjx.Model, x0: torch.Tensor, us_nominal: torch.Tens
     if bool((eps <= 0).any()):
         raise ValueError("fd_grad_terminal_cost: eps must be positive (actuators need a ctrlrange, or pass eps)")
     N = us_nominal.shape[0]
-    L = _lib.lib()
+    L = m._h.L  # the library build the model lives in
     need = C.c_size_t()
-    _lib.check(L.amx_fd_workspace_bytes(m._h.ptr, nsamples, N, C.byref(need)))
+    _lib.check(L.amx_fd_workspace_bytes(m._h.ptr, nsamples, N, C.byref(need)), L)
     ws = torch.empty(max(need.value, 4) // 4 + 1, dtype=torch.float32, device=dev)
     J = torch.empty(nsamples, dtype=torch.float32, device=dev)
     g = torch.empty(nsamples - 1, dtype=torch.float32, device=dev)

@@ -123,3 +123,29 @@ def test_generated_spec_header_is_current():
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     assert subprocess.run([sys.executable, os.path.join(root, "tools", "gen_specs.py"), "--check"], cwd=root).returncode == 0
+
+
+def jit_test_model():
+    """A model the library ships no specialisation for: the quadruped with two solver iterations instead of three."""
+    import copy
+    from ambersim_amd.mjcf import recompile_options
+    from ambersim_amd.utils.io_utils import load_mj_model_from_file
+    mj = copy.copy(load_mj_model_from_file("models/quadruped/quadruped.xml"))
+    mj.opt = mj.opt.replace(iterations=2)
+    return recompile_options(mj)
+
+
+def test_per_model_specialised_build():
+    """ambersim_amd._spec.build_specialised_library: the record of an arbitrary model is rendered and csrc/ compiles against it
+    (hipcc cross-compiles without a GPU); the library exports the whole ABI.  The build is cached in csrc/jit/, where the GPU
+    test of the same model finds it."""
+    from ambersim_amd import _spec
+    mj = jit_test_model()
+    p = _spec.plan(mj)
+    assert p["iterations"] == "2" and p["nv"] == "18" and p["G"] == "32" and p["fusedH"] == "1"
+    rec = _spec.render_record("model", p)
+    assert "static constexpr int iterations = 2;" in rec and "dof_parent[32]" in rec
+    path = _spec.build_specialised_library(mj)
+    assert path.exists() and path == _spec.build_specialised_library(mj)  # cached
+    L = _lib.load(path)
+    assert L.amx_version() == 2

@@ -184,6 +184,42 @@ def test_specialised_and_generic_kernels(cases, golden):
     assert model.replace(opt=model.opt.replace(iterations=2))._h.query("specialised") == 0
 
 
+def test_per_model_specialised_build_runs(cases, dev):
+    """`mjx.put_model(mj, specialise=True)` on a model the library ships no kernels for (the quadruped with two solver
+    iterations): a build of csrc/ compiled for exactly that launch plan is loaded (ambersim_amd/_spec.py; built by the CPU test
+    into csrc/jit/ or here, about half a minute), reports itself specialised, and agrees with the generic kernels and the fp64
+    oracle; the C4 entry point works through it as well."""
+    import time
+    from test_abi import jit_test_model
+    from ambersim_amd import mjx
+    from ambersim_amd.trajopt.fd import fd_grad_terminal_cost
+    from oracle.oracle import Oracle
+    mj = jit_test_model()
+    _, _, x0, us = cases["quadruped"]
+    generic = mjx.put_model(mj, dev)
+    fast = mjx.put_model(mj, dev, specialise=True)
+    assert generic._h.query("specialised") == 0 and fast._h.query("specialised") == 1
+    a, b = gpu_rollout(generic, x0, us), gpu_rollout(fast, x0, us)
+    ref = Oracle(mj, np.float64).rollout(x0.astype(np.float32), us.astype(np.float32))
+    assert rel(a[:, 1], ref[:, 1]) < TOL and rel(b[:, 1], ref[:, 1]) < TOL and rel(a[:, 3], b[:, 3]) < 5e-5
+    nx = mj.nq + mj.nv
+    r = fd_grad_terminal_cost(fast, torch.tensor(x0[0]), torch.tensor(us[0, :8]), torch.eye(nx), torch.tensor(x0[0]), nsamples=16)
+    assert torch.isfinite(r.grad).all()
+    # the point of it: the same model, same launch, static kernels vs the generic ones
+    X0 = torch.tensor(np.tile(x0[:1], (4096, 1)), dtype=torch.float32, device=dev)
+    U = torch.tensor(np.tile(us[:1, :50], (4096, 1, 1)), dtype=torch.float32, device=dev)
+    t = {}
+    for name, mdl in (("generic", generic), ("specialised", fast)):
+        mjx.rollout(mdl, X0, U); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            mjx.rollout(mdl, X0, U)
+        torch.cuda.synchronize()
+        t[name] = (time.perf_counter() - t0) / 3
+    print(f"per-model build: 4096 x 50 rollout generic {1e3 * t['generic']:.2f} ms, specialised {1e3 * t['specialised']:.2f} ms")
+    assert t["specialised"] < t["generic"]
+
+
 def test_step_api_matches_rollout_bitwise(cases):
     """amx_step (state through HBM each call, warm start carried) and amx_rollout (state in LDS) run the same phases:
     identical bits after 20 steps."""
