@@ -1836,6 +1836,7 @@ struct Env {
     const bool first = p1.d0 < p0.d0;
     LSD lo = PICK(first, p1, p0d), hi = PICK(first, p0d, p1);
     bool swap = true;
+#pragma unroll  // static trip count in the specialised kernels: +1 %
     for (int it = 0; it < m.ls_iterations(); ++it) {
       bool done = !swap;
       done = done || ((lo.d0 < 0) && (lo.d0 > -gtol));
