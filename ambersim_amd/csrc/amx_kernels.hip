@@ -118,9 +118,26 @@ DEV f3 normalize3(f3 v, float *len) {
   *len = n;
   return n > 0 ? mk3(v.x / n, v.y / n, v.z / n) : v;
 }
+// sin and cos of a joint-sized angle (|x| up to a few thousand radians): nearest multiple of pi/2 removed with a two-term
+// Cody-Waite reduction (exact products through fma), then the classical single-precision minimax polynomials on
+// [-pi/4, pi/4] (Cephes sinf / cosf coefficients, < 1 ulp there) and the quadrant fix-up.  libm's sincosf carries a
+// large-argument path with a private table (the only scratch memory the kernels had) and costs several hundred instructions.
+DEV void sincos_joint(float x, float *s, float *c) {
+  const float k = rintf(x * 0.636619772367581343f);  // x * 2/pi
+  float r = __builtin_fmaf(-k, 1.57079625129699707031f, x);
+  r = __builtin_fmaf(-k, 7.54978941586159635335e-8f, r);
+  const float r2 = r * r;
+  const float sp = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f) * r2, r, r);
+  const float cp = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f) * r2, r2,
+                                  __builtin_fmaf(-0.5f, r2, 1.0f));
+  const int q = (int)k & 3;
+  const float ss = (q & 1) ? cp : sp, cc = (q & 1) ? sp : cp;
+  *s = (q & 2) ? -ss : ss;
+  *c = ((q + 1) & 2) ? -cc : cc;
+}
 DEV f4 axisangle(f3 axis, float ang) {
   float s, c;
-  sincosf(0.5f * ang, &s, &c);
+  sincos_joint(0.5f * ang, &s, &c);
   f4 r = {c, axis.x * s, axis.y * s, axis.z * s};
   return r;
 }
@@ -1188,7 +1205,8 @@ struct Env {
         l = mk3(d_axis == 0 ? 1.0f : 0.0f, d_axis == 1 ? 1.0f : 0.0f, d_axis == 2 ? 1.0f : 0.0f);
       } else if (d_kind == 1) {
         const m33 R = q2m(ld_xquat(d_body));
-        w = mk3(R.a[d_axis], R.a[3 + d_axis], R.a[6 + d_axis]);
+        // column d_axis of R by selects: a run-time index would put the matrix in scratch memory
+        w = d_axis == 0 ? mk3(R.a[0], R.a[3], R.a[6]) : (d_axis == 1 ? mk3(R.a[1], R.a[4], R.a[7]) : mk3(R.a[2], R.a[5], R.a[8]));
         l = cross(w, off);
       } else if (d_kind == 2) {
         w = mk3(jnt(3, j), jnt(4, j), jnt(5, j));
