@@ -163,8 +163,8 @@ def test_convex_convex_gpu_vs_oracle():
         print(f"convex-convex {name}: {nact} active contacts over {nenv} envs; 1-step err {e1.max():.2e} (fp32 oracle's own scale {floor1:.2e}; "
               f"{(e1_64 < 1e-5).mean():.2f} of the envs within 1e-5 of the fp64 oracle), 5-step err median {np.median(e5):.2e} max {e5.max():.2e}")
         # contacts here start centimetres deep (random placement): the first step's penalty forces are large and the fp32 floor
-        # sits above 1e-5 for a few envs (3e-5 bound); most envs, and every env after five steps, are inside the usual bounds
-        assert e1.max() < 3e-5 and (e1_64 < 1e-5).mean() >= 0.75, (name, e1.max(), floor1)
+        # sits above 1e-5 for a few envs (bound: 3e-5, or 4x the CPU oracle's own fp32 scale); most envs, and every env after five steps, are inside the usual bounds
+        assert e1.max() < max(3e-5, 4 * floor1) and (e1_64 < 1e-5).mean() >= 0.75, (name, e1.max(), floor1)
         assert e5.max() < 5e-5, (name, e5.max())
         assert np.median(e5) < 5e-5, (name, np.median(e5))
     xml = """<mujoco><option timestep="0.002" iterations="10" ls_iterations="10"/><worldbody><geom type="plane" size="5 5 .1"/>
