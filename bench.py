@@ -353,6 +353,31 @@ def secondary(args, model, mj, model_path, x0_np, us_np, kern_ms, dev):
                 "valu_busy_source": (f"RECORDED: {rec['file']}" if rec and "valu_busy_frac" in rec else None)}
 
     steps_per_s = args.nenv * args.horizon / (kern_ms * 1e-3)
+    # A8: the batched trajectory cost over the headline's trajectories - the one HBM-shaped kernel of the path
+    try:
+        from ambersim_amd.trajopt.cost import StaticGoalQuadraticCost
+        nx = mj.nq + mj.nv
+        xs_t = mjx.rollout(model, torch.tensor(x0_np, device=dev), torch.tensor(us_np, device=dev))
+        us_t = torch.tensor(us_np, device=dev)
+        cost = StaticGoalQuadraticCost(torch.eye(nx, device=dev), 2 * torch.eye(nx, device=dev), 0.1 * torch.eye(mj.nu, device=dev), xs_t[0, 0].clone())
+        cost.cost(xs_t, us_t)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10):
+            cost.cost(xs_t, us_t)
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / 10
+        nbytes = 4.0 * (xs_t.numel() + us_t.numel())
+        out.append({"name": "A8 quadcost", "metric": "trajectory bytes/s of amx_quadcost (StaticGoalQuadraticCost over the headline's rollouts)",
+                    "ms_per_call": ms, "roofline": {"bound": "hbm", "achieved": nbytes / ms * 1e-6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                    "frac": nbytes / ms * 1e-6 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes,
+                                                    "kernel": "amx_quadcost_mfma_kernel",
+                                                    "note": "bound by LDS operand staging and the fp32 MFMA rate in equal parts (DESIGN.md §4); 1-2 % of a trajectory-optimisation iteration"}})
+        del xs_t, us_t
+    except Exception as e:  # a secondary figure must never take the headline down
+        out.append({"name": "A8 quadcost", "error": f"{type(e).__name__}: {e}"})
     out.append({"name": "fp32_valu", "workload": os.path.basename(model_path), **fp32(mj, x0_np, us_np, steps_per_s, model_path)})
 
     if model_path != BIPED:
