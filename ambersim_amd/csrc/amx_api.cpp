@@ -77,6 +77,7 @@ template <class F> static bool for_spec(int spec, F &&f) {
 template <class S> static hipError_t set_lds_limit_spec(int bytes) {
   hipError_t e;
   if ((e = hipFuncSetAttribute((const void *)amx_rollout_kernel<S::G, S>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute((const void *)amx_rollout_kernel<S::G, S, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute((const void *)amx_step_kernel<S::G, S>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return e;
   return hipFuncSetAttribute((const void *)amx_forward_kernel<S::G, S>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
@@ -163,14 +164,17 @@ extern "C" int amx_model_query(const amx_model *m, const char *name, int *out) {
 // bound, but co-resident waves still share the SIMD's issue slots: 8 waves per CU cost 1.26x the step time of 2, measured on
 // the 1024-rollout gradient launch).  Cost model: sum over residency rounds of 1 + 0.05 * (waves per CU in that round);
 // ties go to the larger workgroup.
-static int choose_wpb(const amx_model *m, int nenv) {
+static int choose_wpb(const amx_model *m, int nenv, int minw = AMX_MIN_WAVES_PER_SIMD, double *cost_out = nullptr) {
   if (const char *force = getenv("AMX_FORCE_WPB")) { int w = atoi(force); if (w >= 1 && w <= m->dev.wpb) return w; }
   const int epw = AMX_WAVE / m->dev.G, nwaves = (nenv + epw - 1) / epw, ncu = m->ncu > 0 ? m->ncu : 256;
   int best = 1;
   double best_cost = 1e30;
   for (int w = 1; w <= m->dev.wpb; w++) {
+    // powers of two only: a workgroup's waves go round the CU's four SIMDs, so 3, 5, 6 or 7 of them load the SIMDs unevenly and
+    // the register file of the fuller ones caps the residency (measured: 6-wave workgroups at 3 waves/SIMD ran at 6 per CU)
+    if (w & (w - 1)) continue;
     const int bytes = (m->dev.nconst + w * epw * m->dev.env_floats) * (int)sizeof(float);
-    const int wg_per_cu = std::min(160 * 1024 / bytes, AMX_MIN_WAVES_PER_SIMD * 4 / w);  // LDS and register residency
+    const int wg_per_cu = std::min(160 * 1024 / bytes, minw * 4 / w);  // LDS and register residency
     if (wg_per_cu < 1) continue;
     const long nwg = (nwaves + w - 1) / w, per_round = (long)wg_per_cu * ncu;
     const long full = nwg / per_round, rest = nwg % per_round;
@@ -178,6 +182,7 @@ static int choose_wpb(const amx_model *m, int nenv) {
     if (rest) cost += 1.0 + 0.05 * w * (double)((rest + ncu - 1) / ncu);
     if (cost <= best_cost + 1e-9) { best_cost = cost; best = w; }
   }
+  if (cost_out) *cost_out = best_cost;
   return best;
 }
 static int pre_launch(const amx_model *m, int nenv, dim3 *grid, int *wpb, int *lds_bytes) {
@@ -254,9 +259,25 @@ extern "C" int amx_rollout(const amx_model *m, int nenv, int nsteps, const float
 #ifdef AMX_PROFILE
   prof = g_prof;
 #endif
+  // large batches of a specialised small-slab model: the build sized for 3 waves per SIMD, when the residency model says the
+  // third wave pays (fewer rounds outweigh the denser CU)
+  bool three = false;
+  if (m->spec >= 0 && !getenv("AMX_NO_W3")) {
+    double c2 = 0, c3 = 0;
+    (void)choose_wpb(m, nenv, 2, &c2);
+    const int w3 = choose_wpb(m, nenv, 3, &c3);
+    if (c3 < 0.9 * c2) {
+      three = true;
+      wpb = w3;
+      const int per_block = wpb * (AMX_WAVE / m->dev.G);
+      lds_bytes = (m->dev.nconst + per_block * m->dev.env_floats) * (int)sizeof(float);
+      grid = dim3((nenv + per_block - 1) / per_block);
+    }
+  }
   if (!for_spec(m->spec, [&](auto sp) {
         using S = decltype(sp);
-        hipLaunchKernelGGL((amx_rollout_kernel<S::G, S>), grid, dim3(AMX_WAVE * wpb), lds_bytes, (hipStream_t)stream, m->dev, nenv, nsteps, x0_batched, x0, us, xs, xfinal, prof);
+        if (three) hipLaunchKernelGGL((amx_rollout_kernel<S::G, S, 3>), grid, dim3(AMX_WAVE * wpb), lds_bytes, (hipStream_t)stream, m->dev, nenv, nsteps, x0_batched, x0, us, xs, xfinal, prof);
+        else hipLaunchKernelGGL((amx_rollout_kernel<S::G, S>), grid, dim3(AMX_WAVE * wpb), lds_bytes, (hipStream_t)stream, m->dev, nenv, nsteps, x0_batched, x0, us, xs, xfinal, prof);
       }))
     AMX_LAUNCH_G(amx_rollout_kernel, m, grid, stream, m->dev, nenv, nsteps, x0_batched, x0, us, xs, xfinal, prof);
   HIP_TRY(hipGetLastError());

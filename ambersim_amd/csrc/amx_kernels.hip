@@ -2100,8 +2100,11 @@ DEV DevModel split_scalars(const DevModel &in) {
   const int qp = eb + m.e_qpos(), qv = eb + m.e_qvel();
 
 // vmap(shoot): state stays in LDS for the whole horizon; HBM sees one control row in and one state row out per step.
-template <int G, class S>
-__global__ void __launch_bounds__(AMX_BLOCK, AMX_MIN_WAVES_PER_SIMD)
+// MINW: waves per SIMD the register budget is sized for.  2 (256 VGPRs) is what a 4096-environment batch can fill; the
+// specialised kernels are also built for 3 (168 VGPRs, a handful of spills), which large batches of small-slab models use:
+// quadruped, 32768 environments, 121 -> 161 M env-steps/s (r02).
+template <int G, class S, int MINW = AMX_MIN_WAVES_PER_SIMD>
+__global__ void __launch_bounds__(AMX_BLOCK, MINW)
 amx_rollout_kernel(const DevModel m_in, int nenv, int nsteps, int x0_batched, const float *__restrict__ x0g, const float *__restrict__ usg,
                    float *__restrict__ xs, float *__restrict__ xfinal, float *__restrict__ prof) {
   AMX_KERNEL_PROLOGUE()
@@ -2150,8 +2153,11 @@ amx_rollout_kernel(const DevModel m_in, int nenv, int nsteps, int x0_batched, co
 }
 
 // MjxEnv.pipeline_step: nsub physics steps with ctrl held; state comes from and returns to HBM.
-template <int G, class S>
-__global__ void __launch_bounds__(AMX_BLOCK, AMX_MIN_WAVES_PER_SIMD)
+// MINW: waves per SIMD the register budget is sized for.  2 (256 VGPRs) is what a 4096-environment batch can fill; the
+// specialised kernels are also built for 3 (168 VGPRs, a handful of spills), which large batches of small-slab models use:
+// quadruped, 32768 environments, 121 -> 161 M env-steps/s (r02).
+template <int G, class S, int MINW = AMX_MIN_WAVES_PER_SIMD>
+__global__ void __launch_bounds__(AMX_BLOCK, MINW)
 amx_step_kernel(const DevModel m_in, int nenv, int nsub, float *__restrict__ qpos, float *__restrict__ qvel, const float *__restrict__ ctrl,
                 float *__restrict__ warm, float *__restrict__ time) {
   AMX_KERNEL_PROLOGUE()
@@ -2177,8 +2183,11 @@ amx_step_kernel(const DevModel m_in, int nenv, int nsub, float *__restrict__ qpo
 struct ForwardOut { float *qacc, *qacc_smooth, *qfrc_bias, *qfrc_constraint, *qM, *xpos, *xquat, *cdist; int *nefc; };
 
 // mjx.forward: derived quantities for a given state, no integration.
-template <int G, class S>
-__global__ void __launch_bounds__(AMX_BLOCK, AMX_MIN_WAVES_PER_SIMD)
+// MINW: waves per SIMD the register budget is sized for.  2 (256 VGPRs) is what a 4096-environment batch can fill; the
+// specialised kernels are also built for 3 (168 VGPRs, a handful of spills), which large batches of small-slab models use:
+// quadruped, 32768 environments, 121 -> 161 M env-steps/s (r02).
+template <int G, class S, int MINW = AMX_MIN_WAVES_PER_SIMD>
+__global__ void __launch_bounds__(AMX_BLOCK, MINW)
 amx_forward_kernel(const DevModel m_in, int nenv, const float *__restrict__ qpos, const float *__restrict__ qvel, const float *__restrict__ ctrl,
                    const float *__restrict__ warm, const ForwardOut o) {
   AMX_KERNEL_PROLOGUE()
