@@ -20,7 +20,8 @@ for step in "$@"; do
     parity)  run 600 gpurun_out/r02_parity.log python tools/parity_horizons.py --out gpurun_out/r02_parity_horizons.txt ;;
     bench)   run 600 gpurun_out/r02_bench_n1.log python bench.py ;;
     configs) run 600 gpurun_out/r02_configs_throughput.txt python tools/configs_bench.py ;;
-    stats)   (cd /tmp && export TMPDIR=/tmp && run 600 $REPO/gpurun_out/r02_stats.log rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/r02_stats -o stats -- python3 $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary) ;;
+    stats)   (cd /tmp && export TMPDIR=/tmp && run 600 $REPO/gpurun_out/r02_stats.log rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/r02_stats -o stats -- python3 $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary)
+             (cd /tmp && export TMPDIR=/tmp && run 600 $REPO/gpurun_out/r02_stats_biped.log rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/r02_stats_biped -o stats -- python3 $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary --model models/biped/biped.xml) ;;
     pmc)     mkdir -p gpurun_out/pmc_quadruped gpurun_out/pmc_biped
              run 900 gpurun_out/r02_pmc_quadruped.log bash tools/pmc_collect.sh quadruped
              run 900 gpurun_out/r02_pmc_biped.log bash tools/pmc_collect.sh biped --model models/biped/biped.xml ;;
