@@ -6,7 +6,7 @@ from ambersim_amd.utils.io_utils import load_mj_model_from_file
 from bench import make_inputs
 dev = torch.device("cuda", 0)
 Q = "models/quadruped/quadruped.xml"
-for path, nenv, hor in [(Q, n, 200) for n in (4096, 6144, 8192, 12288, 16384, 24576, 32768)]:
+for path, nenv, hor in [(Q, n, 200) for n in (4096, 5120, 6144, 7168, 8192, 9216, 10240, 12288)]:
     mj = load_mj_model_from_file(path); model = mjx.put_model(mj, dev)
     x0, us = make_inputs(mj, nenv, hor, 1, 2, dev)
     mjx.rollout(model, x0, us); torch.cuda.synchronize()
