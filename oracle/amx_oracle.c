@@ -517,7 +517,12 @@ static int argmax_r(const REAL *v, int n) { int k = 0; for (int i = 1; i < n; i+
  * slots per pair; unused ones report dist = 1.  Contact normal points from geom1 to geom2. */
 #define CX_MAXV 32
 #define CX_MAXP 16
-static REAL cx_dbg[32]; /* last convex_convex call: np, idx[4], depth[16] (debugging aid for tools/dbg) */
+#ifdef __cplusplus
+#define AMXO_TLS thread_local
+#else
+#define AMXO_TLS _Thread_local
+#endif
+static AMXO_TLS REAL cx_dbg[32]; /* this thread's last convex_convex call: np, idx[4], depth[16] (debugging aid for tools/dbg) */
 typedef struct { int nv, nf, ne; const REAL *vert, *normal; const int *fvadr, *fvnum, *fvert, *edge; } hull_view;
 static void hull_get(const amxo_model *m, int h, hull_view *H) {
   H->nv = m->hull_vertnum[h]; H->nf = m->hull_facenum[h]; H->ne = m->hull_edgenum[h];
