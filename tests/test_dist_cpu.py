@@ -100,3 +100,15 @@ def test_bench_self_launch_propagates_failure():
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode != 0
     assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_self_launch_dry_run_four_ranks():
+    """The same launcher with four ranks (rehearsal of a wider node on the CPU: gloo, block order 0..3 in the gathered tensor)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1", "--dry-run", "--nenv", "3", "--horizon", "2"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 4 and out["config"]["gather"] == "traj+overlapped" and out["scaling_report"]["gathered_GB_per_rank"] > 0
