@@ -282,6 +282,8 @@ def rollout(m: Model, x0: torch.Tensor, us: torch.Tensor, return_traj: bool = Tr
         raise ValueError(f"rollout: shapes x0 {tuple(x0.shape)}, us {tuple(us.shape)} do not match nx={nx}, nu={m.nu}")
     xs = torch.empty((S, N + 1, nx), dtype=torch.float32, device=dev) if return_traj else None
     xf = None if return_traj else torch.empty((S, nx), dtype=torch.float32, device=dev)
+    if S == 0:  # an empty batch is a valid input: nothing to launch
+        return xs if return_traj else xf
     with torch.cuda.device(dev):
         _lib.check(m._h.L.amx_rollout(m._h.ptr, S, N, x0.data_ptr(), int(x0.dim() == 2), us.data_ptr(),
                                           xs.data_ptr() if xs is not None else None, xf.data_ptr() if xf is not None else None,

@@ -717,3 +717,68 @@ def test_c_host_over_the_abi():
     r = subprocess.run([os.path.join(d, "pendulum_host")], capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "max relative error vs closed form" in r.stdout
+
+
+def test_edge_cases_and_maximum_sizes(dev):
+    """Empty and ragged batches, a zero-length horizon, and models at the capacity limits: 32 dofs on a 32-lane group (the
+    largest matrix row a lane can hold: a free body carrying a 26-link hinge chain with limits), a branched 32-dof tree with 16
+    sphere contacts on the plane (64 contact rows: a 64-lane group), 63 bodies (welded riders) on a 64-lane group.  One step against the fp64 oracle (or 3x the fp32
+    oracle's own distance for the ill-conditioned long chain), finite five-step rollouts, and one dof / contact more is refused."""
+    from ambersim_amd import mjx
+    from ambersim_amd.mjcf import MjModel
+    from oracle.oracle import Oracle
+    mj0, = [__import__("ambersim_amd.utils.io_utils", fromlist=["x"]).load_mj_model_from_file("models/quadruped/quadruped.xml")]
+    model = mjx.put_model(mj0, dev)
+    nx = mj0.nq + mj0.nv
+    x0 = torch.tensor(np.concatenate([mj0.key_qpos[0], np.zeros(mj0.nv)]), dtype=torch.float32, device=dev)
+    assert mjx.rollout(model, x0.expand(0, nx), torch.zeros((0, 5, mj0.nu), device=dev)).shape == (0, 6, nx)       # empty batch
+    xs = mjx.rollout(model, x0, torch.zeros((3, 0, mj0.nu), device=dev))                                                  # zero-length horizon
+    assert xs.shape == (3, 1, nx) and torch.equal(xs[:, 0], x0.expand(3, nx))
+    a = mjx.rollout(model, x0, torch.zeros((17, 4, mj0.nu), device=dev))                                                 # ragged last workgroup
+    assert torch.equal(a[16], a[0]) and bool(torch.isfinite(a).all())
+
+    def chain(n, extra="", root=""):
+        open_, close = "", ""
+        for k in range(n):
+            open_ += f'<body pos="0 0 -0.1"><joint type="hinge" axis="{"1 0 0" if k % 2 else "0 1 0"}" range="-1 1" damping="0.05"/><geom type="capsule" size="0.02 0.04" mass="0.1" contype="0" conaffinity="0"/>'
+            close += "</body>"
+        return f'<mujoco><compiler angle="radian"/><option timestep="0.002" iterations="2" ls_iterations="4"/><worldbody><geom type="plane" size="5 5 .1"/><body pos="0 0 4">{root}{open_}{close}{extra}</body></worldbody></mujoco>'
+
+    def tree():
+        legs = "".join(f'<body pos="{0.2 * np.cos(k):.3f} {0.2 * np.sin(k):.3f} 0"><joint type="hinge" axis="0 1 0" range="-1 1"/><joint type="hinge" axis="1 0 0" range="-1 1"/>'
+                       f'<geom type="capsule" fromto="0 0 0 0 0 -0.2" size="0.03" mass="0.3" contype="0" conaffinity="0"/>'
+                       f'<body pos="0 0 -0.2"><joint type="hinge" axis="0 1 0" range="-2 0"/><geom type="sphere" size="0.04" pos="0 0 -0.2" mass="0.2" contype="0" conaffinity="1"/></body></body>' for k in range(8))
+        # 6 (free) + 8 legs x 3 = 30 dofs, + 2 tail hinges = 32; 8 sphere feet = 8 contact slots, + 8 more spheres on the torso = 16
+        tail = '<body pos="-0.3 0 0"><joint type="hinge" axis="0 1 0"/><joint type="hinge" axis="0 0 1"/><geom type="sphere" size="0.03" mass="0.1" contype="0" conaffinity="0"/></body>'
+        belly = "".join(f'<geom type="sphere" size="0.02" pos="{0.1 * np.cos(k):.3f} {0.1 * np.sin(k):.3f} -0.05" mass="0.01" contype="0" conaffinity="1"/>' for k in range(8))
+        return (f'<mujoco><compiler angle="radian"/><option timestep="0.002" iterations="3" ls_iterations="5"/><worldbody><geom type="plane" size="5 5 .1"/>'
+                f'<body pos="0 0 0.47"><freejoint/><geom type="box" size="0.25 0.25 0.04" mass="3" contype="0" conaffinity="0"/>{belly}{legs}{tail}</body></worldbody></mujoco>')
+
+    rng = np.random.default_rng(3)
+    free = '<freejoint/><geom type="sphere" size="0.05" mass="0.5" contype="0" conaffinity="0"/>'
+    # chain32: a free root + 26 hinge links = 32 dofs on 28 bodies (32 lanes); tree32: 16 contacts = 64 contact rows (64 lanes)
+    for name, xml, want_g in (("chain32", chain(26, root=free), 32), ("tree32", tree(), 64)):
+        mj = MjModel.from_xml_string(xml)
+        assert mj.nv == 32, (name, mj.nv)
+        model = mjx.put_model(mj, dev)
+        assert model._h.query("lanes_per_env") == want_g, name
+        if name == "tree32":
+            assert model.ncon == 16
+        q = np.tile(mj.qpos0, (8, 1))
+        q[:, -min(mj.nq, 20):] += 0.2 * rng.standard_normal((8, min(mj.nq, 20)))
+        x = np.concatenate([q, 0.3 * rng.standard_normal((8, mj.nv))], axis=1).astype(np.float32)
+        us = np.zeros((8, 5, mj.nu), dtype=np.float32)
+        xs = gpu_rollout(model, x, us)
+        ref, ref32 = Oracle(mj, np.float64).rollout(x, us), Oracle(mj, np.float32).rollout(x, us)
+        e1, f1 = rel(xs[:, 1], ref[:, 1]), rel(ref32[:, 1], ref[:, 1])
+        assert np.isfinite(xs).all() and e1 <= max(TOL, 3 * f1), (name, e1, f1)
+    riders = "".join(f'<body name="r{k}" pos="0.001 0 0"><inertial pos="0 0 0" mass="0.001" diaginertia="1e-7 1e-7 1e-7"/></body>' for k in range(60))
+    mj = MjModel.from_xml_string(chain(2, riders))
+    assert mj.nbody == 64
+    model = mjx.put_model(mj, dev)
+    assert model._h.query("lanes_per_env") == 64
+    x = np.concatenate([np.tile(mj.qpos0, (4, 1)), 0.3 * rng.standard_normal((4, mj.nv))], axis=1).astype(np.float32)
+    xs = gpu_rollout(model, x, np.zeros((4, 5, 0), dtype=np.float32))
+    assert rel(xs[:, 1], Oracle(mj, np.float64).rollout(x, np.zeros((4, 5, 0)))[:, 1]) < TOL
+    with pytest.raises(NotImplementedError):
+        mjx.put_model(MjModel.from_xml_string(chain(27, root=free)), dev)  # 33 dofs: beyond the register-row capacity
