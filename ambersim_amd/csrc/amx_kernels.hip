@@ -1487,6 +1487,51 @@ struct Env {
         }
 #undef VERT
 #undef MASKV
+      } else if (fn == 7) {
+        // sphere - convex hull (oracle: sphere_convex): in the hull's frame, the face of largest support (least penetrated, or
+        // most separating), then the closest point of that polygon to the centre (projection, or the nearest violated edge)
+        const int hB = CI(rec + 26), nfB = CI(hB + 2), vB = CI(hB + 1), nB_ = CI(hB + 3), pB = CI(hB + 4);
+#define HV(base, i) mk3(CF((base) + 3 * (i)), CF((base) + 3 * (i) + 1), CF((base) + 3 * (i) + 2))
+        const float r = CF(s1);
+        const f3 c = mulTv(R2, pos1 - pos2);
+        int bf = 0;
+        float bs = -1e30f;
+        for (int f = 0; f < nfB; ++f) {
+          const f3 n = HV(nB_, f), v0 = HV(vB, CI(pB + 9 * f + 1));
+          float sup = dot(c - n * r - v0, n);
+          if (sup > bs) { bs = sup; bf = f; }
+        }
+        const f3 n = HV(nB_, bf);
+        const int poly = pB + 9 * bf, nvf = CI(poly);
+        const f3 v0 = HV(vB, CI(poly + 1));
+        f3 pt = c - n * dot(c - v0, n);
+        bool inside = true;
+        int be = -1;
+        float bd = 1e12f;
+        for (int k = 0; k < nvf; ++k) {
+          const f3 p0 = HV(vB, CI(poly + 1 + (k == 0 ? nvf - 1 : k - 1))), p1 = HV(vB, CI(poly + 1 + k));
+          const f3 en = cross(p1 - p0, n);
+          const float ed = dot(pt - p0, en);
+          if (ed > 0) inside = false;
+          const bool degenerate = en.x == 0 && en.y == 0 && en.z == 0;
+          if (!degenerate && !(ed < 0) && ed < bd) { bd = ed; be = k; }
+        }
+        if (!inside && be >= 0) {
+          const f3 p0 = HV(vB, CI(poly + 1 + (be == 0 ? nvf - 1 : be - 1))), p1 = HV(vB, CI(poly + 1 + be));
+          const f3 e = p1 - p0;
+          const float t = fminf(fmaxf(dot(pt - p0, e) / fmaxf(dot(e, e), MINVAL), 0.0f), 1.0f);
+          pt = p0 + e * t;
+        }
+#undef HV
+        float dn;
+        f3 pn = normalize3(pt - c, &dn);
+        if (dn == 0) pn = n * -1.0f;
+        const bool below = dot(pn, n) > 0;  // the centre is under the face: deep penetration
+        const f3 nl = below ? pn * -1.0f : pn;
+        const float d = (below ? -dn : dn) - r;
+        const f3 posl = (pt + c + nl * r) * 0.5f;
+        st_contact(c0, d, pos2 + mulv(R2, posl));
+        make_frame(mulv(R2, nl), fr);
       } else {
         f3 p1 = pos1, p2 = pos2;
         const float r1 = CF(s1), r2 = CF(s2);

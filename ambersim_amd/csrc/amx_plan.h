@@ -35,7 +35,7 @@ struct Image {
   int geti(int off) const { int x; memcpy(&x, &v[off], 4); return x; }
   void setf(int off, double x) { v[off] = (float)x; }
 };
-const int PAIR_NCON[7] = {1, 2, 4, 1, 1, 1, 4};
+const int PAIR_NCON[8] = {1, 2, 4, 1, 1, 1, 4, 1};
 
 // {k, b, dmin, dmax, width, mid, power, ca, cb}: the position-independent part of MuJoCo's solref/solimp
 // mapping (reference physics: constraint._kbi), evaluated once on the host in double precision.
@@ -262,7 +262,8 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
   int ncon = 0;
   for (int p = 0; p < np; p++) {
     int g1 = d->pair_geom1[p], g2 = d->pair_geom2[p], fn = d->pair_fn[p], o = m.c_pair + p * PAIR_S;
-    if (fn < 0 || fn > 6) return fail(AMX_EUNSUPPORTED, "pair %d: unknown collision function %d", p, fn);
+    if (fn < 0 || fn > 7) return fail(AMX_EUNSUPPORTED, "pair %d: unknown collision function %d", p, fn);
+    if (fn == 7 && (d->pair_hull2[p] < 0 || d->pair_hull2[p] >= d->nhull)) return fail(AMX_EINVAL, "pair %d: sphere-convex pair without a hull", p);
     if (fn == 6 && (d->pair_hull1[p] < 0 || d->pair_hull1[p] >= d->nhull || d->pair_hull2[p] < 0 || d->pair_hull2[p] >= d->nhull))
       return fail(AMX_EINVAL, "pair %d: convex-convex pair without hulls", p);
     if (fn == 2 && (d->pair_vertnum[p] < 1 || d->pair_vertadr[p] < 0 || d->pair_vertadr[p] + d->pair_vertnum[p] > d->nconvexvert))
@@ -272,6 +273,7 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
     im.seti(o + 5, fn == 2 ? d->pair_vertadr[p] : 0); im.seti(o + 6, fn == 2 ? d->pair_vertnum[p] : 0);
     im.seti(o + 7, root_slot[b1]); im.seti(o + 8, root_slot[b2]);
     if (fn == 6) { im.seti(o + 25, hull_rec[d->pair_hull1[p]]); im.seti(o + 26, hull_rec[d->pair_hull2[p]]); }
+    if (fn == 7) im.seti(o + 26, hull_rec[d->pair_hull2[p]]);
     im.setf(o + 11, d->pair_friction[3 * p]);
     write_kbi(im, o + 12, d->pair_solref + 2 * p, d->pair_solimp + 5 * p, d->timestep, refsafe);
     im.setf(o + 21, d->pair_margin[p]);

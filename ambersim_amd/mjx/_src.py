@@ -154,7 +154,7 @@ def put_model(mj: MjModel, device=None, specialise: bool = False) -> Model:
         raise NotImplementedError("only the Euler integrator is implemented")
     if getattr(mj, "nunsupported_pairs", 0):
         raise NotImplementedError(
-            f"{mj.nunsupported_pairs} collision pairs are outside the implemented pair functions (condim != 3, sphere / capsule "
+            f"{mj.nunsupported_pairs} collision pairs are outside the implemented pair functions (condim != 3, a capsule "
             "against a box or mesh, or a convex hull beyond 32 vertices / 32 faces / 64 edges); disable contact "
             "(DisableBit.CONTACT), restrict contype/conaffinity or simplify the meshes")
     return Model(mj, _dev(device), specialise=specialise)

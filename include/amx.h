@@ -66,13 +66,13 @@ typedef struct amx_model_desc {
   const double *geom_pos, *geom_quat, *geom_size /*[ngeom,3]*/;
   /* static collision pairs [npair] (contype/conaffinity/parent filters already applied) */
   const int *pair_geom1, *pair_geom2, *pair_fn /*0 plane-sphere 1 plane-capsule 2 plane-convex
-      3 sphere-sphere 4 sphere-capsule 5 capsule-capsule 6 convex-convex (box / mesh hulls)*/, *pair_vertadr, *pair_vertnum;
+      3 sphere-sphere 4 sphere-capsule 5 capsule-capsule 6 convex-convex (box / mesh hulls) 7 sphere-convex*/, *pair_vertadr, *pair_vertnum;
   const double *pair_friction /*[npair,3]*/, *pair_solref /*[npair,2]*/, *pair_solimp /*[npair,5]*/,
       *pair_margin /*[npair] margin-gap*/, *convex_vert /*[nconvexvert,3] geom-local hull vertices*/;
   /* convex hulls of the box / mesh geoms in convex-convex pairs (pair_fn 6): polygon faces (coplanar triangles merged,
    * vertices counter-clockwise seen from outside), outward unit face normals, unique edges; everything geom-local.
    * Limits: <= 32 vertices, <= 32 faces of <= 8 vertices, <= 64 edges per hull. */
-  const int *pair_hull1, *pair_hull2 /*[npair] hull of geom1 / geom2 for pair_fn 6, else -1*/;
+  const int *pair_hull1, *pair_hull2 /*[npair] hull of geom1 / geom2 for pair_fn 6 (pair_fn 7: of geom2 only), else -1*/;
   const int *hull_vertadr, *hull_vertnum, *hull_faceadr, *hull_facenum, *hull_edgeadr, *hull_edgenum /*[nhull]*/;
   const double *hull_vert /*[nhullvert,3]*/, *hull_face_normal /*[nhullface,3]*/;
   const int *hull_face_vertadr, *hull_face_vertnum /*[nhullface] into hull_facevert*/, *hull_facevert /*[nhullfacevert] vertex ids local to the hull*/,

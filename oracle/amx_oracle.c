@@ -97,7 +97,7 @@ static REAL *dup_r(const double *src, size_t n) {
   return p;
 }
 
-static const int PAIR_NCON[7] = {1, 2, 4, 1, 1, 1, 4};
+static const int PAIR_NCON[8] = {1, 2, 4, 1, 1, 1, 4, 1};
 
 amxo_model *amxo_model_create(const amx_model_desc *d) {
   amxo_model *m = (amxo_model *)calloc(1, sizeof(amxo_model));
@@ -688,6 +688,64 @@ static void convex_convex(const amxo_model *m, amxo_data *d, int p) {
   for (int k = 0; k < 4; k++) memcpy(d->con_frame + 9 * (c0 + k), frame, sizeof(frame));
 }
 
+/* ------------------------------------------------------------------ sphere-convex [mjx:collision_convex.sphere_convex]
+ * In the hull's frame: support of every face = signed height of the sphere's lowest point over the face plane; the face
+ * with the largest support (the one the sphere penetrates least, or the most separating one when it is clear of the hull);
+ * the closest point of that face's polygon to the sphere centre (its projection, or the closest point of the nearest
+ * violated edge); distance and normal from there.
+ * DEVIATION, recorded in DESIGN.md 4c: the published routine, as recalled (mujoco-mjx is not in this image), first replaces
+ * every support >= 0 by -1e12, which for a sphere clear of the hull selects a far face and reports a deep penetration. The
+ * two selections are the same whenever all supports are negative, i.e. whenever the sphere reaches below every face plane. */
+static void sphere_convex(const amxo_model *m, amxo_data *d, int p) {
+  int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p], c0 = m->pair_conadr[p];
+  const REAL *pos1 = d->geom_xpos + 3 * g1, *pos2 = d->geom_xpos + 3 * g2, *mat2 = d->geom_xmat + 9 * g2;
+  REAL r = m->geom_size[3 * g1];
+  hull_view H;
+  hull_get(m, m->pair_hull2[p], &H);
+  REAL rel[3] = {pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2]}, c[3];
+  matT_mul_vec3(c, mat2, rel);
+  int bf = 0; REAL bs = (REAL)-1e30;
+  for (int f = 0; f < H.nf; f++) {
+    const REAL *n = H.normal + 3 * f, *v0 = H.vert + 3 * H.fvert[H.fvadr[f]];
+    REAL q[3] = {c[0] - n[0] * r - v0[0], c[1] - n[1] * r - v0[1], c[2] - n[2] * r - v0[2]};
+    REAL sup = dot3(q, n);
+    if (sup > bs) { bs = sup; bf = f; }
+  }
+  const REAL *n = H.normal + 3 * bf;
+  int nvf = H.fvnum[bf];
+  const int *fv = H.fvert + H.fvadr[bf];
+  const REAL *v0 = H.vert + 3 * fv[0];
+  REAL cv[3] = {c[0] - v0[0], c[1] - v0[1], c[2] - v0[2]}, h = dot3(cv, n), pt[3] = {c[0] - n[0] * h, c[1] - n[1] * h, c[2] - n[2] * h};
+  int inside = 1, be = -1; REAL bd = (REAL)1e12;
+  for (int k = 0; k < nvf; k++) { /* edge k: from vertex k-1 to vertex k */
+    const REAL *p0 = H.vert + 3 * fv[(k + nvf - 1) % nvf], *p1 = H.vert + 3 * fv[k];
+    REAL e[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]}, en[3], w[3] = {pt[0] - p0[0], pt[1] - p0[1], pt[2] - p0[2]};
+    cross3(en, e, n);
+    REAL ed = dot3(w, en);
+    if (ed > 0) inside = 0;
+    int degenerate = en[0] == 0 && en[1] == 0 && en[2] == 0;
+    if (!degenerate && !(ed < 0) && ed < bd) { bd = ed; be = k; }
+  }
+  if (!inside && be >= 0) { /* closest point of the nearest violated edge */
+    const REAL *p0 = H.vert + 3 * fv[(be + nvf - 1) % nvf], *p1 = H.vert + 3 * fv[be];
+    REAL e[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]}, w[3] = {pt[0] - p0[0], pt[1] - p0[1], pt[2] - p0[2]};
+    REAL t = r_clip(dot3(w, e) / r_max(dot3(e, e), MINVAL), 0, 1);
+    for (int i = 0; i < 3; i++) pt[i] = p0[i] + t * e[i];
+  }
+  REAL pn[3] = {pt[0] - c[0], pt[1] - c[1], pt[2] - c[2]};
+  REAL dn = normalize_n(pn, 3);
+  if (dn == 0) { pn[0] = -n[0]; pn[1] = -n[1]; pn[2] = -n[2]; }
+  int below = dot3(pn, n) > 0; /* the centre is under the face: deep penetration */
+  REAL nl[3], sgn = below ? (REAL)-1 : (REAL)1;
+  for (int i = 0; i < 3; i++) nl[i] = below ? -pn[i] : pn[i];
+  REAL dist = dn * sgn - r, posl[3], nw[3], pw[3];
+  for (int i = 0; i < 3; i++) posl[i] = (REAL)0.5 * (pt[i] + c[i] + nl[i] * r);
+  mat_mul_vec3(nw, mat2, nl); mat_mul_vec3(pw, mat2, posl);
+  d->con_dist[c0] = dist;
+  for (int i = 0; i < 3; i++) d->con_pos[3 * c0 + i] = pw[i] + pos2[i];
+  make_frame(d->con_frame + 9 * c0, nw);
+}
+
 static void collision(const amxo_model *m, amxo_data *d) {
   for (int p = 0; p < m->npair; p++) {
     int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p], c0 = m->pair_conadr[p], fn = m->pair_fn[p];
@@ -696,6 +754,7 @@ static void collision(const amxo_model *m, amxo_data *d) {
     const REAL *size1 = m->geom_size + 3 * g1, *size2 = m->geom_size + 3 * g2;
     for (int k = 0; k < PAIR_NCON[fn]; k++) d->con_pair[c0 + k] = p;
     if (fn == 6) { convex_convex(m, d, p); continue; }
+    if (fn == 7) { sphere_convex(m, d, p); continue; }
     if (fn == 0) { /* plane-sphere */
       REAL n[3] = {mat1[2], mat1[5], mat1[8]};
       plane_sphere_core(n, pos1, pos2, size2[0], d->con_dist + c0, d->con_pos + 3 * c0);

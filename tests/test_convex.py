@@ -246,3 +246,89 @@ def test_barrett_two_fingers_gpu_vs_oracle():
     e10 = np.minimum(np.abs(xs[:, 10] - ref[:, 10]).max(axis=1), np.abs(xs[:, 10] - ref32[:, 10]).max(axis=1)) / np.maximum(1.0, np.abs(ref[:, 10]).max(axis=1))
     print(f"bh280 two fingers: {nact} of {nenv} envs in contact; 1-step err {e1.max():.2e}, 10-step err median {np.median(e10):.2e} max {e10.max():.2e}")
     assert np.isfinite(xs).all() and e1.max() < 3e-5 and np.median(e10) < 1e-4
+
+
+SPHERE_BOX = """
+<mujoco><option timestep="0.002" iterations="{it}" ls_iterations="{it}" gravity="0 0 {g}"/><worldbody>
+  <body name="box" pos="0 0 0" {qa}>{ja}<geom type="box" size="0.5 0.4 0.3" mass="5"/></body>
+  <body name="ball" pos="{pb}"><freejoint/><geom type="sphere" size="0.1" mass="0.5"/></body>
+</worldbody></mujoco>
+"""
+
+
+def test_sphere_convex_closed_forms():
+    """Sphere (r = 0.1) against a box (half sizes 0.5, 0.4, 0.3): above a face the distance is height - r along the face normal;
+    beyond an edge it is the distance to the edge; with the centre inside the box the distance is -(depth + r); the contact
+    point lies midway between the two surfaces; the normal points from the sphere (geom1) to the box (geom2)."""
+    def one(pb, qa=""):
+        mj = MjModel.from_xml_string(SPHERE_BOX.format(pb=pb, qa=qa, ja="", g=0, it=10))
+        assert mj.pair_fn.tolist() == [7] and mj.ncon == 1 and mj.pair_hull2.tolist() == [0]
+        d, p, f = contacts(mj)
+        return d[0], p[0], f[0, 0]
+    d, p, n = one("0.1 -0.2 0.45")                      # 0.05 above the top face
+    assert np.isclose(d, 0.05, atol=1e-12) and np.allclose(n, [0, 0, -1]) and np.allclose(p, [0.1, -0.2, 0.325], atol=1e-12)
+    d, p, n = one("0.1 -0.2 0.37")                      # 0.03 into the top face
+    assert np.isclose(d, -0.03, atol=1e-12) and np.allclose(n, [0, 0, -1]) and np.allclose(p, [0.1, -0.2, 0.285], atol=1e-12)
+    d, p, n = one("0.56 0 0.38")                        # beyond the +x edge of the top face: closest point (0.5, 0, 0.3)
+    assert np.isclose(d, 0.1 - 0.1, atol=1e-12) and np.allclose(n, [-0.6, 0, -0.8], atol=1e-12)
+    d, p, n = one("0.2 0.1 0.25")                       # centre 0.05 below the top face, inside the box
+    assert np.isclose(d, -0.15, atol=1e-12) and np.allclose(n, [0, 0, -1])
+    d, p, n = one("0 0 0.45", qa='euler="0 0 37"')      # the box turned about z: same as unrotated
+    assert np.isclose(d, 0.05, atol=1e-12) and np.allclose(n, [0, 0, -1], atol=1e-12)
+
+
+def test_sphere_resting_on_box():
+    """A ball on a fixed box: at rest the constraint force on the ball's vertical translation is its weight."""
+    mj = MjModel.from_xml_string(SPHERE_BOX.format(pb="0.1 0.05 0.401", qa="", ja="", g=-9.81, it=50))
+    o = Oracle(mj)
+    xs = o.rollout(np.concatenate([mj.qpos0, np.zeros(6)]), np.zeros((1, 1000, 0)))[0]
+    assert np.abs(xs[-1, 7:]).max() < 1e-3 and 0.399 < xs[-1, 2] < 0.4005
+    o.set_state(xs[-1, :7], xs[-1, 7:], np.zeros(0)); o.forward()
+    assert abs(o.get("qfrc_constraint")[2] - 0.5 * 9.81) < 0.01 * 0.5 * 9.81
+
+
+@pytest.mark.gpu
+def test_sphere_convex_gpu_vs_oracle():
+    """The HIP path on seeded random sphere-box and sphere-mesh poses (touching, penetrating, separated, near edges and corners):
+    contact distance within 1e-5 of the oracle's for every env, one step within 3e-5 and five within 1e-4 of the fp64 oracle (relative to the state scale)."""
+    import ctypes as C
+    import torch
+    from ambersim_amd import _lib, mjx
+    dev = torch.device("cuda", 0)
+    octa = "0.3 0 0  -0.3 0 0  0 0.3 0  0 -0.3 0  0 0 0.35  0 0 -0.25"
+    for name, geom in (("sphere-box", 'type="box" size="0.5 0.4 0.3"'), ("sphere-mesh", 'type="mesh" mesh="o"')):
+        xml = SPHERE_BOX.format(pb="0 0 0.6", qa="", ja="<freejoint/>", g=-9.81, it=3).replace('type="box" size="0.5 0.4 0.3"', geom)
+        if "mesh" in geom:
+            xml = xml.replace("<worldbody>", f'<asset><mesh name="o" vertex="{octa}"/></asset><worldbody>')
+        mj = MjModel.from_xml_string(xml)
+        assert mj.pair_fn.tolist() == [7], name
+        model = mjx.put_model(mj, dev)
+        rng = np.random.default_rng(31 if name == "sphere-box" else 32)
+        nenv = 64
+        q = np.tile(mj.qpos0, (nenv, 1))
+        for k in range(nenv):
+            quat = np.array([1.0, 0, 0, 0]) + 0.6 * rng.uniform(-1, 1, 4)
+            q[k, 3:7] = quat / np.linalg.norm(quat)
+            u = rng.standard_normal(3)
+            q[k, 7:10] = u / np.linalg.norm(u) * (rng.uniform(0.3, 0.75) if name == "sphere-box" else rng.uniform(0.1, 0.45))
+        v = 0.3 * rng.standard_normal((nenv, mj.nv))
+        x0 = np.concatenate([q, v], axis=1).astype(np.float32)
+        tq, tv = torch.tensor(x0[:, :mj.nq], device=dev), torch.tensor(x0[:, mj.nq:], device=dev)
+        cd = torch.zeros((nenv, 1), device=dev)
+        out = _lib.AmxForwardOut(None, None, None, None, None, None, None, cd.data_ptr(), None)
+        _lib.check(_lib.lib().amx_forward(model._h.ptr, nenv, tq.data_ptr(), tv.data_ptr(), torch.zeros((nenv, 1), device=dev).data_ptr(), None, C.byref(out), None))
+        torch.cuda.synchronize()
+        o = Oracle(mj, np.float64)
+        ref_d = np.zeros(nenv)
+        for k in range(nenv):
+            o.set_state(x0[k, :mj.nq], x0[k, mj.nq:], np.zeros(0)); o.forward()
+            ref_d[k] = o.get("con_dist")[0]
+        assert (ref_d < 0).sum() >= 8 and (ref_d > 0).sum() >= 8, name
+        assert np.abs(cd[:, 0].cpu().numpy() - ref_d).max() < 1e-5, (name, np.abs(cd[:, 0].cpu().numpy() - ref_d).max())
+        us = np.zeros((nenv, 5, 0), dtype=np.float32)
+        xs = mjx.rollout(model, torch.tensor(x0), torch.tensor(us)).cpu().numpy().astype(np.float64)
+        ref = Oracle(mj, np.float64).rollout(x0, us)
+        e1 = np.abs(xs[:, 1] - ref[:, 1]).max() / max(1.0, np.abs(ref[:, 1]).max())
+        e5 = np.abs(xs[:, 5] - ref[:, 5]).max() / max(1.0, np.abs(ref[:, 5]).max())
+        print(f"{name}: {(ref_d < 0).sum()} of {nenv} envs in contact, 1-step err {e1:.2e}, 5-step err {e5:.2e}")
+        assert e1 < 3e-5 and e5 < 1e-4, (name, e1, e5)
