@@ -31,6 +31,9 @@
 // vector registers through scratch memory (callee-saved v40..v255), which cost the biped 24 % (r02 A/B).  The generic
 // kernels keep their size-dispatched solves out of line (fifteen instantiations per call site would not fit the I-cache).
 #define AMX_STATIC_SOLVE_ATTR __device__ __forceinline__
+#ifndef AMX_NO_SYM_ELIM
+#define AMX_NO_SYM_ELIM 0  // 1: the static eliminations broadcast pivot rows through the crossbar as before (A/B switch)
+#endif
 #define MINVAL 1e-15f
 
 enum { JFREE = 0, JBALL = 1, JSLIDE = 2, JHINGE = 3 };
@@ -488,9 +491,133 @@ template <class S, int G, int J> struct GJTree {
 };
 template <class S, int G> struct GJTree<S, G, -1> { static DEV void run(float (&)[S::nv], float &, int) {} };
 
+
+// ---- the static eliminations without the crossbar (r02b): groups of 16 or 32 lanes, nv < G.
+// The Schur complement of the dofs not yet eliminated is symmetric, so the pivot ROW J is also what register a[J] (column J)
+// holds across the lanes: entry (J, K) sits in lane K.  One register therefore carries everything pivot J needs - the
+// pivot itself (lane J), the lane's own multiplier (its own entry) and every pivot-row entry (lane K) - and a DPP
+// row_newbcast modifier on the multiply-add fetches lane K of a 16-lane row for free.  Groups of 32 lanes first make both
+// rows of a group hold the wanted source row: one v_permlane16_swap of the register with itself returns (row 0, row 0) and
+// (row 1, row 1).  Per pivot: two copies + one swap + max + rcp + multiply + select + one v_fmac_f32_dpp per updated
+// column, no LDS instruction and a dependent chain of VALU latencies instead of two crossbar round trips (~60 cycles per
+// pivot instead of ~450 measured).  The right-hand side rides along as column N of an (N+1) x (N+1) symmetric matrix whose
+// row N (lane N, which the caller loads with b through a staging vector) mirrors it, so b_J is lane N of the same
+// register (BCOL); 16-lane groups broadcast b directly instead.
+// The multiply-adds are inline assembly because the compiler's DPP combiner does not fold a DPP move into v_fma/v_fmac
+// (it does into v_rcp / v_max).  The hazard recogniser does not look into inline assembly, so the 2 wait states a DPP read
+// needs after a VALU write of the same register are guaranteed by construction: every asm multiply-add consumes `nf`, which
+// depends on the compiler-emitted v_max_f32_dpp of the same source registers (the compiler pads that one), and 16-lane
+// groups pass the register through an explicit `s_nop 1` first.  tools/check_dpp_hazard.py re-checks the emitted code.
+struct RowPair { float r0, r1; };
+template <int G> DEV RowPair row_pair(float c) {
+  if constexpr (G == 16) {
+    return RowPair{c, c};  // the first DPP reader (sym_pivot's v_max_f32_dpp) carries the wait states itself
+  } else {
+    static_assert(G == 32, "row_pair: 16- or 32-lane groups");
+    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(c), __float_as_uint(c), false, false);
+    return RowPair{__uint_as_float(sw[0]), __uint_as_float(sw[1])};
+  }
+}
+template <int K> DEV float bcast_row(const RowPair &p) { return K < 16 ? dpp_f<0x150 + (K & 15)>(p.r0) : dpp_f<0x150 + (K & 15)>(p.r1); }
+// acc += (lane K of my group of p) * nf
+template <int K> DEV void fmac_bcast(float &acc, const RowPair &p, float nf) {
+  asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(K < 16 ? p.r0 : p.r1), "v"(nf), "n"(K & 15));
+}
+template <class S, int G, int K> struct SymAnc {  // K walks the pivot's ancestor chain
+  static DEV void run(float (&a)[S::nv + 1], const RowPair &p, float nf) {
+    fmac_bcast<K>(a[K], p, nf);
+    SymAnc<S, G, S::dof_parent[K]>::run(a, p, nf);
+  }
+};
+template <class S, int G> struct SymAnc<S, G, -1> { static DEV void run(float (&)[S::nv + 1], const RowPair &, float) {} };
+template <class S, int G, int K> struct SymRest {  // dense order: every column after the pivot
+  static DEV void run(float (&a)[S::nv + 1], const RowPair &p, float nf) {
+    if constexpr (K < S::nv) {
+      fmac_bcast<K>(a[K], p, nf);
+      SymRest<S, G, K + 1>::run(a, p, nf);
+    }
+  }
+};
+template <class S, int G, int J, bool TREE, bool BCOL> DEV void sym_pivot(float (&a)[S::nv + 1], int gl) {
+  constexpr int N = S::nv;
+  const float c = a[J];
+  const RowPair p = row_pair<G>(c);
+  // max(lane J of p, MINVAL) in one instruction; the leading s_nop 1 is the 2 wait states after the swap / the last writer
+  float piv;
+  asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(piv) : "v"(J < 16 ? p.r0 : p.r1), "v"(MINVAL), "n"(J & 15));
+  float nf = -c * __builtin_amdgcn_rcpf(piv);
+  nf = gl == J ? 0.0f : nf;  // the pivot row itself is left alone
+  if constexpr (BCOL) {
+    fmac_bcast<N>(a[N], p, nf);
+  } else {
+    const RowPair pb = row_pair<G>(a[N]);
+    a[N] = __builtin_fmaf(nf, bcast_row<J>(pb), a[N]);
+  }
+  if constexpr (TREE) SymAnc<S, G, S::dof_parent[J]>::run(a, p, nf);
+  else SymRest<S, G, J + 1>::run(a, p, nf);
+}
+template <class S, int G, int J, bool BCOL> struct SymTree {  // leaves before their ancestors
+  static DEV void run(float (&a)[S::nv + 1], int gl) {
+    sym_pivot<S, G, J, true, BCOL>(a, gl);
+    SymTree<S, G, J - 1, BCOL>::run(a, gl);
+  }
+};
+template <class S, int G, bool BCOL> struct SymTree<S, G, -1, BCOL> { static DEV void run(float (&)[S::nv + 1], int) {} };
+template <class S, int G, int J, bool BCOL> struct SymDense {
+  static DEV void run(float (&a)[S::nv + 1], int gl) {
+    if constexpr (J < S::nv) {
+      sym_pivot<S, G, J, false, BCOL>(a, gl);
+      SymDense<S, G, J + 1, BCOL>::run(a, gl);
+    }
+  }
+};
+template <class S, int G> constexpr bool sym_elim_ok() { return S::is_static && G <= 32 && S::nv < G && !AMX_NO_SYM_ELIM; }
+
 template <class S, int G, bool TREE>
-AMX_STATIC_SOLVE_ATTR void spd_solve_static(int A_off, int rhs_off, int x_off, int gl, int rot) {
+AMX_STATIC_SOLVE_ATTR void spd_solve_static(int A_off, int rhs_off, int x_off, int gl, int rot, int bt_off) {
   constexpr int N = S::nv, ld = S::ldm, nch = ld / 4;
+  if constexpr (sym_elim_ok<S, G>()) {
+    // bt_off: an idle vector of ld floats (the M*v staging vector) through which b reaches lane N as a row; < 0: none, b is
+    // broadcast on its own (always so for 16-lane groups, where that costs nothing)
+    constexpr bool BCOL = G == 32;
+    float a[N + 1];
+    const int li = gl < N ? gl : 0;
+    float b = lds[rhs_off + li * DOF_E];
+    b = gl < N ? b : 0.0f;
+    const bool brow = BCOL && gl == N && bt_off >= 0;
+    if (BCOL && bt_off >= 0) {
+      if (gl < ld) lds[bt_off + gl] = b;
+      WSYNC();
+    }
+    const float4 *rowp = reinterpret_cast<const float4 *>(lds + (brow ? bt_off : A_off + li * ld));
+    const int rot_l = brow ? 0 : rot;
+#pragma unroll
+    for (int c = 0; c < (N + 3) / 4; ++c) {
+      int pc = c + (S::mrot ? rot_l : 0);
+      pc -= pc >= nch ? nch : 0;
+      const float4 v = rowp[pc];
+      const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = 4 * c + q;
+        if (k < N) a[k] = (gl < N || brow) ? e[q] : 0.0f;
+      }
+    }
+    a[N] = b;
+    if (BCOL && bt_off >= 0) {
+      if (TREE) SymTree<S, G, N - 1, true>::run(a, gl);
+      else SymDense<S, G, 0, true>::run(a, gl);
+    } else {
+      if (TREE) SymTree<S, G, N - 1, false>::run(a, gl);
+      else SymDense<S, G, 0, false>::run(a, gl);
+    }
+    float d = 1.0f;
+#pragma unroll
+    for (int k = 0; k < N; ++k) d = (k == gl) ? a[k] : d;
+    if (gl < N) lds[x_off + gl * DOF_E] = a[N] / d;
+    WSYNC();
+    return;
+  }
   float a[N];
   const int li = gl < N ? gl : 0;
   const float4 *rowp = reinterpret_cast<const float4 *>(lds + A_off + li * ld);
@@ -523,7 +650,46 @@ AMX_STATIC_SOLVE_ATTR void spd_solve_static(int A_off, int rhs_off, int x_off, i
 // those registers: H never touches LDS.  S static: N = nv, tree-sparse elimination when TREE; S = DynSpec: N is the padded size.
 template <class S, int N, int G, bool TREE>
 AMX_STATIC_SOLVE_ATTR void newton_solve_fused(int M_off, int ld_, int n_, unsigned long long crows_, int row_base, int J_base, int ldc_, int slot_base_,
-                                                int rhs_off, int x_off, float dlim, int gl, int gb4, int rot) {
+                                                int rhs_off, int x_off, float dlim, int gl, int gb4, int rot, int bt_off) {
+  if constexpr (sym_elim_ok<S, G>() && G == 32) {
+    // crossbar-free elimination (see sym_pivot): b reaches lane N as a row through the staging vector at bt_off
+    constexpr int NS = S::nv, lds_ = S::ldm, nchs = lds_ / 4;
+    const unsigned long long crows_u = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(crows_ >> 32)) << 32) |
+                                       (unsigned)__builtin_amdgcn_readfirstlane((int)crows_);
+    unsigned lo[4][4], hi[4][4];
+    jtdj_rows_mfma<G>(crows_u, row_base, J_base, S::ldc, S::c_slot, gl, lo, hi);
+    const bool owner = gl < NS, brow = gl == NS;
+    const int li = owner ? gl : 0;
+    float b = lds[rhs_off + li * DOF_E];
+    b = owner ? b : 0.0f;
+    if (gl < lds_) lds[bt_off + gl] = b;
+    WSYNC();
+    const float4 *rowp = reinterpret_cast<const float4 *>(lds + (brow ? bt_off : M_off + li * lds_));
+    const int rot_l = brow ? 0 : rot;
+    float a[NS + 1];
+#pragma unroll
+    for (int c = 0; c < (NS + 3) / 4; ++c) {
+      int pc = c + (S::mrot ? rot_l : 0);
+      pc -= pc >= nchs ? nchs : 0;
+      const float4 v = rowp[pc];
+      const unsigned *src = (c & 1) ? hi[c >> 1] : lo[c >> 1];
+      const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = 4 * c + q;
+        if (k < NS) a[k] = owner ? (e[q] + __uint_as_float(src[q])) + (k == gl ? dlim : 0.0f) : (brow ? e[q] : 0.0f);
+      }
+    }
+    a[NS] = b;
+    if constexpr (TREE) SymTree<S, G, NS - 1, true>::run(a, gl);
+    else SymDense<S, G, 0, true>::run(a, gl);
+    float d = 1.0f;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) d = (k == gl) ? a[k] : d;
+    if (owner) lds[x_off + gl * DOF_E] = a[NS] / d;
+    WSYNC();
+    return;
+  }
   const int ld = S::is_static ? S::ldm : __builtin_amdgcn_readfirstlane(ld_), n = S::is_static ? S::nv : __builtin_amdgcn_readfirstlane(n_);
   const int ldc = S::is_static ? S::ldc : __builtin_amdgcn_readfirstlane(ldc_), slot_base = S::is_static ? S::c_slot : __builtin_amdgcn_readfirstlane(slot_base_);
   const unsigned long long crows = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(crows_ >> 32)) << 32) |
@@ -561,8 +727,8 @@ AMX_STATIC_SOLVE_ATTR void newton_solve_fused(int M_off, int ld_, int n_, unsign
 template <int G>
 __device__ __noinline__ void newton_fused_dyn(int nchol, int M_off, int ld, int n, unsigned long long crows, int row_base, int J_base, int ldc, int slot_base,
                                               int rhs_off, int x_off, float dlim, int gl, int gb4, int rot) {
-#define AMX_NF_CASE(NN) else if (nchol <= NN) newton_solve_fused<DynSpec, NN, G, false>(M_off, ld, n, crows, row_base, J_base, ldc, slot_base, rhs_off, x_off, dlim, gl, gb4, rot);
-  if (nchol <= 4) newton_solve_fused<DynSpec, 4, G, false>(M_off, ld, n, crows, row_base, J_base, ldc, slot_base, rhs_off, x_off, dlim, gl, gb4, rot);
+#define AMX_NF_CASE(NN) else if (nchol <= NN) newton_solve_fused<DynSpec, NN, G, false>(M_off, ld, n, crows, row_base, J_base, ldc, slot_base, rhs_off, x_off, dlim, gl, gb4, rot, 0);
+  if (nchol <= 4) newton_solve_fused<DynSpec, 4, G, false>(M_off, ld, n, crows, row_base, J_base, ldc, slot_base, rhs_off, x_off, dlim, gl, gb4, rot, 0);
   AMX_NF_CASE(6) AMX_NF_CASE(8) AMX_NF_CASE(10) AMX_NF_CASE(12) AMX_NF_CASE(14) AMX_NF_CASE(16) AMX_NF_CASE(18)
   AMX_NF_CASE(20) AMX_NF_CASE(22) AMX_NF_CASE(24) AMX_NF_CASE(26) AMX_NF_CASE(28) AMX_NF_CASE(30) AMX_NF_CASE(32)
 #undef AMX_NF_CASE
@@ -611,8 +777,10 @@ struct LSPoint { float alpha, cost, d0, d1; };
 // Diagnostic build only (-DAMX_PROFILE, libamx_prof.so): per-phase cycle shares via s_memtime.  Never in the product build.
 #ifdef AMX_PROFILE
 #define PROF_N 24
-#define PROF_DECL unsigned prof_t;
-#define PROF(id) do { unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); if (gl == 0) lds[eb + m.e_prof() + (id)] += (float)(t_ - prof_t); prof_t = t_; } while (0)
+// The counters live in HBM (one row per environment, fire-and-forget atomic adds from the group's lane 0): the slab and the
+// launch plan are those of the product build, so the specialised kernels are the ones profiled.
+#define PROF_DECL unsigned prof_t; float *prof_row;
+#define PROF(id) do { unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); if (gl == 0 && prof_row) unsafeAtomicAdd(prof_row + (id), (float)(t_ - prof_t)); prof_t = t_; } while (0)
 #else
 #define PROF_DECL
 #define PROF(id)
@@ -1795,7 +1963,7 @@ struct Env {
         dlim = (gl < nv && d_limrow >= 0 && nA() > 0) ? dlim : 0.0f;
         PROF(19);
         if constexpr (S::is_static)
-          newton_solve_fused<S, S::nv, G, S::tree_H>(Mo, ldm, nv, rows, eb + m.e_row() + row0 * ROW_E, Jo, ldc, m.c_slot(), dofoff(D_GRAD), dofoff(D_MGRAD), dlim, gl, gb4, m_rot);
+          newton_solve_fused<S, S::nv, G, S::tree_H>(Mo, ldm, nv, rows, eb + m.e_row() + row0 * ROW_E, Jo, ldc, m.c_slot(), dofoff(D_GRAD), dofoff(D_MGRAD), dlim, gl, gb4, m_rot, eb + m.e_H());
         else
           newton_fused_dyn<G>(m.nchol(), Mo, ldm, nv, rows, eb + m.e_row() + row0 * ROW_E, Jo, ldc, m.c_slot(), dofoff(D_GRAD), dofoff(D_MGRAD), dlim, gl, gb4, m_rot);
         PROF(14);
@@ -1845,7 +2013,7 @@ struct Env {
       WSYNC();
     }
     PROF(14);
-    if constexpr (S::is_static) spd_solve_static<S, G, S::tree_H>(Ho, dofoff(D_GRAD), dofoff(D_MGRAD), gl, m_rot);
+    if constexpr (S::is_static) spd_solve_static<S, G, S::tree_H>(Ho, dofoff(D_GRAD), dofoff(D_MGRAD), gl, m_rot, -1);
     else spd_solve<G>(m.nchol(), Ho, ldm, nv, dofoff(D_GRAD), dofoff(D_MGRAD), gl, gb4, m_rot);
   }
 
@@ -2046,7 +2214,7 @@ struct Env {
     // qacc_smooth = M^-1 qfrc_smooth.  Newton never reuses the factor: one-shot Gauss-Jordan solve;
     // CG keeps a Cholesky factor in Lb as its preconditioner.
     if (m.solver() == 2) {
-      if constexpr (S::is_static) spd_solve_static<S, G, true>(eb + m.e_M(), dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), gl, m_rot);
+      if constexpr (S::is_static) spd_solve_static<S, G, true>(eb + m.e_M(), dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), gl, m_rot, eb + m.e_H());
       else spd_solve<G>(m.nchol(), eb + m.e_M(), m.ldm(), nv, dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), gl, gb4, m_rot);
     }
     else chol_solve<G>(m.nchol(), eb + m.e_M(), m.ldm(), nv, eb + m.e_Lb(), dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), true, gl, gb4);
@@ -2070,7 +2238,7 @@ struct Env {
       // M + dt*diag(damping) in place: this is the last reader of M in the step and the crb pass rewrites it
       if (gl < nv) { dof(D_SEARCH, gl) = dof(D_FSMOOTH, gl) + dof(D_FCON, gl); lds[Mo + m_diag] += m.dt() * CF(m.c_dof() + gl * DOF_S + 5); }
       WSYNC();
-      if constexpr (S::is_static) spd_solve_static<S, G, true>(Mo, dofoff(D_SEARCH), dofoff(D_MV), gl, m_rot);
+      if constexpr (S::is_static) spd_solve_static<S, G, true>(Mo, dofoff(D_SEARCH), dofoff(D_MV), gl, m_rot, eb + m.e_H());
       else spd_solve<G>(m.nchol(), Mo, m.ldm(), nv, dofoff(D_SEARCH), dofoff(D_MV), gl, gb4, m_rot);
     } else {
       if (gl < nv) dof(D_MV, gl) = dof(D_QACC, gl);
@@ -2155,6 +2323,7 @@ amx_rollout_kernel(const DevModel m_in, int nenv, int nsteps, int x0_batched, co
   AMX_KERNEL_PROLOGUE()
 #ifdef AMX_PROFILE
   env.prof_t = (unsigned)__builtin_amdgcn_s_memtime();
+  env.prof_row = (prof && live) ? prof + (size_t)e * PROF_N : nullptr;
 #endif
   const float *x0 = x0g + ((x0_batched && live) ? (size_t)e * nx : 0);
   if (live) {
@@ -2185,16 +2354,11 @@ amx_rollout_kernel(const DevModel m_in, int nenv, int nsteps, int x0_batched, co
       }
     }
 #ifdef AMX_PROFILE
-    { unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); if (gl == 0) lds[eb + m.e_prof() + 18] += (float)(t_ - env.prof_t); env.prof_t = t_; }
+    { unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); if (gl == 0 && env.prof_row) unsafeAtomicAdd(env.prof_row + 18, (float)(t_ - env.prof_t)); env.prof_t = t_; }
 #endif
   }
   if (xfinal && live)
     for (int i = gl; i < nx; i += G) xfinal[(size_t)e * nx + i] = i < nq ? lds[qp + i] : lds[qv + i - nq];
-#ifdef AMX_PROFILE
-  WSYNC();
-  if (prof && live && gl < PROF_N) prof[(size_t)e * PROF_N + gl] = lds[eb + m.e_prof() + gl];
-  if (prof && live && G < PROF_N && gl + G < PROF_N) prof[(size_t)e * PROF_N + gl + G] = lds[eb + m.e_prof() + gl + G];
-#endif
 }
 
 // MjxEnv.pipeline_step: nsub physics steps with ctrl held; state comes from and returns to HBM.

@@ -445,9 +445,7 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
     m.e_H = m.fusedH ? vstage : take(std::max(nv * m.ldm, nv + 8));
   }
   m.e_Lb = d->solver == 1 ? take(ntri) : m.e_H;
-#ifdef AMX_PROFILE
-  m.e_prof = take(24);
-#endif
+  m.e_prof = 0;  // (unused since r02b: the diagnostic build keeps its counters in HBM)
   m.env_floats = (off + 3) & ~3;  // slabs keep 16-byte alignment
   // waves per workgroup: each workgroup carries one copy of the constants, so pick the size that keeps the most
   // waves resident per CU (160 KiB of LDS, at most AMX_MIN_WAVES_PER_SIMD*4 waves by registers); ties go to the larger

@@ -10,7 +10,7 @@ from ambersim_amd.utils.io_utils import load_mj_model_from_file
 from bench import make_inputs
 dev = torch.device("cuda", 0)
 out = []
-for path, nenv, hor in (("models/quadruped/quadruped.xml", 4096, 1000), ("models/biped/biped.xml", 4096, 1000), ("models/biped/biped.xml", 1024, 64)):
+for path, nenv, hor in (("models/quadruped/quadruped.xml", 4096, 1000), ("models/biped/biped.xml", 4096, 1000), ("models/biped/biped.xml", 1024, 64), ("models/quadruped/quadruped.xml", 32768, 200), ("models/biped/biped.xml", 32768, 100)):
     mj = load_mj_model_from_file(path); model = mjx.put_model(mj, dev)
     x0, us = make_inputs(mj, nenv, hor, 1, 2, dev)
     mjx.rollout(model, x0, us); torch.cuda.synchronize()

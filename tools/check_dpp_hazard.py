@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Checks the emitted gfx950 code for the one hazard the compiler cannot see for us: a DPP instruction written as inline
+assembly (v_fmac_f32_dpp in the static eliminations) whose DPP source register (src0) was written by a VALU instruction
+fewer than 2 wait states earlier.  Wait states: every instruction issued in between counts 1, `s_nop N` counts N + 1.
+python tools/check_dpp_hazard.py [ambersim_amd/csrc/amx_gfx950.s]   (make -C ambersim_amd/csrc asm writes that file)"""
+import os, re, sys
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "ambersim_amd", "csrc", "amx_gfx950.s")
+reg = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+def regs(tok):
+    out = set()
+    for m in reg.finditer(tok):
+        if m.group(1): out.add(int(m.group(1)))
+        else: out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+bad = checked = 0
+func = None
+hist = []  # (written vgprs, wait states this instruction accounts for)
+for line in open(path):
+    m = re.match(r"^(_Z\w+):", line)
+    if m: func, hist = m.group(1), []; continue
+    t = line.strip()
+    if not line.startswith("\t") or t.startswith((".", ";")) or not t: continue
+    op, _, rest = t.partition(" ")
+    ops = [o.strip() for o in rest.split(",")]
+    if "_dpp" in op and op.startswith("v_fmac"):
+        checked += 1
+        src0 = regs(ops[1].split()[0])
+        ws = 0
+        for wr, n in reversed(hist):
+            if ws >= 2: break
+            if wr & src0:
+                bad += 1
+                print(f"HAZARD in {func}: `{t}` reads {sorted(src0)} written {ws} wait states earlier")
+                break
+            ws += n
+    if op == "s_nop": hist.append((set(), int(ops[0], 0) + 1))
+    elif op.startswith("v_") and not op.startswith("v_cmp"):
+        w = regs(ops[0])
+        if op.startswith("v_permlane") and len(ops) > 1: w |= regs(ops[1])  # the swaps write both operands
+        hist.append((w, 1))
+    elif op.startswith(("s_cbranch", "s_branch", "s_setpc", "s_swappc")): hist = []  # label targets: start over (conservative enough: producers are in-block)
+    else: hist.append((set(), 1))
+    hist = hist[-4:]
+print(f"{checked} inline-assembly DPP multiply-adds checked, {bad} hazards")
+sys.exit(1 if bad else 0)

@@ -37,6 +37,7 @@ ms = t0.elapsed_time(t1)
 p = prof.cpu().numpy().astype(np.float64)
 tot = p.sum(axis=1).mean()
 print(f"{model_path}: {nenv} envs x {steps} steps  kernel {ms:.2f} ms  -> {nenv*steps/ms*1e3/1e6:.2f} M env-steps/s")
+print(f"kernel: {'specialised' if model._h.query('specialised') else 'generic'}, lane group {model._h.query('lanes_per_env')}, {model._h.query('envs_per_block')} envs per workgroup")
 print(f"mean cycles per env-step per wave: {tot/steps:.0f}")
 for i in range(24):
     v = p[:, i].mean()
