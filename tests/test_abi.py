@@ -149,3 +149,17 @@ def test_per_model_specialised_build():
     assert path.exists() and path == _spec.build_specialised_library(mj)  # cached
     L = _lib.load(path)
     assert L.amx_version() == 2
+
+
+def test_inline_assembly_dpp_reads_keep_their_wait_states():
+    """The crossbar-free eliminations issue v_fmac_f32_dpp as inline assembly, which the compiler's hazard recogniser does not
+    look into: tools/check_dpp_hazard.py re-checks on the emitted gfx950 code that no such instruction reads a register a
+    VALU instruction wrote fewer than 2 wait states earlier."""
+    hipcc = os.environ.get("AMX_HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "ambersim_amd", "csrc")
+    subprocess.run(["make", "-C", csrc, "asm"], check=True, capture_output=True)
+    r = subprocess.run(["python3", os.path.join(ROOT, "tools", "check_dpp_hazard.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert int(r.stdout.strip().splitlines()[-1].split()[0]) > 1000  # the check saw the eliminations
