@@ -135,6 +135,15 @@ def jit_test_model():
     return recompile_options(mj)
 
 
+def jit_test_model_equality():
+    """A second one: the quadruped with its two front knees coupled by a joint equality - equality rows, so the Hessian is
+    stored and solved densely (no fused path) in a 32-lane group, the one static-solve combination no shipped model has."""
+    from ambersim_amd.mjcf import MjModel
+    xml = open(os.path.join(ROOT, "ambersim_amd", "models", "quadruped", "quadruped.xml")).read()
+    xml = xml.replace("<actuator>", '<equality><joint joint1="fl_knee" joint2="fr_knee" polycoef="0 1 0 0 0"/></equality>\n  <actuator>')
+    return MjModel.from_xml_string(xml)
+
+
 def test_per_model_specialised_build():
     """ambersim_amd._spec.build_specialised_library: the record of an arbitrary model is rendered and csrc/ compiles against it
     (hipcc cross-compiles without a GPU); the library exports the whole ABI.  The build is cached in csrc/jit/, where the GPU
@@ -149,6 +158,10 @@ def test_per_model_specialised_build():
     assert path.exists() and path == _spec.build_specialised_library(mj)  # cached
     L = _lib.load(path)
     assert L.amx_version() == 2
+    mj2 = jit_test_model_equality()
+    p2 = _spec.plan(mj2)
+    assert p2["neq"] == "1" and p2["G"] == "32" and p2["fusedH"] == "0"
+    assert _spec.build_specialised_library(mj2).exists()
 
 
 def test_inline_assembly_dpp_reads_keep_their_wait_states():

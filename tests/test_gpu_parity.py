@@ -220,6 +220,23 @@ def test_per_model_specialised_build_runs(cases, dev):
     assert t["specialised"] < t["generic"]
 
 
+def test_per_model_build_with_equality_rows(cases, dev):
+    """The static solves' remaining combination (32-lane group, stored Hessian, dense elimination, right-hand side broadcast on
+    its own): the quadruped with its front knees coupled, compiled for its plan, against the generic kernels and the oracle."""
+    from test_abi import jit_test_model_equality
+    from ambersim_amd import mjx
+    from oracle.oracle import Oracle
+    mj = jit_test_model_equality()
+    _, _, x0, us = cases["quadruped"]
+    generic = mjx.put_model(mj, dev)
+    fast = mjx.put_model(mj, dev, specialise=True)
+    assert generic._h.query("specialised") == 0 and fast._h.query("specialised") == 1
+    a, b = gpu_rollout(generic, x0, us), gpu_rollout(fast, x0, us)
+    ref = Oracle(mj, np.float64).rollout(x0.astype(np.float32), us.astype(np.float32))
+    print(f"equality model: 1-step generic {rel(a[:, 1], ref[:, 1]):.2e}, specialised {rel(b[:, 1], ref[:, 1]):.2e}; 3-step spec vs generic {rel(a[:, 3], b[:, 3]):.2e}")
+    assert rel(a[:, 1], ref[:, 1]) < TOL and rel(b[:, 1], ref[:, 1]) < TOL and rel(a[:, 3], b[:, 3]) < 5e-5
+
+
 def test_step_api_matches_rollout_bitwise(cases):
     """amx_step (state through HBM each call, warm start carried) and amx_rollout (state in LDS) run the same phases:
     identical bits after 20 steps."""
