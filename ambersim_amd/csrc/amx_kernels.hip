@@ -111,15 +111,31 @@ DEV f3 mulTv(const m33 &M, f3 v) {
              M.a[2] * v.x + M.a[5] * v.y + M.a[8] * v.z);
 }
 DEV f3 qrot(f4 q, f3 v) { return mulv(q2m(q), v); }
+// x / y without the IEEE expansion (two v_div_scale, v_div_fmas, v_div_fixup around the same v_rcp_f32): reciprocal, one
+// residual correction.  Within 1 ulp of the correctly rounded quotient for operands whose reciprocal neither overflows nor
+// goes denormal - used where the operands are sums of squares, clamped pivots and step lengths (AMX_IEEE_DIV=1: plain x / y).
+#ifndef AMX_IEEE_DIV
+#define AMX_IEEE_DIV 0
+#endif
+DEV float fdiv(float x, float y) {
+#if AMX_IEEE_DIV
+  return x / y;
+#else
+  const float r = __builtin_amdgcn_rcpf(y);
+  const float q = x * r;
+  return __builtin_fmaf(__builtin_fmaf(-y, q, x), r, q);
+#endif
+}
 DEV f4 qnormalize(f4 q) {
   float n = sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
-  if (n > 0) { float s = 1.0f / n; q.w *= s; q.x *= s; q.y *= s; q.z *= s; }
+  if (n > 0) { float s = fdiv(1.0f, n); q.w *= s; q.x *= s; q.y *= s; q.z *= s; }
   return q;
 }
 DEV f3 normalize3(f3 v, float *len) {
   float n = sqrtf(dot(v, v));
   *len = n;
-  return n > 0 ? mk3(v.x / n, v.y / n, v.z / n) : v;
+  const float s = fdiv(1.0f, n > 0 ? n : 1.0f);
+  return n > 0 ? mk3(v.x * s, v.y * s, v.z * s) : v;
 }
 // sin and cos of a joint-sized angle (|x| up to a few thousand radians): nearest multiple of pi/2 removed with a two-term
 // Cody-Waite reduction (exact products through fma), then the classical single-precision minimax polynomials on
@@ -614,7 +630,7 @@ AMX_STATIC_SOLVE_ATTR void spd_solve_static(int A_off, int rhs_off, int x_off, i
     float d = 1.0f;
 #pragma unroll
     for (int k = 0; k < N; ++k) d = (k == gl) ? a[k] : d;
-    if (gl < N) lds[x_off + gl * DOF_E] = a[N] / d;
+    if (gl < N) lds[x_off + gl * DOF_E] = fdiv(a[N], d);
     WSYNC();
     return;
   }
@@ -640,7 +656,7 @@ AMX_STATIC_SOLVE_ATTR void spd_solve_static(int A_off, int rhs_off, int x_off, i
   float d = 1.0f;
 #pragma unroll
   for (int k = 0; k < N; ++k) d = (k == gl) ? a[k] : d;
-  if (gl < N) lds[x_off + gl * DOF_E] = b / d;
+  if (gl < N) lds[x_off + gl * DOF_E] = fdiv(b, d);
   WSYNC();
 }
 
@@ -686,7 +702,7 @@ AMX_STATIC_SOLVE_ATTR void newton_solve_fused(int M_off, int ld_, int n_, unsign
     float d = 1.0f;
 #pragma unroll
     for (int k = 0; k < NS; ++k) d = (k == gl) ? a[k] : d;
-    if (owner) lds[x_off + gl * DOF_E] = a[NS] / d;
+    if (owner) lds[x_off + gl * DOF_E] = fdiv(a[NS], d);
     WSYNC();
     return;
   }
@@ -721,7 +737,7 @@ AMX_STATIC_SOLVE_ATTR void newton_solve_fused(int M_off, int ld_, int n_, unsign
   float d = 1.0f;
 #pragma unroll
   for (int k = 0; k < N; ++k) d = (k == gl) ? a[k] : d;
-  if (owner) lds[x_off + gl * DOF_E] = b / d;
+  if (owner) lds[x_off + gl * DOF_E] = fdiv(b, d);
   WSYNC();
 }
 template <int G>
@@ -763,7 +779,7 @@ __device__ __noinline__ void chol_solve(int nchol, int A_off, int ld, int n, int
 // impedance of one constraint row [A9.6]; k and b are folded on the host, rec points at {k,b,dmin,dmax,width,mid,power,ca,cb}
 DEV float row_impedance(int rec, float pos) {
   const float dmin = CF(rec + 2), dmax = CF(rec + 3), width = CF(rec + 4), mid = CF(rec + 5), power = CF(rec + 6);
-  const float x = fabsf(pos) / width;
+  const float x = fdiv(fabsf(pos), width);
   float ia, ib;
   if (power == 2.0f) { ia = CF(rec + 7) * (x * x); ib = 1.0f - CF(rec + 8) * ((1 - x) * (1 - x)); }
   else { ia = CF(rec + 7) * powf(x, power); ib = 1.0f - CF(rec + 8) * powf(1 - x, power); }
@@ -1804,8 +1820,8 @@ struct Env {
       }
       if (active) {
         const float imp = row_impedance(rec, pos);
-        const float rr = fmaxf(invw * (1 - imp) / imp, MINVAL);
-        dd = 1.0f / rr;
+        const float rr = fmaxf(fdiv(invw * (1 - imp), imp), MINVAL);
+        dd = fdiv(1.0f, rr);
         ar = -CF(rec + 1) * jv - CF(rec) * imp * pos;
       }
     }
@@ -1820,7 +1836,7 @@ struct Env {
       const float pos = dist - margin;
       const float mu = CF(prec + 11), tw = CF(prec + 22);
       const float f = (k & 1) ? -mu : mu;
-      const float invw = (tw + f * f * tw) * 2 * f * f / m.impratio();
+      const float invw = fdiv((tw + f * f * tw) * 2 * f * f, m.impratio());
       float jv = 0;
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
@@ -1834,8 +1850,8 @@ struct Env {
       if (dist < margin) {
         const int rec = prec + 12;
         const float imp = row_impedance(rec, pos);
-        const float rr = fmaxf(invw * (1 - imp) / imp, MINVAL);
-        dd = 1.0f / rr;
+        const float rr = fmaxf(fdiv(invw * (1 - imp), imp), MINVAL);
+        dd = fdiv(1.0f, rr);
         ar = -CF(rec + 1) * jv - CF(rec) * imp * pos;
       }
     }
@@ -2063,7 +2079,7 @@ struct Env {
 #define PICK(c, a, b) { (c) ? (a).alpha : (b).alpha, (c) ? (a).d0 : (b).d0, (c) ? (a).d1 : (b).d1 }
     const LSPoint p0 = POINT(0.0f);
     const LSD p0d = {p0.alpha, p0.d0, p0.d1};
-    const LSD p1 = DERIV(p0.alpha - p0.d0 / p0.d1);
+    const LSD p1 = DERIV(p0.alpha - fdiv(p0.d0, p0.d1));
     const bool first = p1.d0 < p0.d0;
     LSD lo = PICK(first, p1, p0d), hi = PICK(first, p0d, p1);
     bool swap = true;
@@ -2073,8 +2089,8 @@ struct Env {
       done = done || ((lo.d0 < 0) && (lo.d0 > -gtol));
       done = done || ((hi.d0 > 0) && (hi.d0 < gtol));
       if (!wave_any(!done && alive)) break;  // every group of the wave has finished its search
-      const LSD lo_next = DERIV(lo.alpha - lo.d0 / lo.d1);
-      const LSD hi_next = DERIV(hi.alpha - hi.d0 / hi.d1);
+      const LSD lo_next = DERIV(lo.alpha - fdiv(lo.d0, lo.d1));
+      const LSD hi_next = DERIV(hi.alpha - fdiv(hi.d0, hi.d1));
       const LSD mid = DERIV(0.5f * (lo.alpha + hi.alpha));
       LSD nlo = lo, nhi = hi;
       const bool s_lo_next = (nlo.d0 > 0) || (nlo.d0 < lo_next.d0);
@@ -2148,8 +2164,8 @@ struct Env {
       if (m.iterations() != 1) {
         const float g = gl < nv ? dof(D_GRAD, gl) : 0.0f;
         const float gn = gsum<G>(g * g);
-        bool done = ((prev_cost - cost) / m.scale() < m.tolerance());
-        done = done || (sqrtf(gn) / m.scale() < m.tolerance());
+        bool done = (fdiv(prev_cost - cost, m.scale()) < m.tolerance());
+        done = done || (fdiv(sqrtf(gn), m.scale()) < m.tolerance());
         alive = alive && !done;
       }
       if (!wave_any(alive)) break;
