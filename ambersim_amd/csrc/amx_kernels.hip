@@ -693,7 +693,10 @@ AMX_STATIC_SOLVE_ATTR void newton_solve_fused(int M_off, int ld_, int n_, unsign
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int k = 4 * c + q;
-        if (k < NS) a[k] = owner ? (e[q] + __uint_as_float(src[q])) + (k == gl ? dlim : 0.0f) : (brow ? e[q] : 0.0f);
+        if (k < NS) {  // both arms computed, then selected: a lazily evaluated ?: became a branch per entry
+          const float hk = (e[q] + __uint_as_float(src[q])) + (k == gl ? dlim : 0.0f), bk = brow ? e[q] : 0.0f;
+          a[k] = owner ? hk : bk;
+        }
       }
     }
     a[NS] = b;
@@ -1837,16 +1840,7 @@ struct Env {
       const float mu = CF(prec + 11), tw = CF(prec + 22);
       const float f = (k & 1) ? -mu : mu;
       const float invw = fdiv((tw + f * f * tw) * 2 * f * f, m.impratio());
-      float jv = 0;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const int pk = rchain[w];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int t = 4 * w + q;
-          if (t < rdn) jv += lds[Jo + cr * ldc + t] * lds[qv + ((pk >> (8 * q)) & 255)];
-        }
-      }
+      const float jv = chain_dot(Jo + cr * ldc, qv, 1);
       if (dist < margin) {
         const int rec = prec + 12;
         const float imp = row_impedance(rec, pos);
@@ -1887,21 +1881,33 @@ struct Env {
     if (rd2 >= 0) a += rJ2 * lds[vo + rd2 * DOF_E];
     return a;
   }
-  DEV float row_dot_B(int vf) const {
-    const int vo = dofoff(vf);
-    if (gl >= nB()) return 0.0f;
-    const int Jr = eb + m.e_J() + gl * m.ldc();
-    float a = 0;
+  // sum over the contact row's dof list of J[t] * v[dof_t] (J at Jr, v at vo with stride vs).  Branch-free: every term of
+  // the row's ldc slots is loaded (slots past the list hold stale floats of the slab, dof index 0) and a select keeps
+  // the listed ones, so all the loads are in flight together - one LDS latency per dot product instead of one per term
+  // behind a divergent branch (r02b: 56 such branches per step, each with its own wait).  Two partial sums.
+  DEV float chain_dot(int Jr, int vo, int vs) const {
+    float a0 = 0, a1 = 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {  // dof list from registers: no metadata loads on this path
       const int pk = rchain[w];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int t = 4 * w + q;
-        if (t < rdn) a += lds[Jr + t] * lds[vo + ((pk >> (8 * q)) & 255) * DOF_E];
+        if (t < m.ldc()) {  // static in the specialised kernels, wave-uniform otherwise
+          // the select sits on the Jacobian entry (stale slots become 0; v is always a live dof value), so each term stays
+          // one fused multiply-add as in the branchy loop
+          const float jraw = lds[Jr + t], vt = lds[vo + ((pk >> (8 * q)) & 255) * vs];  // loaded unconditionally, then selected
+          const float jt = t < rdn ? jraw : 0.0f;
+          if (t & 1) a1 = __builtin_fmaf(jt, vt, a1); else a0 = __builtin_fmaf(jt, vt, a0);
+        }
       }
     }
-    return a;
+    return a0 + a1;
+  }
+  DEV float row_dot_B(int vf) const {
+    const bool valid = gl < nB();
+    const float a = chain_dot(eb + m.e_J() + (valid ? gl : 0) * m.ldc(), dofoff(vf), DOF_E);
+    return valid ? a : 0.0f;
   }
   // Ma = M v, Jaref = J v - aref  (v = dof field vf)
   DEV void init_context(int vf) {
