@@ -1169,7 +1169,7 @@ struct Env {
   const MV<S> m;
   const int eb, gl, gb4;  // slab base, lane-in-group, 4 * first lane of the group (crossbar address base)
   // static role constants of this lane
-  int b_parent, b_level, b_root, b_jntadr, b_jntnum, b_childadr, b_childnum;  // body `lane`
+  int b_parent, b_level, b_root, b_jntadr, b_jntnum, b_childadr, b_childnum, b_subend;  // body `lane` (b_subend: one past its last descendant)
   int d_body, d_jnt, d_kind, d_axis, d_root, d_jadr, d_limrow;                // dof `lane` (d_jadr: first dof of its joint; d_limrow: lane of its limit row)
   int m_rot, m_diag;  // row `lane` of M: chunk rotation of the row (0 unless MV::mrot), float offset of its diagonal entry inside M
   // Constraint rows: a lane owns TWO row slots, so that a group of G lanes carries up to 2 G rows -
@@ -1192,7 +1192,7 @@ struct Env {
     const int lane = gl;
     const int br = m.c_body() + (lane < m.nb() ? lane : 0) * BODY_S;
     b_parent = CI(br); b_level = lane < m.nb() ? CI(br + 1) : -1; b_root = CI(br + 2); b_jntadr = CI(br + 3); b_jntnum = CI(br + 4);
-    b_childadr = CI(br + 5); b_childnum = CI(br + 6);
+    b_childadr = CI(br + 5); b_childnum = CI(br + 6) & 255; b_subend = CI(br + 6) >> 8;
     const int dr = m.c_dof() + (lane < m.nv() ? lane : 0) * DOF_S;
     d_body = CI(dr); d_jnt = CI(dr + 1); d_kind = CI(dr + 2); d_axis = CI(dr + 3); d_root = CI(dr + 8); d_jadr = CI(dr + 9); d_limrow = CI(dr + 10);
     {
@@ -1419,6 +1419,39 @@ struct Env {
   // ------------------------------------------------------------------ A9.3 crb + mass matrix
   DEV void crb_and_M() {
     const int b = gl, nv = m.nv();
+    if (m.subtree_contig()) {
+      // crb_b = sum of cinert over the subtree of b = the records b .. b_subend-1 (depth-first numbering): every lane adds up
+      // its own range, all loads independent - no level-by-level dependence.  A lane past its range reads the world body's
+      // record, which is all zeros.  The tree roots (whole trees: the longest ranges by far) wait for their children instead:
+      // the common trip count is the largest subtree below a root (quadruped 3, biped 7 instead of 13 and 22).
+      const bool isb = b > 0 && b < m.nb(), inner = isb && b_parent > 0;
+      float r[10];
+#pragma unroll
+      for (int k = 0; k < 10; ++k) r[k] = 0.0f;
+#pragma unroll 4
+      for (int k = 0; k < m.sub_iter(); ++k) {
+        const int d_ = b + k, src = (inner && d_ < b_subend) ? d_ : 0;
+#pragma unroll
+        for (int q = 0; q < 10; ++q) r[q] += body(F_CINERT + q, src);
+      }
+      if (inner) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) body(F_CRB + k, b) = r[k];
+      }
+      WSYNC();
+      if (isb && !inner) {  // a root: itself + its children's composites
+#pragma unroll
+        for (int k = 0; k < 10; ++k) r[k] = body(F_CINERT + k, b);
+        for (int c = 0; c < b_childnum; ++c) {
+          const int cb = CI(m.c_child() + b_childadr + c);
+#pragma unroll
+          for (int k = 0; k < 10; ++k) r[k] += body(F_CRB + k, cb);
+        }
+#pragma unroll
+        for (int k = 0; k < 10; ++k) body(F_CRB + k, b) = r[k];
+      }
+      WSYNC();
+    } else
     for (int L = m.nlevel() - 1; L >= 1; --L) {
       if (b_level == L) {
         float r[10];
@@ -1434,6 +1467,7 @@ struct Env {
       }
       WSYNC();
     }
+    PROF(20);
     if (gl < nv) {
       float I[10];
 #pragma unroll
@@ -1525,6 +1559,7 @@ struct Env {
       }
       WSYNC();
     }
+    PROF(23);
     if (b > 0 && b < m.nb()) {  // local force of every body in parallel: I cacc + cvel x* (I cvel)
       const sv cv = ld_bsv(F_CVEL, b), ca = ld_bsv(F_CACC, b);
       float I[10];
@@ -1537,6 +1572,32 @@ struct Env {
       st_bsv(F_CFRC, b, f);
     }
     WSYNC();
+    if (m.subtree_contig()) {
+      // total force below each body = sum of the local forces over its record range (see crb_and_M); read everything, then
+      // store; the roots then add their children's totals
+      const bool isb = b > 0 && b < m.nb(), inner = isb && b_parent > 0;
+      sv f = {{0, 0, 0, 0, 0, 0}};
+#pragma unroll 4
+      for (int k = 0; k < m.sub_iter(); ++k) {
+        const int d_ = b + k;
+        const sv g = ld_bsv(F_CFRC, (inner && d_ < b_subend) ? d_ : 0);
+#pragma unroll
+        for (int e = 0; e < 6; ++e) f.v[e] += g.v[e];
+      }
+      WSYNC();
+      if (inner) st_bsv(F_CFRC, b, f);
+      WSYNC();
+      if (isb && !inner) {
+        f = ld_bsv(F_CFRC, b);
+        for (int c = 0; c < b_childnum; ++c) {
+          const sv g = ld_bsv(F_CFRC, CI(m.c_child() + b_childadr + c));
+#pragma unroll
+          for (int e = 0; e < 6; ++e) f.v[e] += g.v[e];
+        }
+        st_bsv(F_CFRC, b, f);
+      }
+      WSYNC();
+    } else
     for (int L = m.nlevel() - 2; L >= 1; --L) {  // up-scan: gather children
       if (b_level == L && b_childnum > 0) {
         sv f = ld_bsv(F_CFRC, b);

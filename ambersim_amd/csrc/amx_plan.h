@@ -157,13 +157,29 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
     child_num[b] = (int)child_list.size() - child_adr[b];
   }
 
+  // subtree of body b = bodies b .. sub_last[b] when the bodies are numbered depth-first (MuJoCo's order): the up-scans then
+  // sum contiguous record ranges instead of walking the tree level by level
+  std::vector<int> sub_last(nb);
+  for (int b = 0; b < nb; b++) sub_last[b] = b;
+  for (int b = nb - 1; b >= 1; b--) sub_last[d->body_parentid[b]] = std::max(sub_last[d->body_parentid[b]], sub_last[b]);
+  m.subtree_contig = 1;
+  for (int c = 1; c < nb; c++) {  // contiguous iff every body between an ancestor and c is also below that ancestor
+    for (int a = d->body_parentid[c]; a > 0; a = d->body_parentid[a])
+      for (int x = a + 1; x < c; x++) {
+        bool below = false;
+        for (int y = x; y > 0; y = d->body_parentid[y]) if (y == a) { below = true; break; }
+        if (!below) m.subtree_contig = 0;
+      }
+  }
+  m.sub_iter = 1;
+  for (int b = 1; b < nb; b++) if (d->body_parentid[b] > 0) m.sub_iter = std::max(m.sub_iter, sub_last[b] - b + 1);
   // bodies
   m.c_body = im.reserve(nb * BODY_S);
   for (int b = 0; b < nb; b++) {
     int o = m.c_body + b * BODY_S;
     im.seti(o, d->body_parentid[b]); im.seti(o + 1, depth[b]); im.seti(o + 2, root_slot[b]);
     im.seti(o + 3, d->body_jntadr[b] < 0 ? 0 : d->body_jntadr[b]); im.seti(o + 4, d->body_jntnum[b]);
-    im.seti(o + 5, child_adr[b]); im.seti(o + 6, child_num[b]);
+    im.seti(o + 5, child_adr[b]); im.seti(o + 6, (child_num[b] & 255) | ((m.subtree_contig ? sub_last[b] + 1 : 0) << 8));
     for (int k = 0; k < 3; k++) { im.setf(o + 7 + k, d->body_pos[3 * b + k]); im.setf(o + 14 + k, d->body_ipos[3 * b + k]); im.setf(o + 22 + k, d->body_inertia[3 * b + k]); }
     for (int k = 0; k < 4; k++) { im.setf(o + 10 + k, d->body_quat[4 * b + k]); im.setf(o + 17 + k, d->body_iquat[4 * b + k]); }
     im.setf(o + 21, d->body_mass[b]);
