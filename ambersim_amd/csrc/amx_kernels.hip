@@ -31,6 +31,12 @@
 // vector registers through scratch memory (callee-saved v40..v255), which cost the biped 24 % (r02 A/B).  The generic
 // kernels keep their size-dispatched solves out of line (fifteen instantiations per call site would not fit the I-cache).
 #define AMX_STATIC_SOLVE_ATTR __device__ __forceinline__
+#ifndef AMX_CHAIN_WALK_MIN_LEVELS
+#define AMX_CHAIN_WALK_MIN_LEVELS 5
+#endif
+#ifndef AMX_LEVEL_SCANS
+#define AMX_LEVEL_SCANS 0  // 1: poses and velocities travel down the tree level by level as before (A/B switch)
+#endif
 #ifndef AMX_NO_SYM_ELIM
 #define AMX_NO_SYM_ELIM 0  // 1: the static eliminations broadcast pivot rows through the crossbar as before (A/B switch)
 #endif
@@ -1313,6 +1319,33 @@ struct Env {
       body(3, b) = quat.w; body(4, b) = quat.x; body(5, b) = quat.y; body(6, b) = quat.z;
     }
     WSYNC();
+    if (m.nlevel() > AMX_CHAIN_WALK_MIN_LEVELS && !AMX_LEVEL_SCANS) {  // shallow trees: the level scan is as fast (quadruped, 5 levels: measured)
+      // every body walks its own ancestor chain (root first, constants c_anc) and composes the local poses in registers: the
+      // same products in the same order as the level-by-level scan, but the loads are independent and nothing waits for a
+      // parent's result to come back through LDS.  Chains are padded with the world body, whose pose is the identity (exact
+      // no-ops).  All local poses are read before any world pose is stored.
+      const bool deep = b > 0 && b < m.nb() && b_level >= 2;
+      const int bs = deep ? b : 0, W = m.nlevel() - 2, ar = m.c_anc() + bs * W;
+      const f3 lp = ld_xpos(bs);
+      const f4 lq = ld_xquat(bs);
+      const int a0 = CI(ar);
+      f3 ap = ld_xpos(a0);
+      f4 aq = ld_xquat(a0);
+#pragma unroll
+      for (int k = 1; k < W; ++k) {
+        const int a = CI(ar + k);
+        ap = ap + qrot(aq, ld_xpos(a));
+        aq = qmul(aq, ld_xquat(a));
+      }
+      const f3 pos = ap + qrot(aq, lp);
+      const f4 quat = qmul(aq, lq);
+      WSYNC();
+      if (deep) {
+        body(0, b) = pos.x; body(1, b) = pos.y; body(2, b) = pos.z;
+        body(3, b) = quat.w; body(4, b) = quat.x; body(5, b) = quat.y; body(6, b) = quat.z;
+      }
+      WSYNC();
+    } else
     for (int L = 2; L < m.nlevel(); ++L) {
       if (b_level == L) {
         const f4 pq = ld_xquat(b_parent);
@@ -1547,6 +1580,33 @@ struct Env {
         }
       }
     }
+    if (!m.deep_free() && m.nlevel() > AMX_CHAIN_WALK_MIN_LEVELS && !AMX_LEVEL_SCANS) {
+      // The same chain walk as in kinematics(): every body stores its own joint sums (vJ, loc), then accumulates them along its
+      // ancestor chain in registers - cvel and cacc of every ancestor are recomputed in the lane, in the order the level scan
+      // produces them.  w of an ancestor is its vJ (they differ only for free joints, which sit on the first level, where the
+      // velocity arriving from the world is zero and the cross product vanishes either way).
+      const bool isb = b > 0 && b < m.nb();
+      if (isb) { st_bsv(F_CVEL, b, vJ); st_bsv(F_CACC, b, loc); }
+      if (gl == 0) { sv z = {{0, 0, 0, 0, 0, 0}}; st_bsv(F_CACC, 0, z); }
+      WSYNC();
+      const int W = m.nlevel() > 2 ? m.nlevel() - 2 : 0, ar = m.c_anc() + (isb ? b : 0) * (W > 0 ? W : 1);
+      sv cv = {{0, 0, 0, 0, 0, 0}}, ca = {{0, 0, 0, 0, 0, 0}};
+      if (!(m.disableflags() & DIS_GRAVITY)) { ca.v[3] = -m.gx(); ca.v[4] = -m.gy(); ca.v[5] = -m.gz(); }
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        const int a = CI(ar + k);
+        const sv va = ld_bsv(F_CVEL, a), la = ld_bsv(F_CACC, a);
+        const sv x = motion_cross(cv, va);
+#pragma unroll
+        for (int e = 0; e < 6; ++e) { ca.v[e] = ca.v[e] + x.v[e] + la.v[e]; cv.v[e] = cv.v[e] + va.v[e]; }
+      }
+      const sv x = motion_cross(cv, w);
+#pragma unroll
+      for (int e = 0; e < 6; ++e) { ca.v[e] = ca.v[e] + x.v[e] + loc.v[e]; cv.v[e] = cv.v[e] + vJ.v[e]; }
+      WSYNC();
+      if (isb) { st_bsv(F_CVEL, b, cv); st_bsv(F_CACC, b, ca); }
+      WSYNC();
+    } else
     for (int L = 1; L < m.nlevel(); ++L) {
       if (b_level == L) {
         const sv cvp = ld_bsv(F_CVEL, b_parent), cap = ld_bsv(F_CACC, b_parent);

@@ -385,6 +385,20 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
   // lists
   auto add_ints = [&](const std::vector<int> &v) { int o = im.reserve((int)v.size()); for (size_t k = 0; k < v.size(); k++) im.seti(o + (int)k, v[k]); return o; };
   m.c_child = add_ints(child_list);
+  {
+    // ancestor chains, root first: the down-scans (poses, velocities) walk a body's own chain in registers instead of waiting
+    // level by level for the parent's result to come back through LDS
+    const int w = std::max(m.nlevel - 2, 1);
+    std::vector<int> anc((size_t)nb * w, 0);
+    for (int b = 1; b < nb; b++) {
+      std::vector<int> chain;
+      for (int a = d->body_parentid[b]; a > 0; a = d->body_parentid[a]) chain.push_back(a);
+      for (size_t k = 0; k < chain.size(); k++) anc[(size_t)b * w + k] = chain[chain.size() - 1 - k];
+    }
+    m.c_anc = add_ints(anc);
+    m.deep_free = 0;
+    for (int j = 0; j < nj; j++) if (d->jnt_type[j] == 0 && depth[d->jnt_bodyid[j]] > 1) m.deep_free = 1;
+  }
   if (m.G >= 32) { hent.clear(); m.nhent = 0; }  // wide groups build the Hessian on the matrix cores; only 16-lane groups walk the term list
   m.c_dofact = add_ints(dofact); m.c_pairdof = add_ints(pairdof); m.c_jac = add_ints(jac_items); m.c_hent = add_ints(hent);
   m.c_conpair = add_ints(con_pair); m.c_rootbody = add_ints(roots);
