@@ -1517,7 +1517,7 @@ struct Env {
         const sv f = ld_dsv(D_FCRB, i), c = ld_dsv(D_CDOF, j);
         const float arm = CF(m.c_dof() + i * DOF_S + 4);
         float v = (c.v[0] * f.v[0] + c.v[1] * f.v[1]) + (c.v[2] * f.v[2] + c.v[3] * f.v[3]) + (c.v[4] * f.v[4] + c.v[5] * f.v[5]);
-        if (i == j) v += arm;
+        v += i == j ? arm : 0.0f;  // a select: as `if`, the armature load sank into a branch of its own with its own wait
         return MEnt{Mo + (int)(pk & 2047u), Mo + (int)((pk >> 11) & 2047u), v};  // j is an ancestor of i: both triangles are stored
       },
       [&](int, const MEnt &r) { lds[r.at] = r.v; lds[r.at2] = r.v; });
@@ -1894,9 +1894,11 @@ struct Env {
                    ft2 = mk3(lds[fo + 6], lds[fo + 7], lds[fo + 8]);
           const f3 w = mk3(dof(0, i), dof(1, i), dof(2, i)), l = mk3(dof(3, i), dof(4, i), dof(5, i));
           const f3 com1 = ld_com(root1), com2 = ld_com(root2);  // unconditional loads, selected below
-          f3 jp = mk3(0, 0, 0);
-          if (sg & 1) jp = jp + (l + cross(w, pt - com2));
-          if (sg & 2) jp = jp - (l + cross(w, pt - com1));
+          // both arms computed and selected (as `if`s the loads above sank into two branches, each with its own waits)
+          const f3 a2 = l + cross(w, pt - com2), a1 = l + cross(w, pt - com1);
+          const bool s1 = sg & 1, s2 = sg & 2;
+          f3 jp = mk3(s1 ? a2.x : 0.0f, s1 ? a2.y : 0.0f, s1 ? a2.z : 0.0f);
+          jp = mk3(s2 ? jp.x - a1.x : jp.x, s2 ? jp.y - a1.y : jp.y, s2 ? jp.z - a1.z : jp.z);
           const float jn = dot(fn_, jp), j1 = dot(ft1, jp), j2 = dot(ft2, jp);
           return JEnt{Jo + (4 * c) * ldc + slot, jn + mu * j1, jn - mu * j1, jn + mu * j2, jn - mu * j2};
         },
@@ -1984,6 +1986,17 @@ struct Env {
     const float4 *mr = reinterpret_cast<const float4 *>(lds + eb + m.e_M() + i * ldm), *vv = reinterpret_cast<const float4 *>(lds + Vo);
     float acc0 = 0, acc1 = 0;
     const int nch = ldm >> 2;
+    if constexpr (S::is_static) {  // static chunk count: one straight block, every load in flight
+#pragma unroll
+      for (int c = 0; c < S::ldm / 4; ++c) {
+        int pc = c + m_rot;
+        pc -= pc >= S::ldm / 4 ? S::ldm / 4 : 0;
+        const float4 a = mr[pc], v = vv[c];
+        acc0 = __builtin_fmaf(a.x, v.x, __builtin_fmaf(a.y, v.y, acc0));
+        acc1 = __builtin_fmaf(a.z, v.z, __builtin_fmaf(a.w, v.w, acc1));
+      }
+      return acc0 + acc1;
+    }
 #pragma unroll 5
     for (int c = 0; c < nch; ++c) {
       int pc = c + m_rot;  // chunk c of the row sits at position (c + rot) mod nch; v is staged unrotated: one address per group
@@ -2057,15 +2070,18 @@ struct Env {
     if (gl < nA()) { row(0, gl) = aact ? aD : 0.0f; row(1, gl) = f; }
     if (gl < nB()) { row(0, row0 + gl) = cact ? cD : 0.0f; row(1, row0 + gl) = fc; }
     WSYNC();
-    // contact rows: dof lane i gathers over the (pair, slot) memberships of its dof
-    if (gl < m.nv()) {
+    // contact rows: dof lane i gathers over the (pair, slot) memberships of its dof.  Straight-line: the trip count is the
+    // model's largest membership list (static in the specialised kernels, so the loop unrolls and every load of every term
+    // is in flight together); a lane past its own list re-reads term 0 and adds 0.  Two terms per trip, summed in list order.
+    {
+      const bool isd = gl < m.nv();
       float acc = 0;
-      const int mem0 = CI(m.c_dofmemadr() + gl), mem1 = CI(m.c_dofmemadr() + gl + 1);
-      // one term per contact whose ancestor chain holds this dof; two terms per trip so that their sixteen loads are in
-      // flight together (an odd tail re-reads the last term with weight 0)
-      for (int t = mem0; t < mem1; t += 2) {
-        const bool two = t + 1 < mem1;
-        const int pk0 = CI(m.c_dofmem() + t), pk1 = CI(m.c_dofmem() + (two ? t + 1 : t));
+      const int mem0 = CI(m.c_dofmemadr() + (isd ? gl : 0)), mem1 = isd ? CI(m.c_dofmemadr() + (isd ? gl : 0) + 1) : mem0;
+#pragma unroll
+      for (int u = 0; u < m.max_dofmem(); u += 2) {
+        const int t0 = mem0 + u, t1 = t0 + 1;
+        const bool w0 = t0 < mem1, w1 = t1 < mem1;
+        const int pk0 = CI(m.c_dofmem() + (w0 ? t0 : 0)), pk1 = CI(m.c_dofmem() + (w1 ? t1 : 0));
         const int c0 = pk0 & 255, c1 = pk1 & 255;
         const int Ja = Jo + c0 * ldc + (pk0 >> 8), Fa = eb + m.e_row() + (row0 + c0) * ROW_E + 1;
         const int Jb = Jo + c1 * ldc + (pk1 >> 8), Fb = eb + m.e_row() + (row0 + c1) * ROW_E + 1;
@@ -2074,14 +2090,20 @@ struct Env {
         for (int k = 0; k < 4; ++k) { ja[k] = lds[Ja + k * ldc]; fa[k] = lds[Fa + k * ROW_E]; jb[k] = lds[Jb + k * ldc]; fb[k] = lds[Fb + k * ROW_E]; }
         const float sa = (ja[0] * fa[0] + ja[1] * fa[1]) + (ja[2] * fa[2] + ja[3] * fa[3]);
         const float sb = (jb[0] * fb[0] + jb[1] * fb[1]) + (jb[2] * fb[2] + jb[3] * fb[3]);
-        acc += sa;
-        acc += two ? sb : 0.0f;
+        acc += w0 ? sa : 0.0f;
+        acc += w1 ? sb : 0.0f;
       }
-      dof(D_FCON, gl) = acc;
+      // limit rows have one entry each and a dof at most one limit row: without equality rows the dof lane fetches its row's
+      // force through the crossbar instead of the rows scattering with LDS atomics
+      if (m.neq() == 0 && nA() > 0) {
+        const float fl = __int_as_float(__builtin_amdgcn_ds_bpermute(gb4 + 4 * (d_limrow < 0 ? 0 : d_limrow), __float_as_int(rJ1 * f)));
+        acc += (isd && d_limrow >= 0) ? fl : 0.0f;
+      }
+      if (isd) dof(D_FCON, gl) = acc;
     }
     WSYNC();
     // equality / limit rows scatter their one or two entries
-    if (gl < row0 && f != 0.0f) {
+    if (m.neq() > 0 && gl < row0 && f != 0.0f) {
       atomicAdd(&dof(D_FCON, rd1), rJ1 * f);
       if (rd2 >= 0) atomicAdd(&dof(D_FCON, rd2), rJ2 * f);
     }

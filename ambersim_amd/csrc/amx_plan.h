@@ -414,6 +414,9 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
     std::vector<int> adr(nv + 1, 0), flat;
     for (int i = 0; i < nv; i++) { adr[i] = (int)flat.size(); flat.insert(flat.end(), dofmem[i].begin(), dofmem[i].end()); }
     adr[nv] = (int)flat.size();
+    m.max_dofmem = 0;
+    for (int i = 0; i < nv; i++) m.max_dofmem = std::max(m.max_dofmem, (int)dofmem[i].size());
+    if (flat.empty()) flat.push_back(0);  // the gather reads entry 0 with weight 0 when a dof has no terms
     m.c_dofmemadr = add_ints(adr); m.c_dofmem = add_ints(flat);
   }
   m.ldc = maxchain | 1;
