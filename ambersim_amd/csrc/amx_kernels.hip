@@ -1463,23 +1463,23 @@ struct Env {
       for (int k = 0; k < 10; ++k) r[k] = 0.0f;
 #pragma unroll 4
       for (int k = 0; k < m.sub_iter(); ++k) {
-        const int d_ = b + k, src = (inner && d_ < b_subend) ? d_ : 0;
+        const int d_ = b + k, src = (inner && d_ < b_subend) ? d_ : ((isb && k == 0) ? b : 0);  // a root reads just itself
 #pragma unroll
         for (int q = 0; q < 10; ++q) r[q] += body(F_CINERT + q, src);
       }
-      if (inner) {
+      // a root's composite = itself + the composites of its children = a group sum over the lanes of the root and of the
+      // bodies right below it (registers and DPP only; the child-list loop it replaces waited on LDS for every child)
+      for (int rt = 0; rt < m.nroot(); ++rt) {
+        const bool part = isb && b_root == rt && b_level <= 2;
+        float tot[10];
 #pragma unroll
-        for (int k = 0; k < 10; ++k) body(F_CRB + k, b) = r[k];
-      }
-      WSYNC();
-      if (isb && !inner) {  // a root: itself + its children's composites
+        for (int k = 0; k < 10; ++k) tot[k] = gsum<G>(part ? r[k] : 0.0f);
+        if (isb && !inner && b_root == rt) {
 #pragma unroll
-        for (int k = 0; k < 10; ++k) r[k] = body(F_CINERT + k, b);
-        for (int c = 0; c < b_childnum; ++c) {
-          const int cb = CI(m.c_child() + b_childadr + c);
-#pragma unroll
-          for (int k = 0; k < 10; ++k) r[k] += body(F_CRB + k, cb);
+          for (int k = 0; k < 10; ++k) r[k] = tot[k];
         }
+      }
+      if (isb) {
 #pragma unroll
         for (int k = 0; k < 10; ++k) body(F_CRB + k, b) = r[k];
       }
@@ -1640,22 +1640,19 @@ struct Env {
 #pragma unroll 4
       for (int k = 0; k < m.sub_iter(); ++k) {
         const int d_ = b + k;
-        const sv g = ld_bsv(F_CFRC, (inner && d_ < b_subend) ? d_ : 0);
+        const sv g = ld_bsv(F_CFRC, (inner && d_ < b_subend) ? d_ : ((isb && k == 0) ? b : 0));
 #pragma unroll
         for (int e = 0; e < 6; ++e) f.v[e] += g.v[e];
       }
-      WSYNC();
-      if (inner) st_bsv(F_CFRC, b, f);
-      WSYNC();
-      if (isb && !inner) {
-        f = ld_bsv(F_CFRC, b);
-        for (int c = 0; c < b_childnum; ++c) {
-          const sv g = ld_bsv(F_CFRC, CI(m.c_child() + b_childadr + c));
+      for (int rt = 0; rt < m.nroot(); ++rt) {  // roots: group sum over themselves and the bodies right below them
+        const bool part = isb && b_root == rt && b_level <= 2;
+        sv tot;
 #pragma unroll
-          for (int e = 0; e < 6; ++e) f.v[e] += g.v[e];
-        }
-        st_bsv(F_CFRC, b, f);
+        for (int e = 0; e < 6; ++e) tot.v[e] = gsum<G>(part ? f.v[e] : 0.0f);
+        if (isb && !inner && b_root == rt) f = tot;
       }
+      WSYNC();
+      if (isb) st_bsv(F_CFRC, b, f);
       WSYNC();
     } else
     for (int L = m.nlevel() - 2; L >= 1; --L) {  // up-scan: gather children
