@@ -37,6 +37,9 @@
 #ifndef AMX_LEVEL_SCANS
 #define AMX_LEVEL_SCANS 0  // 1: poses and velocities travel down the tree level by level as before (A/B switch)
 #endif
+#ifndef AMX_NO_GRADCOL
+#define AMX_NO_GRADCOL 0  // 1: J'f of the contact rows always by the per-dof gather (A/B switch)
+#endif
 #ifndef AMX_NO_SYM_ELIM
 #define AMX_NO_SYM_ELIM 0  // 1: the static eliminations broadcast pivot rows through the crossbar as before (A/B switch)
 #endif
@@ -356,7 +359,11 @@ typedef float v32f __attribute__((ext_vector_type(32)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 // The matrix-core part: on return lane (b, j) holds row j of its environment's J'DJ as sixteen-byte chunks,
 // lo[q][r] = (J'DJ)[j][8q+r], hi[q][r] = (J'DJ)[j][8q+4+r].  crows, ldc, slot_base are wave-uniform scalars.
-template <int G>
+// COL31 (32-lane groups, nv <= 31): lane 31 of each block feeds A = field 1 of the row record (the row's force f_r) instead of
+// D_r J_r[31] = 0, so row 31 of the product is sum_r f_r J_r[i] = the contact rows' part of J'f = qfrc_constraint.  Lane i
+// holds column i of the accumulator: the entry reaches it as hi[3][3] with its Hessian row, for four more broadcast loads per
+// contact.
+template <int G, bool COL31 = false>
 DEV void jtdj_rows_mfma(unsigned long long crows, int row_base, int J_base, int ldc, int slot_base, int gl, unsigned (&lo)[4][4], unsigned (&hi)[4][4]) {
   const int j = gl & 31, h = gl >> 5;
   // one bit per contact that is active in some environment of the wave (wave-uniform scalar loop over the set bits)
@@ -369,13 +376,17 @@ DEV void jtdj_rows_mfma(unsigned long long crows, int row_base, int J_base, int 
       const int slot = CI(slot_base + 32 * c + j);
       const bool has = slot >= 0;
       const int Jr = J_base + 4 * c * ldc + (has ? slot : 0), Dr = row_base + 4 * c * ROW_E;
-      float d[4], jv[4];
+      float d[4], jv[4], g[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { d[r] = lds[Dr + r * ROW_E]; jv[r] = lds[Jr + r * ldc]; }
+      for (int r = 0; r < 4; ++r) {
+        d[r] = lds[Dr + r * ROW_E]; jv[r] = lds[Jr + r * ldc];
+        if (COL31) g[r] = lds[Dr + r * ROW_E + 1];
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float v = has ? jv[r] : 0.0f;
-        C = __builtin_amdgcn_mfma_f32_32x32x1f32(d[r] * v, v, C, 0, 0, 0);
+        const float aop = (COL31 && j == 31) ? g[r] : d[r] * v;
+        C = __builtin_amdgcn_mfma_f32_32x32x1f32(aop, v, C, 0, 0, 0);
       }
     }
 #pragma unroll
@@ -670,19 +681,33 @@ AMX_STATIC_SOLVE_ATTR void spd_solve_static(int A_off, int rhs_off, int x_off, i
 // arrive in registers (jtdj_rows_mfma), the lane adds its row of M (stored chunk-rotated when MV::mrot) and the diagonal
 // term of the limit row on its dof (dlim, fetched by the caller through the crossbar), and the elimination starts from
 // those registers: H never touches LDS.  S static: N = nv, tree-sparse elimination when TREE; S = DynSpec: N is the padded size.
-template <class S, int N, int G, bool TREE>
+// GRADCOL (static, 32-lane groups, nv <= 31; see jtdj_rows_mfma COL31): the caller has not formed qfrc_constraint and the
+// gradient; they come out of the matrix cores' column 31 here - fcon = column + flim (the lane's limit-row force),
+// grad = Ma - qfrc_smooth - fcon - and are stored to fcon_off / rhs_off before the elimination uses grad as its right-hand side.
+template <class S, int N, int G, bool TREE, bool GRADCOL = false>
 AMX_STATIC_SOLVE_ATTR void newton_solve_fused(int M_off, int ld_, int n_, unsigned long long crows_, int row_base, int J_base, int ldc_, int slot_base_,
-                                                int rhs_off, int x_off, float dlim, int gl, int gb4, int rot, int bt_off) {
+                                                int rhs_off, int x_off, float dlim, int gl, int gb4, int rot, int bt_off, float flim = 0.0f, int ma_off = 0,
+                                                int fs_off = 0, int fcon_off = 0, bool store_ok = true) {
   if constexpr (sym_elim_ok<S, G>() && G == 32) {
     // crossbar-free elimination (see sym_pivot): b reaches lane N as a row through the staging vector at bt_off
     constexpr int NS = S::nv, lds_ = S::ldm, nchs = lds_ / 4;
     const unsigned long long crows_u = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(crows_ >> 32)) << 32) |
                                        (unsigned)__builtin_amdgcn_readfirstlane((int)crows_);
     unsigned lo[4][4], hi[4][4];
-    jtdj_rows_mfma<G>(crows_u, row_base, J_base, S::ldc, S::c_slot, gl, lo, hi);
     const bool owner = gl < NS, brow = gl == NS;
     const int li = owner ? gl : 0;
-    float b = lds[rhs_off + li * DOF_E];
+    float b;
+    if constexpr (GRADCOL) {
+      static_assert(NS <= 31, "column 31 must be spare");
+      const float ma = lds[ma_off + li * DOF_E], fs = lds[fs_off + li * DOF_E];
+      jtdj_rows_mfma<G, true>(crows_u, row_base, J_base, S::ldc, S::c_slot, gl, lo, hi);
+      const float fcon = __uint_as_float(hi[3][3]) + flim;
+      b = ma - fs - fcon;
+      if (owner && store_ok) { lds[fcon_off + gl * DOF_E] = fcon; lds[rhs_off + gl * DOF_E] = b; }
+    } else {
+      jtdj_rows_mfma<G>(crows_u, row_base, J_base, S::ldc, S::c_slot, gl, lo, hi);
+      b = lds[rhs_off + li * DOF_E];
+    }
     b = owner ? b : 0.0f;
     if (gl < lds_) lds[bt_off + gl] = b;
     WSYNC();
@@ -2059,7 +2084,14 @@ struct Env {
   }
   // qfrc_constraint = J' f with f = -D*Jaref on active rows, grad = Ma - qfrc_smooth - qfrc_constraint;
   // also publishes D*active per row for the Hessian assembly.
-  DEV void constraint_force_and_grad() {
+  // grad_in_solve(): the specialised fused Newton path takes J'f of the contact rows from the matrix cores (newton_solve_fused
+  // GRADCOL), so a call that is followed by newton_direction() only publishes the row records and the limit-row force
+  static constexpr bool grad_in_solve() { return S::is_static && G == 32 && S::fusedH && S::solver == 2 && S::nv <= 31 && sym_elim_ok<S, G>() && !AMX_NO_GRADCOL; }
+  float pend_flim;  // limit-row force on this lane's dof, handed from a deferring constraint_force_and_grad to newton_direction
+  // alive: false for a group whose solve has converged while its wave mate iterates on - its force and gradient are left as
+  // they are (recomputing them is idempotent in value but not in bits: the matrix-core sum and the gather round differently,
+  // and which of the two ran last must not depend on the wave mate)
+  DEV void constraint_force_and_grad(bool defer = false, bool alive = true) {
     const int Jo = eb + m.e_J(), ldc = m.ldc(), row0 = m.neq() + m.nlim();
     aact = gl < nA() && (aJaref < 0 || gl < m.neq()) && aD > 0;
     cact = gl < nB() && cJaref < 0 && cD > 0;
@@ -2067,6 +2099,15 @@ struct Env {
     if (gl < nA()) { row(0, gl) = aact ? aD : 0.0f; row(1, gl) = f; }
     if (gl < nB()) { row(0, row0 + gl) = cact ? cD : 0.0f; row(1, row0 + gl) = fc; }
     WSYNC();
+    if (grad_in_solve() && defer) {
+      float fl = 0.0f;
+      if (nA() > 0) {
+        fl = __int_as_float(__builtin_amdgcn_ds_bpermute(gb4 + 4 * (d_limrow < 0 ? 0 : d_limrow), __float_as_int(rJ1 * f)));
+        fl = (gl < m.nv() && d_limrow >= 0) ? fl : 0.0f;
+      }
+      pend_flim = fl;
+      return;
+    }
     // contact rows: dof lane i gathers over the (pair, slot) memberships of its dof.  Straight-line: the trip count is the
     // model's largest membership list (static in the specialised kernels, so the loop unrolls and every load of every term
     // is in flight together); a lane past its own list re-reads term 0 and adds 0.  Two terms per trip, summed in list order.
@@ -2096,23 +2137,23 @@ struct Env {
         const float fl = __int_as_float(__builtin_amdgcn_ds_bpermute(gb4 + 4 * (d_limrow < 0 ? 0 : d_limrow), __float_as_int(rJ1 * f)));
         acc += (isd && d_limrow >= 0) ? fl : 0.0f;
       }
-      if (isd) dof(D_FCON, gl) = acc;
+      if (isd && alive) dof(D_FCON, gl) = acc;
     }
     WSYNC();
     // equality / limit rows scatter their one or two entries
-    if (m.neq() > 0 && gl < row0 && f != 0.0f) {
+    if (m.neq() > 0 && gl < row0 && f != 0.0f && alive) {
       atomicAdd(&dof(D_FCON, rd1), rJ1 * f);
       if (rd2 >= 0) atomicAdd(&dof(D_FCON, rd2), rJ2 * f);
     }
     WSYNC();
-    if (gl < m.nv()) dof(D_GRAD, gl) = dof(D_MA, gl) - dof(D_FSMOOTH, gl) - dof(D_FCON, gl);
+    if (gl < m.nv() && alive) dof(D_GRAD, gl) = dof(D_MA, gl) - dof(D_FSMOOTH, gl) - dof(D_FCON, gl);
     WSYNC();
   }
   // Mgrad = (M + J' D_active J)^-1 grad, H a full symmetric matrix in LDS.
   // G >= 32: the contact rows' J'DJ comes from the matrix cores and lands in H together with M (build_H_mfma); equality and
   // limit rows, rarely active and one or two entries each, are added with LDS atomics only when one of them is active.
   // G = 16 (four environments per wave do not map onto the two MFMA blocks): copy of M + atomics for every row kind.
-  DEV void newton_direction() {
+  DEV void newton_direction(bool alive = true) {
     const int nv = m.nv(), Mo = eb + m.e_M(), Ho = eb + m.e_H(), Jo = eb + m.e_J(), ldc = m.ldc(), ldm = m.ldm();
     const int row0 = m.neq() + m.nlim();
     if constexpr (G >= 32) {
@@ -2124,7 +2165,10 @@ struct Env {
         float dlim = __int_as_float(__builtin_amdgcn_ds_bpermute(gb4 + 4 * (d_limrow < 0 ? 0 : d_limrow), __float_as_int(dsrc)));
         dlim = (gl < nv && d_limrow >= 0 && nA() > 0) ? dlim : 0.0f;
         PROF(19);
-        if constexpr (S::is_static)
+        if constexpr (grad_in_solve())
+          newton_solve_fused<S, S::nv, G, S::tree_H, true>(Mo, ldm, nv, rows, eb + m.e_row() + row0 * ROW_E, Jo, ldc, m.c_slot(), dofoff(D_GRAD), dofoff(D_MGRAD), dlim, gl, gb4, m_rot, eb + m.e_H(),
+                                                          pend_flim, dofoff(D_MA), dofoff(D_FSMOOTH), dofoff(D_FCON), alive);
+        else if constexpr (S::is_static)
           newton_solve_fused<S, S::nv, G, S::tree_H>(Mo, ldm, nv, rows, eb + m.e_row() + row0 * ROW_E, Jo, ldc, m.c_slot(), dofoff(D_GRAD), dofoff(D_MGRAD), dlim, gl, gb4, m_rot, eb + m.e_H());
         else
           newton_fused_dyn<G>(m.nchol(), Mo, ldm, nv, rows, eb + m.e_row() + row0 * ROW_E, Jo, ldc, m.c_slot(), dofoff(D_GRAD), dofoff(D_MGRAD), dlim, gl, gb4, m_rot);
@@ -2298,7 +2342,7 @@ struct Env {
     }
     prev_cost = INFINITY;
     PROF(9);
-    constraint_force_and_grad();
+    constraint_force_and_grad(m.solver() == 2);
     PROF(10);
     if (m.solver() == 2) newton_direction();
     else chol_solve<G>(m.nchol(), eb + m.e_M(), m.ldm(), nv, eb + m.e_Lb(), dofoff(D_GRAD), dofoff(D_MGRAD), false, gl, gb4);
@@ -2329,12 +2373,12 @@ struct Env {
       prev_cost = alive ? cost : prev_cost;
       cost = alive ? ncost : cost;
       gauss = alive ? ngauss : gauss;
-      constraint_force_and_grad();
+      constraint_force_and_grad(m.solver() == 2 && niter + 1 < m.iterations(), alive);
       PROF(10);
       if (m.solver() == 2) {
         // the search direction of an iteration that will not run is never read: skip its factorisation
         if (niter + 1 < m.iterations()) {
-          newton_direction();
+          newton_direction(alive);
           PROF(11);
           if (gl < nv) dof(D_SEARCH, gl) = -dof(D_MGRAD, gl);
         }
