@@ -864,9 +864,10 @@ template <int G> DEV void lds_copy(int dst, int src, int n, int gl) {
 }
 
 // max over each 32-lane unit (a G = 32 group, or half of a G = 64 group)
-DEV float umax32(float x) {
+template <int U> DEV float umax(float x) {  // max over the U-lane unit (16: one DPP row; 32: two rows joined through the crossbar)
   x = fmaxf(x, dpp_f<0xB1>(x)); x = fmaxf(x, dpp_f<0x4E>(x)); x = fmaxf(x, dpp_f<0x141>(x)); x = fmaxf(x, dpp_f<0x140>(x));
-  return fmaxf(x, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x401F)));
+  if (U == 32) x = fmaxf(x, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x401F)));
+  return x;
 }
 // plane - convex hull with one lane per hull vertex (MJX's 4-point manifold: deepest-1mm mask, a = first masked, b =
 // farthest from a, c = farthest from line ab, d = farthest from the other two edges).  Every selection is a max over the
@@ -874,10 +875,10 @@ DEV float umax32(float x) {
 // the winner's coordinates come back through the crossbar.  Used by 64-lane groups, two pairs per pass (the code also
 // handles one pair per pass on a 32-lane unit).  Out of line: models without such pairs do not pay for its registers.
 //   geom_off / con_off / frame_off: LDS offsets of the lane's environment's geom poses, contacts and contact frames
-template <int G>
+template <int G, int U>  // U lanes per pair: 32, or 16 when every hull has at most 16 vertices (two pairs per 32-lane pass)
 DEV void plane_convex_parallel_body(int pcx_first, int pcx_num, int c_pair, int c_vert, int geom_off, int con_off, int frame_off, int gl, int gb4) {
-  const int unit = G == 64 ? (gl >> 5) : 0, v = gl & 31, per_pass = G == 64 ? 2 : 1;
-  const int lane0 = (gb4 >> 2) + 32 * unit;  // first wave lane of my unit
+  const int unit = gl / U, v = gl % U, per_pass = G / U;
+  const int lane0 = (gb4 >> 2) + U * unit;  // first wave lane of my unit
 #define GEO(f, g) lds[geom_off + (g) * GEO_E + (f)]
   for (int p0 = 0; p0 < pcx_num; p0 += per_pass) {
     const bool pair_ok = p0 + unit < pcx_num;
@@ -893,15 +894,15 @@ DEV void plane_convex_parallel_body(int pcx_first, int pcx_num, int c_pair, int 
     const int vi = on ? v : 0;
     const f3 vt = mk3(CF(va + 3 * vi), CF(va + 3 * vi + 1), CF(va + 3 * vi + 2));
     const float sup = dot(pl - vt, n);
-    const float smax = umax32(on ? sup : -1e30f);
+    const float smax = umax<U>(on ? sup : -1e30f);
     const float thr = fmaxf(0.0f, smax - 1e-3f);
     const float mask = sup > thr ? 0.0f : -1e6f;
     // lowest lane of my unit whose score equals the unit's maximum; returns that vertex
     auto pick = [&](float sc, int *idx) {
       const float s = on ? sc : -1e30f;
-      const float best = umax32(s);
+      const float best = umax<U>(s);
       const unsigned long long bal = __ballot(s == best && on);
-      const unsigned mine = (unsigned)(bal >> (lane0 & 63));  // my unit's 32 bits start at its first lane
+      const unsigned mine = (unsigned)(bal >> (lane0 & 63)) & (U == 32 ? 0xFFFFFFFFu : 0xFFFFu);  // my unit's bits start at its first lane
       const int w = mine ? __builtin_ctz(mine) : 0;
       *idx = w;
       const int addr = 4 * (lane0 + w);
@@ -917,7 +918,7 @@ DEV void plane_convex_parallel_body(int pcx_first, int pcx_num, int c_pair, int 
     const f3 ac = cross(n, a - cc), bc = cross(n, bb - cc);
     // d: the serial scan runs over the bc scores first, then the ac scores continue with the same running maximum
     const float s1 = fabsf(dot(bb - vt, bc)) + mask, s2 = fabsf(dot(a - vt, ac)) + mask;
-    const float m1 = umax32(on ? s1 : -1e30f), m2 = umax32(on ? s2 : -1e30f);
+    const float m1 = umax<U>(on ? s1 : -1e30f), m2 = umax<U>(on ? s2 : -1e30f);
     const f3 dd = pick(m2 > m1 ? s2 : s1, &idx[3]);
     const f3 sel[4] = {a, bb, cc, dd};
     if (pair_ok && v < 4) {  // lanes 0..3 of the unit write the four contacts
@@ -944,9 +945,9 @@ DEV void plane_convex_parallel_body(int pcx_first, int pcx_num, int c_pair, int 
   WSYNC();
 }
 // out-of-line entry for the generic kernels (the specialised ones inline the body: see AMX_STATIC_SOLVE_ATTR)
-template <int G>
+template <int G, int U>
 __device__ __noinline__ void plane_convex_parallel(int pcx_first, int pcx_num, int c_pair, int c_vert, int geom_off, int con_off, int frame_off, int gl, int gb4) {
-  plane_convex_parallel_body<G>(pcx_first, pcx_num, c_pair, c_vert, geom_off, con_off, frame_off, gl, gb4);
+  plane_convex_parallel_body<G, U>(pcx_first, pcx_num, c_pair, c_vert, geom_off, con_off, frame_off, gl, gb4);
 }
 
 // ---- group max / min with the value in every lane (same network as gsum)
@@ -1747,8 +1748,9 @@ struct Env {
     const int cx_first = G >= 32 ? m.pcx_first() : 0, cx_num = G >= 32 ? m.npcx() : 0;
     if (G >= 32 && cx_num > 0)  // uniform: a property of the model
     {
-      if constexpr (S::is_static) plane_convex_parallel_body<G>(cx_first, cx_num, m.c_pair(), m.c_vert(), eb + m.e_geom(), eb + m.e_con(), eb + m.e_frame(), gl, gb4);
-      else plane_convex_parallel<G>(cx_first, cx_num, m.c_pair(), m.c_vert(), eb + m.e_geom(), eb + m.e_con(), eb + m.e_frame(), gl, gb4);
+      if constexpr (S::is_static) plane_convex_parallel_body<G, (S::pcx_unit == 16 && G >= 32) ? 16 : 32>(cx_first, cx_num, m.c_pair(), m.c_vert(), eb + m.e_geom(), eb + m.e_con(), eb + m.e_frame(), gl, gb4);
+      else if (m.pcx_unit() == 16) plane_convex_parallel<G, G >= 32 ? 16 : 32>(cx_first, cx_num, m.c_pair(), m.c_vert(), eb + m.e_geom(), eb + m.e_con(), eb + m.e_frame(), gl, gb4);
+      else plane_convex_parallel<G, 32>(cx_first, cx_num, m.c_pair(), m.c_vert(), eb + m.e_geom(), eb + m.e_con(), eb + m.e_frame(), gl, gb4);
     }
     if (m.ncx() > 0)  // uniform: a property of the model
       convex_convex_pairs<G>(m.cx_first(), m.ncx(), m.c_pair(), eb + m.e_geom(), eb + m.e_con(), eb + m.e_frame(), eb + m.e_cx(), gl, gb4);

@@ -339,6 +339,12 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
     for (int p = 0; p < np; p++)
       if (d->pair_fn[p] == 2 && d->pair_vertnum[p] <= 32) { if (first < 0) first = p; last = p; cnt++; }
     if (cnt > 0 && last - first + 1 == cnt) { m.pcx_first = first; m.npcx = cnt; }
+    m.pcx_unit = 32;
+    if (m.npcx > 0) {
+      int mx = 0;
+      for (int p = m.pcx_first; p < m.pcx_first + m.npcx; p++) mx = std::max(mx, d->pair_vertnum[p]);
+      if (mx <= 16) m.pcx_unit = 16;
+    }
   }
   // limit rows, equality rows
   std::vector<int> lim_j;
