@@ -613,6 +613,10 @@ AMX_STATIC_SOLVE_ATTR void spd_solve_static(int A_off, int rhs_off, int x_off, i
     // bt_off: an idle vector of ld floats (the M*v staging vector) through which b reaches lane N as a row; < 0: none, b is
     // broadcast on its own (always so for 16-lane groups, where that costs nothing)
     constexpr bool BCOL = G == 32;
+    // the pivot-lane tests (gl == J) of one elimination are recomputed here (one v_cmp each): left loop-invariant, the thirty
+    // masks were hoisted out of the step loop, held in scalar registers across it and spilled (two v_readlane per use)
+    int gle = gl;
+    asm volatile("" : "+v"(gle));
     float a[N + 1];
     const int li = gl < N ? gl : 0;
     float b = lds[rhs_off + li * DOF_E];
@@ -638,15 +642,15 @@ AMX_STATIC_SOLVE_ATTR void spd_solve_static(int A_off, int rhs_off, int x_off, i
     }
     a[N] = b;
     if (BCOL && bt_off >= 0) {
-      if (TREE) SymTree<S, G, N - 1, true>::run(a, gl);
-      else SymDense<S, G, 0, true>::run(a, gl);
+      if (TREE) SymTree<S, G, N - 1, true>::run(a, gle);
+      else SymDense<S, G, 0, true>::run(a, gle);
     } else {
-      if (TREE) SymTree<S, G, N - 1, false>::run(a, gl);
-      else SymDense<S, G, 0, false>::run(a, gl);
+      if (TREE) SymTree<S, G, N - 1, false>::run(a, gle);
+      else SymDense<S, G, 0, false>::run(a, gle);
     }
     float d = 1.0f;
 #pragma unroll
-    for (int k = 0; k < N; ++k) d = (k == gl) ? a[k] : d;
+    for (int k = 0; k < N; ++k) d = (k == gle) ? a[k] : d;
     if (gl < N) lds[x_off + gl * DOF_E] = fdiv(a[N], d);
     WSYNC();
     return;
@@ -691,6 +695,8 @@ AMX_STATIC_SOLVE_ATTR void newton_solve_fused(int M_off, int ld_, int n_, unsign
   if constexpr (sym_elim_ok<S, G>() && G == 32) {
     // crossbar-free elimination (see sym_pivot): b reaches lane N as a row through the staging vector at bt_off
     constexpr int NS = S::nv, lds_ = S::ldm, nchs = lds_ / 4;
+    int gle = gl;  // see spd_solve_static
+    asm volatile("" : "+v"(gle));
     const unsigned long long crows_u = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(crows_ >> 32)) << 32) |
                                        (unsigned)__builtin_amdgcn_readfirstlane((int)crows_);
     unsigned lo[4][4], hi[4][4];
@@ -725,17 +731,17 @@ AMX_STATIC_SOLVE_ATTR void newton_solve_fused(int M_off, int ld_, int n_, unsign
       for (int q = 0; q < 4; ++q) {
         const int k = 4 * c + q;
         if (k < NS) {  // both arms computed, then selected: a lazily evaluated ?: became a branch per entry
-          const float hk = (e[q] + __uint_as_float(src[q])) + (k == gl ? dlim : 0.0f), bk = brow ? e[q] : 0.0f;
+          const float hk = (e[q] + __uint_as_float(src[q])) + (k == gle ? dlim : 0.0f), bk = brow ? e[q] : 0.0f;
           a[k] = owner ? hk : bk;
         }
       }
     }
     a[NS] = b;
-    if constexpr (TREE) SymTree<S, G, NS - 1, true>::run(a, gl);
-    else SymDense<S, G, 0, true>::run(a, gl);
+    if constexpr (TREE) SymTree<S, G, NS - 1, true>::run(a, gle);
+    else SymDense<S, G, 0, true>::run(a, gle);
     float d = 1.0f;
 #pragma unroll
-    for (int k = 0; k < NS; ++k) d = (k == gl) ? a[k] : d;
+    for (int k = 0; k < NS; ++k) d = (k == gle) ? a[k] : d;
     if (owner) lds[x_off + gl * DOF_E] = fdiv(a[NS], d);
     WSYNC();
     return;
@@ -2045,6 +2051,8 @@ struct Env {
   // behind a divergent branch (r02b: 56 such branches per step, each with its own wait).  Two partial sums.
   DEV float chain_dot(int Jr, int vo, int vs) const {
     float a0 = 0, a1 = 0;
+    int rdn_ = rdn;  // recomputed tests (t < rdn) per call: as loop invariants the masks lived in spilled scalar registers
+    asm volatile("" : "+v"(rdn_));
 #pragma unroll
     for (int w = 0; w < 4; ++w) {  // dof list from registers: no metadata loads on this path
       const int pk = rchain[w];
@@ -2055,7 +2063,7 @@ struct Env {
           // the select sits on the Jacobian entry (stale slots become 0; v is always a live dof value), so each term stays
           // one fused multiply-add as in the branchy loop
           const float jraw = lds[Jr + t], vt = lds[vo + ((pk >> (8 * q)) & 255) * vs];  // loaded unconditionally, then selected
-          const float jt = t < rdn ? jraw : 0.0f;
+          const float jt = t < rdn_ ? jraw : 0.0f;
           if (t & 1) a1 = __builtin_fmaf(jt, vt, a1); else a0 = __builtin_fmaf(jt, vt, a0);
         }
       }
