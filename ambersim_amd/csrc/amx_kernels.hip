@@ -1452,20 +1452,18 @@ struct Env {
     if (gl < m.nv()) {
       const int i = gl, j = d_jadr;
       const f3 off = ld_com(d_root) - mk3(jnt(0, j), jnt(1, j), jnt(2, j));
-      f3 w = mk3(0, 0, 0), l = mk3(0, 0, 0);
-      if (d_kind == 0) {
-        l = mk3(d_axis == 0 ? 1.0f : 0.0f, d_axis == 1 ? 1.0f : 0.0f, d_axis == 2 ? 1.0f : 0.0f);
-      } else if (d_kind == 1) {
-        const m33 R = q2m(ld_xquat(d_body));
-        // column d_axis of R by selects: a run-time index would put the matrix in scratch memory
-        w = d_axis == 0 ? mk3(R.a[0], R.a[3], R.a[6]) : (d_axis == 1 ? mk3(R.a[1], R.a[4], R.a[7]) : mk3(R.a[2], R.a[5], R.a[8]));
-        l = cross(w, off);
-      } else if (d_kind == 2) {
-        w = mk3(jnt(3, j), jnt(4, j), jnt(5, j));
-        l = cross(w, off);
-      } else {
-        l = mk3(jnt(3, j), jnt(4, j), jnt(5, j));
-      }
+      // the four dof kinds without branches: both sources are loaded, the kind selects (a wave holds every kind anyway, so the
+      // branches skipped nothing and put a wait in front of each path's loads)
+      const m33 R = q2m(ld_xquat(d_body));
+      const f3 jax = mk3(jnt(3, j), jnt(4, j), jnt(5, j));
+      const f3 e_ = mk3(d_axis == 0 ? 1.0f : 0.0f, d_axis == 1 ? 1.0f : 0.0f, d_axis == 2 ? 1.0f : 0.0f);
+      // column d_axis of R by selects: a run-time index would put the matrix in scratch memory
+      const f3 rc = d_axis == 0 ? mk3(R.a[0], R.a[3], R.a[6]) : (d_axis == 1 ? mk3(R.a[1], R.a[4], R.a[7]) : mk3(R.a[2], R.a[5], R.a[8]));
+      const bool rot = d_kind == 1 || d_kind == 2;  // free/ball rotation, hinge: w = axis, l = w x off
+      const f3 wa = d_kind == 1 ? rc : jax;
+      const f3 wl = cross(wa, off);
+      const f3 w = rot ? wa : mk3(0, 0, 0);
+      const f3 l = rot ? wl : (d_kind == 0 ? e_ : jax);
       dof(0, i) = w.x; dof(1, i) = w.y; dof(2, i) = w.z; dof(3, i) = l.x; dof(4, i) = l.y; dof(5, i) = l.z;
     }
     if (gl < m.ngc()) {
@@ -1706,13 +1704,19 @@ struct Env {
     const int qp = eb + m.e_qpos(), qv = eb + m.e_qvel();
     const bool act_on = m.nu() > 0 && !(m.disableflags() & DIS_ACTUATION);
     if (act_on && gl < m.nu()) {
+      // every parameter loaded up front, the option flags are selects (as `if`s each one was a branch around its own loads)
       const int ar = m.c_act() + gl * ACT_S, fl = CI(ar + 2);
-      const float gear = CF(ar + 3);
+      const float gear = CF(ar + 3), gain = CF(ar + 4), b0 = CF(ar + 5), b1 = CF(ar + 6), b2 = CF(ar + 7);
+      const float clo = CF(ar + 8), chi = CF(ar + 9), flo = CF(ar + 10), fhi = CF(ar + 11);
+      const float qj = lds[qp + CI(ar)], vj = lds[qv + CI(ar + 1)];
       float c = lds[eb + m.e_ctrl() + gl];
-      if (!(m.disableflags() & DIS_CLAMPCTRL) && (fl & 1)) c = fminf(fmaxf(c, CF(ar + 8)), CF(ar + 9));
-      float force = CF(ar + 4) * c;
-      if (fl & 4) force += CF(ar + 5) + CF(ar + 6) * (lds[qp + CI(ar)] * gear) + CF(ar + 7) * (lds[qv + CI(ar + 1)] * gear);
-      if (fl & 2) force = fminf(fmaxf(force, CF(ar + 10)), CF(ar + 11));
+      const float cc = fminf(fmaxf(c, clo), chi);
+      c = (!(m.disableflags() & DIS_CLAMPCTRL) && (fl & 1)) ? cc : c;
+      float force = gain * c;
+      const float fb = force + (b0 + b1 * (qj * gear) + b2 * (vj * gear));
+      force = (fl & 4) ? fb : force;
+      const float fc = fminf(fmaxf(force, flo), fhi);
+      force = (fl & 2) ? fc : force;
       lds[eb + m.e_actf() + gl] = gear * force;
     }
     WSYNC();
@@ -1725,14 +1729,18 @@ struct Env {
       float pas = 0;
       if (!(m.disableflags() & DIS_PASSIVE)) {
         const int jr = m.c_jnt() + d_jnt * JNT_S;
-        const float k = CF(jr + 11);
-        if (k != 0.0f && d_kind >= 2) pas -= k * (lds[qp + CI(jr + 1)] - CF(jr + 12));
+        const float k = CF(jr + 11), qj = lds[qp + CI(jr + 1)], qref = CF(jr + 12);
+        const float ks = k * (qj - qref);
+        pas -= (k != 0.0f && d_kind >= 2) ? ks : 0.0f;
         pas -= CF(dr + 5) * lds[qv + i];
       }
       float act = 0;
       if (act_on) {
+        // the first actuator of the dof without a branch (a dof rarely has a second one)
         const int a0 = CI(dr + 6), an = CI(dr + 7);
-        for (int a = 0; a < an; ++a) act += lds[eb + m.e_actf() + CI(m.c_dofact() + a0 + a)];
+        const float f0 = lds[eb + m.e_actf() + CI(m.c_dofact() + (an > 0 ? a0 : 0))];
+        act = an > 0 ? f0 : 0.0f;
+        for (int a = 1; a < an; ++a) act += lds[eb + m.e_actf() + CI(m.c_dofact() + a0 + a)];
       }
       dof(D_FBIAS, i) = bias;
       dof(D_FSMOOTH, i) = pas - bias + act;
