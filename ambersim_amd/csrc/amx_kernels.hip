@@ -1206,6 +1206,9 @@ template <int G, class S>
 struct Env {
   const MV<S> m;
   const int eb, gl, gb4;  // slab base, lane-in-group, 4 * first lane of the group (crossbar address base)
+  // bases of the body and dof records, opaque to the compiler: with `eb + e_body` folded into one constant every pair of fields
+  // got its own `v_add_u32` (ds_read2_b32 reaches 1 KB from its base); relative to these the field offsets fit the instruction
+  int ebB, ebD;
   // static role constants of this lane
   int b_parent, b_level, b_root, b_jntadr, b_jntnum, b_childadr, b_childnum, b_subend;  // body `lane` (b_subend: one past its last descendant)
   int d_body, d_jnt, d_kind, d_axis, d_root, d_jadr, d_limrow;                // dof `lane` (d_jadr: first dof of its joint; d_limrow: lane of its limit row)
@@ -1228,6 +1231,8 @@ struct Env {
 
   DEV Env(const MV<S> &m_, int eb_, int gl_, int gb4_) : m(m_), eb(eb_), gl(gl_), gb4(gb4_) {
     const int lane = gl;
+    ebB = eb + m.e_body(); ebD = eb + m.e_dof();
+    asm volatile("" : "+v"(ebB), "+v"(ebD));
     const int br = m.c_body() + (lane < m.nb() ? lane : 0) * BODY_S;
     b_parent = CI(br); b_level = lane < m.nb() ? CI(br + 1) : -1; b_root = CI(br + 2); b_jntadr = CI(br + 3); b_jntnum = CI(br + 4);
     b_childadr = CI(br + 5); b_childnum = CI(br + 6) & 255; b_subend = CI(br + 6) >> 8;
@@ -1263,16 +1268,16 @@ struct Env {
   // SoA accessors of the environment slab
   // Records with odd compile-time strides: gl-per-record access is bank-conflict free and every field
   // is an immediate offset from one base address (no per-field address registers).
-  DEV float &body(int f, int b) const { return lds[eb + m.e_body() + b * BODY_E + f]; }
+  DEV float &body(int f, int b) const { return lds[ebB + b * BODY_E + f]; }
   // joint anchor (0-2) and axis (3-5), world frame: fields 6..11 of the record of the joint's first dof `da` (dead solver vectors
   // of the previous step; crb*cdof overwrites them once the motion axes are formed)
-  DEV float &jnt(int f, int da) const { return lds[eb + m.e_dof() + da * DOF_E + 6 + f]; }
+  DEV float &jnt(int f, int da) const { return lds[ebD + da * DOF_E + 6 + f]; }
   // float offset of M[i][j] inside the matrix block (rows may store their 16-byte chunks rotated, see amx_plan.h)
   DEV int moff(int i, int j) const {
     const int nch = m.ldm() >> 2, rot = m.mrot() ? i % nch : 0;
     return i * m.ldm() + 4 * (((j >> 2) + rot) % nch) + (j & 3);
   }
-  DEV float &dof(int f, int i) const { return lds[eb + m.e_dof() + i * DOF_E + f]; }
+  DEV float &dof(int f, int i) const { return lds[ebD + i * DOF_E + f]; }
   DEV float &row(int f, int r) const { return lds[eb + m.e_row() + r * ROW_E + f]; }
   DEV float &con(int f, int c) const { return lds[eb + m.e_con() + c * CON_E + f]; }
   DEV float &geo(int f, int g) const { return lds[eb + m.e_geom() + g * GEO_E + f]; }
@@ -1295,7 +1300,7 @@ struct Env {
   // crb*cdof (6) is dead once M is built; the six solver vectors reuse its space
   enum { D_CDOF = 0, D_FCRB = 6, D_MA = 6, D_GRAD = 7, D_MGRAD = 8, D_SEARCH = 9, D_MV = 10, D_FCON = 11,
          D_FSMOOTH = 12, D_ASMOOTH = 13, D_QACC = 14, D_WARM = 15, D_FBIAS = 16 };
-  DEV int dofoff(int f) const { return eb + m.e_dof() + f; }  // element i of dof field f lives at dofoff(f) + i*DOF_E
+  DEV int dofoff(int f) const { return ebD + f; }  // element i of dof field f lives at dofoff(f) + i*DOF_E
 
   // ------------------------------------------------------------------ A9.1 kinematics
   // Three passes, so that the joint arithmetic (type switch, sin/cos, quaternion products) runs once per step and not once
