@@ -571,7 +571,7 @@ template <class S, int G, int K> struct SymRest {  // dense order: every column 
     }
   }
 };
-template <class S, int G, int J, bool TREE, bool BCOL> DEV void sym_pivot(float (&a)[S::nv + 1], int gl) {
+template <class S, int G, int J, bool TREE, bool BCOL> DEV void sym_pivot(float (&a)[S::nv + 1], int gl, float &diag) {
   constexpr int N = S::nv;
   const float c = a[J];
   const RowPair p = row_pair<G>(c);
@@ -580,6 +580,7 @@ template <class S, int G, int J, bool TREE, bool BCOL> DEV void sym_pivot(float 
   asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(piv) : "v"(J < 16 ? p.r0 : p.r1), "v"(MINVAL), "n"(J & 15));
   float nf = -c * __builtin_amdgcn_rcpf(piv);
   nf = gl == J ? 0.0f : nf;  // the pivot row itself is left alone
+  diag = gl == J ? piv : diag;  // ... and its diagonal is final: kept for the last division (same test, no pass over the row at the end)
   if constexpr (BCOL) {
     fmac_bcast<N>(a[N], p, nf);
   } else {
@@ -590,17 +591,17 @@ template <class S, int G, int J, bool TREE, bool BCOL> DEV void sym_pivot(float 
   else SymRest<S, G, J + 1>::run(a, p, nf);
 }
 template <class S, int G, int J, bool BCOL> struct SymTree {  // leaves before their ancestors
-  static DEV void run(float (&a)[S::nv + 1], int gl) {
-    sym_pivot<S, G, J, true, BCOL>(a, gl);
-    SymTree<S, G, J - 1, BCOL>::run(a, gl);
+  static DEV void run(float (&a)[S::nv + 1], int gl, float &diag) {
+    sym_pivot<S, G, J, true, BCOL>(a, gl, diag);
+    SymTree<S, G, J - 1, BCOL>::run(a, gl, diag);
   }
 };
-template <class S, int G, bool BCOL> struct SymTree<S, G, -1, BCOL> { static DEV void run(float (&)[S::nv + 1], int) {} };
+template <class S, int G, bool BCOL> struct SymTree<S, G, -1, BCOL> { static DEV void run(float (&)[S::nv + 1], int, float &) {} };
 template <class S, int G, int J, bool BCOL> struct SymDense {
-  static DEV void run(float (&a)[S::nv + 1], int gl) {
+  static DEV void run(float (&a)[S::nv + 1], int gl, float &diag) {
     if constexpr (J < S::nv) {
-      sym_pivot<S, G, J, false, BCOL>(a, gl);
-      SymDense<S, G, J + 1, BCOL>::run(a, gl);
+      sym_pivot<S, G, J, false, BCOL>(a, gl, diag);
+      SymDense<S, G, J + 1, BCOL>::run(a, gl, diag);
     }
   }
 };
@@ -641,16 +642,14 @@ AMX_STATIC_SOLVE_ATTR void spd_solve_static(int A_off, int rhs_off, int x_off, i
       }
     }
     a[N] = b;
-    if (BCOL && bt_off >= 0) {
-      if (TREE) SymTree<S, G, N - 1, true>::run(a, gle);
-      else SymDense<S, G, 0, true>::run(a, gle);
-    } else {
-      if (TREE) SymTree<S, G, N - 1, false>::run(a, gle);
-      else SymDense<S, G, 0, false>::run(a, gle);
-    }
     float d = 1.0f;
-#pragma unroll
-    for (int k = 0; k < N; ++k) d = (k == gle) ? a[k] : d;
+    if (BCOL && bt_off >= 0) {
+      if (TREE) SymTree<S, G, N - 1, true>::run(a, gle, d);
+      else SymDense<S, G, 0, true>::run(a, gle, d);
+    } else {
+      if (TREE) SymTree<S, G, N - 1, false>::run(a, gle, d);
+      else SymDense<S, G, 0, false>::run(a, gle, d);
+    }
     if (gl < N) lds[x_off + gl * DOF_E] = fdiv(a[N], d);
     WSYNC();
     return;
@@ -737,11 +736,9 @@ AMX_STATIC_SOLVE_ATTR void newton_solve_fused(int M_off, int ld_, int n_, unsign
       }
     }
     a[NS] = b;
-    if constexpr (TREE) SymTree<S, G, NS - 1, true>::run(a, gle);
-    else SymDense<S, G, 0, true>::run(a, gle);
     float d = 1.0f;
-#pragma unroll
-    for (int k = 0; k < NS; ++k) d = (k == gle) ? a[k] : d;
+    if constexpr (TREE) SymTree<S, G, NS - 1, true>::run(a, gle, d);
+    else SymDense<S, G, 0, true>::run(a, gle, d);
     if (owner) lds[x_off + gl * DOF_E] = fdiv(a[NS], d);
     WSYNC();
     return;
