@@ -16,11 +16,19 @@
 //     LDS records with odd strides (bank-conflict free), never through dependent HBM loads;
 //   * per-body / per-dof / per-row data are odd-stride records in LDS; M and H are full symmetric with 16-byte rows
 //     (ds_read_b128), the contact Jacobian is chain-compressed;
-//   * tree scans run level by level; up-scans gather from a static child list instead of scattering;
+//   * tree up-scans (composite inertia, force totals) are sums over contiguous record ranges - bodies are numbered
+//     depth-first - and the roots are group sums; down-scans walk each body's ancestor chain in registers (deep trees) or
+//     run level by level (shallow ones, and any model whose numbering is not depth-first);
 //   * the Newton Hessian M + J'DJ is accumulated on the matrix cores (v_mfma_f32_32x32x1_2b: the two blocks are the two
-//     environments of a G = 32 wave) and handed to the solver through v_permlane32_swap;
+//     environments of a G = 32 wave) and handed to the solver through v_permlane32_swap; a spare lane of the product also
+//     delivers J'f (COL31);
 //   * the small dense solves (M, M+J'DJ, M+dt*damping) are one-shot Gauss-Jordan eliminations with one matrix row per
-//     lane in registers; pivot rows travel by v_readlane (G = 64) or through the LDS crossbar (ds_swizzle, G < 64);
+//     lane in registers; in the specialised kernels pivot rows are read from the pivot COLUMN by symmetry through DPP row
+//     broadcasts (sym_pivot: no LDS instruction), in the generic ones they travel by v_readlane (G = 64) or through the
+//     LDS crossbar (ds_swizzle, G < 64);
+//   * hot loops are straight-line: loads are unconditional (clamped to a valid address) and conditions are selects - a
+//     conditional load becomes a divergent branch with its own s_waitcnt - except where a branch lets a lane group skip
+//     real arithmetic (the kernel is VALU-bound);
 //   * group reductions use DPP row operations (+ one ds_swizzle / bpermute step across rows), never LDS memory;
 //   * HBM traffic of a rollout is the control stream in and the state rows out, both coalesced.
 #include <hip/hip_runtime.h>
