@@ -23,7 +23,7 @@ class AmxForwardOut(C.Structure):
 
 
 EXPORTS = ["amx_version", "amx_last_error", "amx_model_create", "amx_model_destroy", "amx_model_query",
-           "amx_forward", "amx_step", "amx_rollout", "amx_quadcost", "amx_fd_workspace_bytes", "amx_fd_grad"]
+           "amx_forward", "amx_step", "amx_step_to", "amx_rollout", "amx_quadcost", "amx_fd_workspace_bytes", "amx_fd_grad"]
 
 
 def build(force: bool = False) -> Path:
@@ -63,6 +63,7 @@ def load(path) -> C.CDLL:
     L.amx_model_query.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]
     L.amx_forward.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.POINTER(AmxForwardOut), C.c_void_p]
     L.amx_step.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_void_p]
+    L.amx_step_to.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 9 + [C.c_void_p]
     L.amx_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.amx_quadcost.argtypes = [C.c_int] * 4 + [C.c_void_p] * 7 + [C.c_void_p]
     L.amx_fd_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t)]

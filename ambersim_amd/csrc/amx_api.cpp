@@ -224,9 +224,9 @@ extern "C" int amx_forward(const amx_model *m, int nenv, const float *qpos, cons
   return AMX_OK;
 }
 
-extern "C" int amx_step(const amx_model *m, int nenv, int nsub, float *qpos, float *qvel, const float *ctrl, float *warm,
-                        float *time, void *stream) {
-  if (!m || !qpos || !qvel || (m->dev.nu > 0 && !ctrl) || nenv < 0 || nsub < 0) return fail(AMX_EINVAL, "amx_step: bad argument");
+extern "C" int amx_step_to(const amx_model *m, int nenv, int nsub, const float *qpos, const float *qvel, const float *ctrl, const float *warm,
+                           const float *time, float *qpos_out, float *qvel_out, float *warm_out, float *time_out, void *stream) {
+  if (!m || !qpos || !qvel || !qpos_out || !qvel_out || (m->dev.nu > 0 && !ctrl) || nenv < 0 || nsub < 0) return fail(AMX_EINVAL, "amx_step: bad argument");
   if (nenv == 0) return AMX_OK;
   AMX_ON_DEVICE(m->device);
   dim3 grid;
@@ -234,11 +234,16 @@ extern "C" int amx_step(const amx_model *m, int nenv, int nsub, float *qpos, flo
   if (int rc = pre_launch(m, nenv, &grid, &wpb, &lds_bytes)) return rc;
   if (!for_spec(m->spec, [&](auto sp) {
         using S = decltype(sp);
-        hipLaunchKernelGGL((amx_step_kernel<S::G, S>), grid, dim3(AMX_WAVE * wpb), lds_bytes, (hipStream_t)stream, m->dev, nenv, nsub, qpos, qvel, ctrl, warm, time);
+        hipLaunchKernelGGL((amx_step_kernel<S::G, S>), grid, dim3(AMX_WAVE * wpb), lds_bytes, (hipStream_t)stream, m->dev, nenv, nsub, qpos, qvel, ctrl, warm, time,
+                           qpos_out, qvel_out, warm_out, time_out);
       }))
-    AMX_LAUNCH_G(amx_step_kernel, m, grid, stream, m->dev, nenv, nsub, qpos, qvel, ctrl, warm, time);
+    AMX_LAUNCH_G(amx_step_kernel, m, grid, stream, m->dev, nenv, nsub, qpos, qvel, ctrl, warm, time, qpos_out, qvel_out, warm_out, time_out);
   HIP_TRY(hipGetLastError());
   return AMX_OK;
+}
+extern "C" int amx_step(const amx_model *m, int nenv, int nsub, float *qpos, float *qvel, const float *ctrl, float *warm,
+                        float *time, void *stream) {
+  return amx_step_to(m, nenv, nsub, qpos, qvel, ctrl, warm, time, qpos, qvel, warm, time, stream);
 }
 
 #ifdef AMX_PROFILE

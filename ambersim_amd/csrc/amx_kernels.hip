@@ -2601,9 +2601,11 @@ amx_rollout_kernel(const DevModel m_in, int nenv, int nsteps, int x0_batched, co
 // quadruped, 32768 environments, 121 -> 161 M env-steps/s (r02).
 template <int G, class S, int MINW = AMX_MIN_WAVES_PER_SIMD>
 __global__ void __launch_bounds__(AMX_BLOCK, MINW)
-amx_step_kernel(const DevModel m_in, int nenv, int nsub, float *__restrict__ qpos, float *__restrict__ qvel, const float *__restrict__ ctrl,
-                float *__restrict__ warm, float *__restrict__ time) {
+amx_step_kernel(const DevModel m_in, int nenv, int nsub, const float *qpos, const float *qvel, const float *__restrict__ ctrl,
+                const float *warm, const float *time, float *qpos_out, float *qvel_out, float *warm_out, float *time_out) {
+  // outputs may alias their inputs (amx_step): every input of an environment is read before any of its outputs is written
   AMX_KERNEL_PROLOGUE()
+  float t0 = 0.0f;
   if (live) {
     for (int i = gl; i < nq; i += G) lds[qp + i] = qpos[(size_t)e * nq + i];
     if (gl < nv) {
@@ -2611,16 +2613,17 @@ amx_step_kernel(const DevModel m_in, int nenv, int nsub, float *__restrict__ qpo
       env.dof(Env<G, S>::D_WARM, gl) = warm ? warm[(size_t)e * nv + gl] : 0.0f;
     }
     for (int i = gl; i < nu; i += G) lds[eb + m.e_ctrl() + i] = ctrl[(size_t)e * nu + i];
+    if (time && gl == 0) t0 = time[e];
   }
   WSYNC();
   for (int t = 0; t < nsub; ++t) { env.forward(); env.euler(); }
   if (!live) return;
-  for (int i = gl; i < nq; i += G) qpos[(size_t)e * nq + i] = lds[qp + i];
+  for (int i = gl; i < nq; i += G) qpos_out[(size_t)e * nq + i] = lds[qp + i];
   if (gl < nv) {
-    qvel[(size_t)e * nv + gl] = lds[qv + gl];
-    if (warm) warm[(size_t)e * nv + gl] = env.dof(Env<G, S>::D_WARM, gl);
+    qvel_out[(size_t)e * nv + gl] = lds[qv + gl];
+    if (warm_out) warm_out[(size_t)e * nv + gl] = env.dof(Env<G, S>::D_WARM, gl);
   }
-  if (time && gl == 0) time[e] += m.dt() * nsub;
+  if (time_out && gl == 0) time_out[e] = t0 + m.dt() * nsub;
 }
 
 struct ForwardOut { float *qacc, *qacc_smooth, *qfrc_bias, *qfrc_constraint, *qM, *xpos, *xquat, *cdist; int *nefc; };

@@ -253,16 +253,20 @@ def forward(m: Model, d: Data) -> Data:
 def step(m: Model, d: Data, nsub: int = 1) -> Data:
     """mjx.step, `nsub` times with ctrl held (reference ambersim/rl/base.py:88-96).  Functional: returns new Data."""
     b, n, t = _prep(m, d, ("qpos", "qvel", "ctrl", "qacc_warmstart"))
-    qpos, qvel, warm = t["qpos"].clone(), t["qvel"].clone(), t["qacc_warmstart"].clone()  # updated in place by the kernel
     ctrl = t["ctrl"]
     time = d.time if torch.is_tensor(d.time) else torch.tensor(float(d.time or 0.0))
     time = time.to(device=m.device, dtype=torch.float32).reshape(-1)
     if time.numel() not in (1, n):
         raise ValueError(f"Data.time has {time.numel()} entries, the batch has {n}")
-    time = time.expand(n).clone()
+    time = time.expand(n).contiguous()
+    # out of place (amx_step_to): fresh outputs, no copies of the inputs in front of the launch
+    qpos, qvel, warm, tout = (torch.empty_like(t["qpos"]), torch.empty_like(t["qvel"]), torch.empty_like(t["qacc_warmstart"]),
+                              torch.empty_like(time))
     with torch.cuda.device(m.device):
-        _lib.check(m._h.L.amx_step(m._h.ptr, n, int(nsub), qpos.data_ptr(), qvel.data_ptr(), ctrl.data_ptr(), warm.data_ptr(),
-                                       time.data_ptr(), _stream_ptr(m.device)))
+        _lib.check(m._h.L.amx_step_to(m._h.ptr, n, int(nsub), t["qpos"].data_ptr(), t["qvel"].data_ptr(), ctrl.data_ptr(),
+                                          t["qacc_warmstart"].data_ptr(), time.data_ptr(), qpos.data_ptr(), qvel.data_ptr(), warm.data_ptr(),
+                                          tout.data_ptr(), _stream_ptr(m.device)), m._h.L)
+    time = tout
     s = (lambda t: t) if b else (lambda t: t[0])
     return d.replace(qpos=s(qpos), qvel=s(qvel), qacc_warmstart=s(warm), qacc=s(warm) if m.nefc_max > 0 else d.qacc, time=s(time),
                      ctrl=s(ctrl))

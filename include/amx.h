@@ -6,7 +6,7 @@
  *
  *   amx_model_create   <- mjx.device_put(mj_model)        ambersim/utils/io_utils.py:225, rl/base.py:52
  *   amx_forward        <- mjx.forward(sys, data)          ambersim/rl/base.py:85, trajopt/shooting.py:36
- *   amx_step           <- lax.scan of mjx.step            ambersim/rl/base.py:88-96  (MjxEnv.pipeline_step)
+ *   amx_step(_to)      <- lax.scan of mjx.step            ambersim/rl/base.py:88-96  (MjxEnv.pipeline_step)
  *   amx_rollout        <- shoot(m, x0, us) under vmap     ambersim/trajopt/shooting.py:22-48,152
  *   amx_quadcost       <- StaticGoalQuadraticCost.cost    ambersim/trajopt/cost.py:62-85 (batched over rollouts)
  *   amx_fd_grad        <- shoot + terminal cost, forward-differenced over ctrl (BASELINE.json configs[3]; composes
@@ -123,6 +123,15 @@ int amx_forward(const amx_model *m, int nenv, const float *qpos_dev, const float
  * qpos[nenv,nq], qvel[nenv,nv], qacc_warmstart[nenv,nv]; time[nenv] may be NULL. */
 int amx_step(const amx_model *m, int nenv, int nsub, float *qpos_dev, float *qvel_dev,
              const float *ctrl_dev, float *qacc_warmstart_dev, float *time_dev, void *stream);
+
+/* The same step out of place, as mjx.step is (it returns a new Data, reference ambersim/rl/base.py:93): reads
+ * qpos/qvel/qacc_warmstart/time, writes the *_out buffers (same shapes).  An output may be its input (that is amx_step);
+ * a functional host layer needs no copies in front of the launch.  qacc_warmstart_dev NULL: cold start; time_dev NULL:
+ * time counts from 0; qacc_warmstart_out_dev / time_out_dev NULL: not written. */
+int amx_step_to(const amx_model *m, int nenv, int nsub, const float *qpos_dev, const float *qvel_dev,
+                const float *ctrl_dev, const float *qacc_warmstart_dev, const float *time_dev,
+                float *qpos_out_dev, float *qvel_out_dev, float *qacc_warmstart_out_dev, float *time_out_dev,
+                void *stream);
 
 /* vmap(shoot): xs[e,0,:] = x0[e], xs[e,t+1,:] = concat(qpos,qvel) after step t under us[e,t,:].
  * x0 is [nenv,nq+nv] when x0_batched != 0, else one shared [nq+nv] row.  State stays on chip

@@ -22,7 +22,7 @@ def declared_functions():
 
 def test_library_exports_every_declared_symbol():
     names = declared_functions()
-    assert set(names) == set(_lib.EXPORTS) and len(names) == 11
+    assert set(names) == set(_lib.EXPORTS) and len(names) == 12
     lib = _lib.lib()
     for n in names:
         assert hasattr(lib, n), n

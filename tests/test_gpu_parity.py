@@ -799,3 +799,29 @@ def test_edge_cases_and_maximum_sizes(dev):
     assert rel(xs[:, 1], Oracle(mj, np.float64).rollout(x, np.zeros((4, 5, 0)))[:, 1]) < TOL
     with pytest.raises(NotImplementedError):
         mjx.put_model(MjModel.from_xml_string(chain(27, root=free)), dev)  # 33 dofs: beyond the register-row capacity
+
+
+def test_step_out_of_place_matches_in_place(cases, dev):
+    """amx_step_to (out of place, what mjx.step calls) and amx_step (in place) are the same kernel: identical bits, inputs
+    untouched; an output may be its input."""
+    import ctypes as C
+    from ambersim_amd import _lib, mjx
+    mj, model, x0, us = cases["quadruped"]
+    n = 16
+    f32 = dict(dtype=torch.float32, device=dev)
+    q = torch.tensor(x0[:n, :mj.nq], **f32).contiguous(); v = torch.tensor(x0[:n, mj.nq:], **f32).contiguous()
+    u = torch.tensor(us[:n, 0], **f32).contiguous(); w = torch.zeros((n, mj.nv), device=dev); t = torch.full((n,), 0.5, device=dev)
+    L = model._h.L
+    q1, v1, w1, t1 = q.clone(), v.clone(), w.clone(), t.clone()
+    _lib.check(L.amx_step(model._h.ptr, n, 3, q1.data_ptr(), v1.data_ptr(), u.data_ptr(), w1.data_ptr(), t1.data_ptr(), None), L)
+    q2, v2, w2, t2 = torch.empty_like(q), torch.empty_like(v), torch.empty_like(w), torch.empty_like(t)
+    qk, vk = q.clone(), v.clone()
+    _lib.check(L.amx_step_to(model._h.ptr, n, 3, q.data_ptr(), v.data_ptr(), u.data_ptr(), w.data_ptr(), t.data_ptr(),
+                             q2.data_ptr(), v2.data_ptr(), w2.data_ptr(), t2.data_ptr(), None), L)
+    torch.cuda.synchronize()
+    assert torch.equal(q, qk) and torch.equal(v, vk)  # inputs untouched
+    assert torch.equal(q1, q2) and torch.equal(v1, v2) and torch.equal(w1, w2) and torch.equal(t1, t2)
+    assert torch.allclose(t2, torch.full((n,), 0.5 + 3 * mj.opt.timestep, device=dev))
+    d = mjx.make_data(model, n).replace(qpos=q, qvel=v, ctrl=u, qacc_warmstart=w, time=t)
+    d2 = mjx.step(model, d, 3)
+    assert torch.equal(d2.qpos, q2) and torch.equal(d2.qvel, v2) and torch.equal(d.qpos, qk)
