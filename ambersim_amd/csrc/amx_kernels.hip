@@ -1361,7 +1361,7 @@ struct Env {
       body(3, b) = quat.w; body(4, b) = quat.x; body(5, b) = quat.y; body(6, b) = quat.z;
     }
     WSYNC();
-    if (m.nlevel() > AMX_CHAIN_WALK_MIN_LEVELS && !AMX_LEVEL_SCANS) {  // shallow trees: the level scan is as fast (quadruped, 5 levels: measured)
+    if (m.nlevel() > AMX_CHAIN_WALK_MIN_LEVELS && !m.deep_free() && !AMX_LEVEL_SCANS) {  // shallow trees: the level scan is as fast (quadruped, 5 levels: measured)
       // every body walks its own ancestor chain (root first, constants c_anc) and composes the local poses in registers: the
       // same products in the same order as the level-by-level scan, but the loads are independent and nothing waits for a
       // parent's result to come back through LDS.  Chains are padded with the world body, whose pose is the identity (exact

@@ -171,6 +171,9 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
         if (!below) m.subtree_contig = 0;
       }
   }
+  const char *level_env = getenv("AMX_LEVEL_SCANS");  // diagnostic: plan as if the numbering were not depth-first (level-by-level scans)
+  const bool force_level = level_env && atoi(level_env) != 0;
+  if (force_level) m.subtree_contig = 0;
   m.sub_iter = 1;
   for (int b = 1; b < nb; b++) if (d->body_parentid[b] > 0) m.sub_iter = std::max(m.sub_iter, sub_last[b] - b + 1);
   // bodies
@@ -404,6 +407,7 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
     m.c_anc = add_ints(anc);
     m.deep_free = 0;
     for (int j = 0; j < nj; j++) if (d->jnt_type[j] == 0 && depth[d->jnt_bodyid[j]] > 1) m.deep_free = 1;
+    if (force_level) m.deep_free = 1;
   }
   if (m.G >= 32) { hent.clear(); m.nhent = 0; }  // wide groups build the Hessian on the matrix cores; only 16-lane groups walk the term list
   m.c_dofact = add_ints(dofact); m.c_pairdof = add_ints(pairdof); m.c_jac = add_ints(jac_items); m.c_hent = add_ints(hent);

@@ -825,3 +825,28 @@ def test_step_out_of_place_matches_in_place(cases, dev):
     d = mjx.make_data(model, n).replace(qpos=q, qvel=v, ctrl=u, qacc_warmstart=w, time=t)
     d2 = mjx.step(model, d, 3)
     assert torch.equal(d2.qpos, q2) and torch.equal(d2.qvel, v2) and torch.equal(d.qpos, qk)
+
+
+def test_level_scan_fallbacks_agree(dev, monkeypatch):
+    """The tree passes have two forms: contiguous subtree sums / ancestor-chain walks (bodies numbered depth-first, which every
+    model of the host compiler is) and the level-by-level scans kept for descriptors that are not.  AMX_LEVEL_SCANS=1 makes the
+    planner choose the scans: same physics within rounding (generic kernels in both runs), on the deep tree (biped) and a
+    shallow one (quadruped)."""
+    from ambersim_amd import mjx
+    from ambersim_amd.utils.io_utils import load_mj_model_from_file
+    from bench import make_inputs
+    for path in ("models/biped/biped.xml", "models/quadruped/quadruped.xml"):
+        mj = load_mj_model_from_file(path)
+        x0, us = make_inputs(mj, 64, 20, 1, 2, dev)
+        monkeypatch.setenv("AMX_NO_SPEC", "1")
+        flat = mjx.put_model(mj, dev)
+        monkeypatch.setenv("AMX_LEVEL_SCANS", "1")
+        level = mjx.put_model(mj, dev)
+        monkeypatch.delenv("AMX_LEVEL_SCANS"); monkeypatch.delenv("AMX_NO_SPEC")
+        assert flat._h.query("specialised") == 0 and level._h.query("specialised") == 0
+        a, b = mjx.rollout(flat, x0, us), mjx.rollout(level, x0, us)
+        e1 = float((a[:, 1] - b[:, 1]).abs().max() / max(1.0, float(b[:, 1].abs().max())))
+        e5 = float((a[:, 5] - b[:, 5]).abs().max() / max(1.0, float(b[:, 5].abs().max())))
+        print(f"{path}: flat vs level scans, 1-step {e1:.2e}, 5-step {e5:.2e}")
+        assert e1 < 5e-6 and e5 < 5e-5
+        assert not torch.equal(a, b)  # the two forms do round differently: the knob did switch them
