@@ -32,6 +32,7 @@
 //   * group reductions use DPP row operations (+ one ds_swizzle / bpermute step across rows), never LDS memory;
 //   * HBM traffic of a rollout is the control stream in and the state rows out, both coalesced.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "amx_dev.h"
 
 #define DEV __device__ __forceinline__
@@ -378,7 +379,9 @@ DEV void jtdj_rows_mfma(unsigned long long crows, int row_base, int J_base, int 
   unsigned long long cm = (crows | (crows >> 1) | (crows >> 2) | (crows >> 3)) & 0x1111111111111111ull;
   if (G == 32) {
     v32f C = {};
-    while (cm != 0ull) {
+    // the first active contact starts the accumulator from the instruction's constant 0 operand: clearing 32 registers
+    // with v_mov costs as much VALU time as two more contacts' operand loads
+    auto contact = [&](auto first) {
       const int c = __builtin_ctzll(cm) >> 2;
       cm &= cm - 1ull;
       const int slot = CI(slot_base + 32 * c + j);
@@ -394,8 +397,13 @@ DEV void jtdj_rows_mfma(unsigned long long crows, int row_base, int J_base, int 
       for (int r = 0; r < 4; ++r) {
         const float v = has ? jv[r] : 0.0f;
         const float aop = (COL31 && j == 31) ? g[r] : d[r] * v;
-        C = __builtin_amdgcn_mfma_f32_32x32x1f32(aop, v, C, 0, 0, 0);
+        if (decltype(first)::value && r == 0) { const v32f Z = {}; C = __builtin_amdgcn_mfma_f32_32x32x1f32(aop, v, Z, 0, 0, 0); }
+        else C = __builtin_amdgcn_mfma_f32_32x32x1f32(aop, v, C, 0, 0, 0);
       }
+    };
+    if (cm != 0ull) {
+      contact(std::true_type{});
+      while (cm != 0ull) contact(std::false_type{});
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
