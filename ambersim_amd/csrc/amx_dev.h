@@ -53,7 +53,7 @@ enum { CX_MAXV = 32, CX_MAXP = 16, CX_VA = 0, CX_VB = 96, CX_POLY = 192, CX_SCRA
   X(c_jac) /* packed contact|slot<<6|dof<<11|chain sign<<16|pair<<18 */                                                    \
   X(c_hent) /* [nhent] terms: packed dof_i|dof_j<<5|first contact row<<10|slot_i<<18|slot_j<<23 (dof_j <= dof_i) */         \
   X(c_dofmemadr) /* [nv+1] */ X(c_dofmem) /* terms: packed first contact row|slot<<8 */ X(c_conpair) /* [ncon] */           \
-  X(c_vert) X(c_rootbody) X(c_slot) /* [ncon][32]: position of dof j in the contact's dof chain, -1 if absent */ X(c_anc) /* [nb][max(nlevel-2,1)]: ancestors of a body, root first, itself and the world excluded, padded with 0 */            \
+  X(c_vert) X(c_rootbody) X(c_slot) /* [ncon][32]: position of dof j in the contact's dof chain, -1 if absent */ X(c_zero) /* one all-zero matrix row (ldm floats, 16-byte aligned): what the lanes without a matrix row load */ X(c_anc) /* [nb][max(nlevel-2,1)]: ancestors of a body, root first, itself and the world excluded, padded with 0 */            \
   /* bases inside one environment slab (float offsets from the slab start) */                                              \
   X(e_qpos) X(e_qvel) X(e_ctrl)                                                                                            \
   X(e_body) /* records [nb][BODY_E]: xpos 0-2 xquat 3-6 cinert 7-16 (then cfrc 7-12) crb 17-26 (then cvel 17-22 cacc 23-28) */ \

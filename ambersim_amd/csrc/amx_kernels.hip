@@ -643,8 +643,9 @@ AMX_STATIC_SOLVE_ATTR void spd_solve_static(int A_off, int rhs_off, int x_off, i
       if (gl < ld) lds[bt_off + gl] = b;
       WSYNC();
     }
-    const float4 *rowp = reinterpret_cast<const float4 *>(lds + (brow ? bt_off : A_off + li * ld));
-    const int rot_l = brow ? 0 : rot;
+    // lanes without a matrix row load the constants' all-zero row: no select per entry
+    const float4 *rowp = reinterpret_cast<const float4 *>(lds + (brow ? bt_off : (gl < N ? A_off + li * ld : S::c_zero)));
+    const int rot_l = gl < N ? rot : 0;
 #pragma unroll
     for (int c = 0; c < (N + 3) / 4; ++c) {
       int pc = c + (S::mrot ? rot_l : 0);
@@ -654,7 +655,7 @@ AMX_STATIC_SOLVE_ATTR void spd_solve_static(int A_off, int rhs_off, int x_off, i
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int k = 4 * c + q;
-        if (k < N) a[k] = (gl < N || brow) ? e[q] : 0.0f;
+        if (k < N) a[k] = e[q];
       }
     }
     a[N] = b;
@@ -717,6 +718,13 @@ AMX_STATIC_SOLVE_ATTR void newton_solve_fused(int M_off, int ld_, int n_, unsign
     unsigned lo[4][4], hi[4][4];
     const bool owner = gl < NS, brow = gl == NS;
     const int li = owner ? gl : 0;
+    // the limit row's diagonal term goes into the stored diagonal of M for the duration of the row loads (one LDS
+    // read-modify-write, hidden behind the matrix-core loop) instead of a compare + select + add per register of the row
+    int dpc = (gl >> 2) + (S::mrot ? rot : 0);
+    dpc -= dpc >= nchs ? nchs : 0;
+    const int dg = M_off + li * lds_ + 4 * dpc + (gl & 3);
+    float d0 = 0.0f;
+    if (owner) { d0 = lds[dg]; lds[dg] = d0 + dlim; }
     float b;
     if constexpr (GRADCOL) {
       static_assert(NS <= 31, "column 31 must be spare");
@@ -732,8 +740,10 @@ AMX_STATIC_SOLVE_ATTR void newton_solve_fused(int M_off, int ld_, int n_, unsign
     b = owner ? b : 0.0f;
     if (gl < lds_) lds[bt_off + gl] = b;
     WSYNC();
-    const float4 *rowp = reinterpret_cast<const float4 *>(lds + (brow ? bt_off : M_off + li * lds_));
-    const int rot_l = brow ? 0 : rot;
+    // lanes without a matrix row load the constants' all-zero row, and their J'DJ registers are zero (no slot): the row is a
+    // plain sum.  The diagonal term of the lane's limit row went into M's diagonal in LDS before the loads (restored below).
+    const float4 *rowp = reinterpret_cast<const float4 *>(lds + (brow ? bt_off : (owner ? M_off + li * lds_ : S::c_zero)));
+    const int rot_l = owner ? rot : 0;
     float a[NS + 1];
 #pragma unroll
     for (int c = 0; c < (NS + 3) / 4; ++c) {
@@ -745,12 +755,10 @@ AMX_STATIC_SOLVE_ATTR void newton_solve_fused(int M_off, int ld_, int n_, unsign
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int k = 4 * c + q;
-        if (k < NS) {  // both arms computed, then selected: a lazily evaluated ?: became a branch per entry
-          const float hk = (e[q] + __uint_as_float(src[q])) + (k == gle ? dlim : 0.0f), bk = brow ? e[q] : 0.0f;
-          a[k] = owner ? hk : bk;
-        }
+        if (k < NS) a[k] = e[q] + __uint_as_float(src[q]);
       }
     }
+    if (owner) lds[dg] = d0;  // M's own diagonal back (after the loads above: one wave's LDS operations execute in order)
     a[NS] = b;
     float d = 1.0f;
     if constexpr (TREE) SymTree<S, G, NS - 1, true>::run(a, gle, d);

@@ -454,6 +454,9 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
   for (int k = 0; k < nq; k++) im.setf(m.c_qpos0 + k, d->qpos0[k]);
   m.c_vert = im.reserve(3 * d->nconvexvert);
   for (int k = 0; k < 3 * d->nconvexvert; k++) im.setf(m.c_vert + k, d->convex_vert[k]);
+  while (im.size() & 3) im.reserve(1);
+  m.c_zero = im.reserve(m.ldm);  // stays zero: Image::reserve clears
+  for (int k = 0; k < m.ldm; k++) im.setf(m.c_zero + k, 0.0f);
   while (im.size() & 3) im.reserve(1);  // environment slabs start 16-byte aligned
   m.nconst = im.size();
 
