@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs the given step names on the GPU box in order; a step that hits its time limit (exit 124 / 137) ends the run - no
 # further GPU step is started after a kill.  Outputs land in gpurun_out/.
-#   bash tools/gpu_steps.sh tests parity bench configs stats pmc phase
+#   bash tools/gpu_steps.sh tests parity bench configs stats pmc phase c4 ppo
 REPO=$(pwd)
 mkdir -p gpurun_out
 run() {  # run <limit seconds> <log> <command...>
@@ -27,6 +27,9 @@ for step in "$@"; do
              run 900 gpurun_out/r02_pmc_biped.log bash tools/pmc_collect.sh biped --model models/biped/biped.xml ;;
     phase)   AMX_LIBRARY=ambersim_amd/csrc/libamx_prof.so run 300 gpurun_out/r02_phase_quadruped.txt python tools/phase_profile.py
              AMX_LIBRARY=ambersim_amd/csrc/libamx_prof.so run 300 gpurun_out/r02_phase_biped.txt python tools/phase_profile.py models/biped/biped.xml 4096 100 ;;
+    c4)      run 300 gpurun_out/r02_c4_fd_grad.txt python tools/c4_bench.py
+             (cd /tmp && export TMPDIR=/tmp && run 600 $REPO/gpurun_out/r02_stats_c4.log rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/r02_stats_c4 -o stats -- python3 $REPO/tools/c4_bench.py) ;;
+    ppo)     run 600 gpurun_out/r02_ppo_pendulum_swingup.log python examples/rl/pendulum/ex_swingup.py ;;
     *) echo "unknown step $step"; exit 2 ;;
   esac
 done
