@@ -41,7 +41,7 @@ enum { CX_MAXV = 32, CX_MAXP = 16, CX_VA = 0, CX_VB = 96, CX_POLY = 192, CX_SCRA
   X(ldm) /* row stride of M and H: >= nv, a multiple of 4 */                                                                \
   X(mrot) /* 1: row i of M stores chunk c at position (c + i) mod ldm/4 (fused path with an even chunk count) */          \
   X(fusedH) /* 1: Newton eliminates H in registers, no H buffer (G >= 32, no equality rows) */                            \
-  X(nchol) X(njac) X(nhent) X(subtree_contig) /* 1: every body's descendants are the bodies right after it (field 6 of the body record carries the end) */ X(sub_iter) /* largest subtree (bodies, itself included) below the tree roots */ X(deep_free) /* 1: a free joint below the first tree level (the chain-walking velocity pass assumes none) */ X(max_dofmem) /* most contacts any one dof takes part in */                                                                                               \
+  X(nchol) X(njac) X(nhent) X(subtree_contig) /* 1: every body's descendants are the bodies right after it (field 6 of the body record carries the end) */ X(sub_iter) /* largest subtree (bodies, itself included) below the tree roots */ X(deep_free) /* 1: a free joint below the first tree level (the chain-walking velocity pass assumes none) */ X(max_dofmem) /* most contacts any one dof takes part in */ X(max_jntnum) /* most joints on one body */                                                                                               \
   X(cx_first) X(ncx) /* run of convex-convex pairs (fn 6), processed one after the other by the whole lane group */         \
   X(pcx_first) X(npcx) /* run of plane - convex pairs (<= 32 hull vertices) handled one lane per vertex; npcx = 0: none */ X(pcx_unit) /* lanes per pair in that routine: 16 when every hull of the run has at most 16 vertices, else 32 */   \
   X(iterations) X(ls_iterations) X(solver) X(disableflags)                                                                 \

@@ -1337,6 +1337,12 @@ struct Env {
       body(0, 0) = 0; body(1, 0) = 0; body(2, 0) = 0;
       body(3, 0) = 1; body(4, 0) = 0; body(5, 0) = 0; body(6, 0) = 0;
     }
+    // Bodies with at most one joint each (max_jntnum <= 1: every shipped model): the joint's anchor and axis in the parent's frame
+    // stay in the body lane's registers and are taken to the world frame in pass 2, where the parent's world pose is at hand -
+    // pass 3 (per joint: body -> parent -> pose, three dependent LDS round trips, and another quaternion-to-matrix) is skipped.
+    const bool fuse3 = m.max_jntnum() <= 1;
+    f3 anc_l = mk3(0, 0, 0), ax_l = mk3(0, 0, 1);
+    int jd0 = 0;
     if (b > 0 && b < m.nb()) {
       const int br = m.c_body() + b * BODY_S;
       f3 pos = mk3(CF(br + 7), CF(br + 8), CF(br + 9));
@@ -1370,13 +1376,17 @@ struct Env {
             pos = pos + axis * (lds[qa] - CF(jr + 10));
           }
         }
-        jnt(0, jd) = anchor.x; jnt(1, jd) = anchor.y; jnt(2, jd) = anchor.z;
-        jnt(3, jd) = axis.x; jnt(4, jd) = axis.y; jnt(5, jd) = axis.z;
+        anc_l = anchor; ax_l = axis; jd0 = jd;
+        if (!fuse3 || b_level < 2) {  // final for bodies hanging off the world; local values for pass 3 otherwise
+          jnt(0, jd) = anchor.x; jnt(1, jd) = anchor.y; jnt(2, jd) = anchor.z;
+          jnt(3, jd) = axis.x; jnt(4, jd) = axis.y; jnt(5, jd) = axis.z;
+        }
       }
       body(0, b) = pos.x; body(1, b) = pos.y; body(2, b) = pos.z;
       body(3, b) = quat.w; body(4, b) = quat.x; body(5, b) = quat.y; body(6, b) = quat.z;
     }
     WSYNC();
+    const bool jfuse = fuse3 && b > 0 && b < m.nb() && b_level >= 2 && b_jntnum == 1;
     if (m.nlevel() > AMX_CHAIN_WALK_MIN_LEVELS && !m.deep_free() && !AMX_LEVEL_SCANS) {  // shallow trees: the level scan is as fast (quadruped, 5 levels: measured)
       // every body walks its own ancestor chain (root first, constants c_anc) and composes the local poses in registers: the
       // same products in the same order as the level-by-level scan, but the loads are independent and nothing waits for a
@@ -1395,26 +1405,39 @@ struct Env {
         ap = ap + qrot(aq, ld_xpos(a));
         aq = qmul(aq, ld_xquat(a));
       }
-      const f3 pos = ap + qrot(aq, lp);
+      const m33 Rp = q2m(aq);  // (ap, aq) is the parent's world pose
+      const f3 pos = ap + mulv(Rp, lp);
       const f4 quat = qmul(aq, lq);
+      const f3 anchor = ap + mulv(Rp, anc_l), axis = mulv(Rp, ax_l);
       WSYNC();
       if (deep) {
         body(0, b) = pos.x; body(1, b) = pos.y; body(2, b) = pos.z;
         body(3, b) = quat.w; body(4, b) = quat.x; body(5, b) = quat.y; body(6, b) = quat.z;
+      }
+      if (jfuse) {
+        jnt(0, jd0) = anchor.x; jnt(1, jd0) = anchor.y; jnt(2, jd0) = anchor.z;
+        jnt(3, jd0) = axis.x; jnt(4, jd0) = axis.y; jnt(5, jd0) = axis.z;
       }
       WSYNC();
     } else
     for (int L = 2; L < m.nlevel(); ++L) {
       if (b_level == L) {
         const f4 pq = ld_xquat(b_parent);
-        const f3 pos = ld_xpos(b_parent) + qrot(pq, ld_xpos(b));
+        const f3 pp = ld_xpos(b_parent);
+        const m33 Rp = q2m(pq);
+        const f3 pos = pp + mulv(Rp, ld_xpos(b));
         const f4 quat = qmul(pq, ld_xquat(b));
         body(0, b) = pos.x; body(1, b) = pos.y; body(2, b) = pos.z;
         body(3, b) = quat.w; body(4, b) = quat.x; body(5, b) = quat.y; body(6, b) = quat.z;
+        if (jfuse) {
+          const f3 anchor = pp + mulv(Rp, anc_l), axis = mulv(Rp, ax_l);
+          jnt(0, jd0) = anchor.x; jnt(1, jd0) = anchor.y; jnt(2, jd0) = anchor.z;
+          jnt(3, jd0) = axis.x; jnt(4, jd0) = axis.y; jnt(5, jd0) = axis.z;
+        }
       }
       WSYNC();
     }
-    if (gl < m.njnt()) {
+    if (!fuse3 && gl < m.njnt()) {
       const int jr = m.c_jnt() + gl * JNT_S, jd = CI(jr + 2);
       const int p = CI(m.c_body() + CI(jr + 3) * BODY_S);  // parent of the joint's body
       if (p > 0) {  // the world's frame is the identity

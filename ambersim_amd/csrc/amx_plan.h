@@ -176,6 +176,8 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
   if (force_level) m.subtree_contig = 0;
   m.sub_iter = 1;
   for (int b = 1; b < nb; b++) if (d->body_parentid[b] > 0) m.sub_iter = std::max(m.sub_iter, sub_last[b] - b + 1);
+  m.max_jntnum = 0;
+  for (int b = 0; b < nb; b++) m.max_jntnum = std::max(m.max_jntnum, d->body_jntnum[b]);
   // bodies
   m.c_body = im.reserve(nb * BODY_S);
   for (int b = 0; b < nb; b++) {
