@@ -5,8 +5,8 @@ One "step" = one amx_rollout launch over one batch: NENV envs x HORIZON physics 
 
   N = 1   headline = BASELINE.md C2 (build-authored quadruped, 4096 envs, random ctrl, 1000-step rollout); the same JSON
           line carries `secondary`: C3 (the ~30-DoF biped, 4096 x 1000, north_star's target config) with its own roofline,
-          C4 (1024 x 64 forward-difference gradient through amx_fd_grad) and the FP32 figure (flop census of the CPU
-          oracle / 157.3 TFLOP/s, VALU-busy from the committed PMC pass); `cpu_baseline`; the MJX-CPU probe.
+          C4 (1024 x 64 forward-difference gradient through amx_fd_grad) and the FP32 figure (recorded flop census,
+          profiles/rNN_flop_census.json, / 157.3 TFLOP/s; VALU-busy from the committed PMC pass); `cpu_baseline`; the MJX-CPU probe.
   N > 1   C5: every rank runs its own 4096 envs of the biped (weak scaling, no collective in the data path) and the
           returned trajectories are all-gathered over RCCL once per step, overlapped with the next rollout; the line
           carries `scaling_report` (rollout alone, gather alone, with / without overlap).
@@ -159,24 +159,19 @@ def probe_mjx_cpu():
     return "available (not timed here)" if not missing else "unavailable on this box (" + "; ".join(missing) + ") - cpu_baseline is the build's own CPU restatement"
 
 
-def flop_census(mj, x0_np, us_np, nsteps=40):
-    """Arithmetic operations per env-step of the restated algorithm (oracle flop census, fp64 counting build), averaged
-    over `nsteps` steps of the first envs of the workload."""
-    import numpy as np
-    from oracle.oracle import Oracle
-    oc = Oracle(mj, variant="count")
-    tot, n = 0.0, 0
-    for e in range(min(4, x0_np.shape[0])):
-        oc.set_state(x0_np[e, :mj.nq], x0_np[e, mj.nq:], np.zeros(mj.nu), np.zeros(mj.nv))
-        oc.forward()
-        oc.lib.amxo_flops_read_and_reset.restype = __import__("ctypes").c_double
-        oc.lib.amxo_flops_read_and_reset()
-        for t in range(min(nsteps, us_np.shape[1])):
-            oc.set_state(None, None, us_np[e, t], None)
-            oc.step()
-        tot += oc.lib.amxo_flops_read_and_reset()
-        n += min(nsteps, us_np.shape[1])
-    return tot / n
+def flop_record(model_path):
+    """Recorded (NOT computed by this run) arithmetic operations per env-step of the restated algorithm for the shipped models:
+    profiles/rNN_flop_census.json, written by tools/flop_census.py from the counting build of the CPU restatement."""
+    import glob
+    import json
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_flop_census.json")))
+    if not cands:
+        return None
+    rec = json.load(open(cands[-1]))
+    tag = os.path.basename(model_path).split(".")[0]
+    if tag not in rec.get("flops_per_env_step", {}):
+        return None
+    return {"flops": float(rec["flops_per_env_step"][tag]), "file": os.path.relpath(cands[-1], ROOT), "how": rec.get("how", "")}
 
 
 def roofline(mj, nenv, horizon, kern_ms, model_path):
@@ -344,11 +339,14 @@ def secondary(args, model, mj, model_path, x0_np, us_np, kern_ms, dev):
     out = []
 
     def fp32(mj_, x0n, usn, steps_per_s, path):
-        fl = flop_census(mj_, x0n, usn)
+        fr = flop_record(path)
+        if fr is None:
+            return {"note": "no recorded flop census for this model (tools/flop_census.py)"}
+        fl = fr["flops"]
         rec = pmc_record(path, args.nenv, args.horizon)
         return {"algorithmic_flops_per_env_step": fl, "achieved_tflops": fl * steps_per_s / 1e12, "peak_tflops": FP32_PEAK_TFLOPS,
                 "frac": fl * steps_per_s / 1e12 / FP32_PEAK_TFLOPS,
-                "flops_source": "flop census of the CPU restatement (oracle/count_real.hpp: every +,-,*,/,sqrt,sin,cos on a REAL), dense algorithm",
+                "flops_source": f"RECORDED: {fr['file']} ({fr['how']})",
                 "valu_busy_frac": rec.get("valu_busy_frac") if rec else None,
                 "valu_busy_source": (f"RECORDED: {rec['file']}" if rec and "valu_busy_frac" in rec else None)}
 
