@@ -2068,7 +2068,8 @@ struct Env {
   // v stream in as ds_read_b128 (v: one address per group = broadcast); 2 * ldm/4 wide loads replace 2 * nv scalar ones.
   DEV float mul_M_row(int vf) const {
     const int nv = m.nv(), ldm = m.ldm(), i = gl < nv ? gl : 0, Vo = eb + m.e_H();
-    if (gl < ldm) lds[Vo + gl] = gl < nv ? dof(vf, gl) : 0.0f;
+    const float dv_ = dof(vf, gl < nv ? gl : 0);  // unconditional load, then selects
+    if (gl < ldm) lds[Vo + gl] = gl < nv ? dv_ : 0.0f;
     WSYNC();
     const float4 *mr = reinterpret_cast<const float4 *>(lds + eb + m.e_M() + i * ldm), *vv = reinterpret_cast<const float4 *>(lds + Vo);
     float acc0 = 0, acc1 = 0;
@@ -2095,12 +2096,13 @@ struct Env {
     return acc0 + acc1;
   }
   // J[row,:] . v over the row's static support, for the lane's two row slots
-  DEV float row_dot_A(int vf) const {
+  DEV float row_dot_A(int vf) const {  // unconditional loads (rd1 = 0 on lanes without a row), selects: no branch, no wait of its own
     const int vo = dofoff(vf);
-    if (gl >= nA()) return 0.0f;
-    float a = rJ1 * lds[vo + rd1 * DOF_E];
-    if (rd2 >= 0) a += rJ2 * lds[vo + rd2 * DOF_E];
-    return a;
+    const float v1 = lds[vo + rd1 * DOF_E], v2 = lds[vo + (rd2 >= 0 ? rd2 : 0) * DOF_E];
+    float a = rJ1 * v1;
+    const float a2 = __builtin_fmaf(rJ2, v2, a);
+    a = rd2 >= 0 ? a2 : a;
+    return gl < nA() ? a : 0.0f;
   }
   // sum over the contact row's dof list of J[t] * v[dof_t] (J at Jr, v at vo with stride vs).  Branch-free: every term of
   // the row's ldc slots is loaded (slots past the list hold stale floats of the slab, dof index 0) and a select keeps
@@ -2143,7 +2145,9 @@ struct Env {
   DEV float constraint_cost(int vf, float *gauss_out) const {
     const bool actA = gl < nA() && (aJaref < 0 || gl < m.neq()), actB = gl < nB() && cJaref < 0;
     float c = (actA ? 0.5f * aD * aJaref * aJaref : 0.0f) + (actB ? 0.5f * cD * cJaref * cJaref : 0.0f);
-    float g = gl < m.nv() ? (dof(D_MA, gl) - dof(D_FSMOOTH, gl)) * (dof(vf, gl) - dof(D_ASMOOTH, gl)) : 0.0f;
+    const int li = gl < m.nv() ? gl : 0;  // unconditional loads, then a select (a lazily evaluated ?: is a branch with its own wait)
+    const float gv = (dof(D_MA, li) - dof(D_FSMOOTH, li)) * (dof(vf, li) - dof(D_ASMOOTH, li));
+    float g = gl < m.nv() ? gv : 0.0f;
     c = gsum<G>(c);
     g = 0.5f * gsum<G>(g);
     *gauss_out = g;
@@ -2320,11 +2324,11 @@ struct Env {
     aJv = row_dot_A(D_SEARCH);
     cJv = row_dot_B(D_SEARCH);
     float sn = 0, g1 = 0, g2 = 0;
-    if (gl < nv) {
-      const float si = dof(D_SEARCH, gl);
-      sn = si * si;
-      g1 = si * dof(D_MA, gl) - si * dof(D_FSMOOTH, gl);
-      g2 = 0.5f * si * mv;
+    {  // unconditional loads, selects at the end
+      const int li = gl < nv ? gl : 0;
+      const float si = dof(D_SEARCH, li), ma_ = dof(D_MA, li), fs_ = dof(D_FSMOOTH, li);
+      const float sn_ = si * si, g1_ = si * ma_ - si * fs_, g2_ = 0.5f * si * mv;
+      sn = gl < nv ? sn_ : 0.0f; g1 = gl < nv ? g1_ : 0.0f; g2 = gl < nv ? g2_ : 0.0f;
     }
     sn = gsum<G>(sn); g1 = gsum<G>(g1); g2 = gsum<G>(g2);
     PROF(21);
@@ -2387,7 +2391,7 @@ struct Env {
       float gw, gs;
       init_context(D_WARM);
       const float cw = constraint_cost(D_WARM, &gw);
-      ma_warm = gl < nv ? dof(D_MA, gl) : 0.0f;
+      { const float t_ = dof(D_MA, gl < nv ? gl : 0); ma_warm = gl < nv ? t_ : 0.0f; }
       ja_warm = aJaref;
       jc_warm = cJaref;
       WSYNC();
@@ -2398,7 +2402,7 @@ struct Env {
       gauss = use_warm ? gw : gs;
     }
     if (gl < nv) {
-      dof(D_QACC, gl) = use_warm ? dof(D_WARM, gl) : dof(D_ASMOOTH, gl);
+      { const float w_ = dof(D_WARM, gl), s_ = dof(D_ASMOOTH, gl); dof(D_QACC, gl) = use_warm ? w_ : s_; }
       if (use_warm) dof(D_MA, gl) = ma_warm;  // context of the chosen start: M*qacc and J*qacc - aref
     }
     if (use_warm) { aJaref = ja_warm; cJaref = jc_warm; }
@@ -2419,7 +2423,8 @@ struct Env {
     bool alive = true;  // per group: still iterating
     for (int niter = 0; niter < m.iterations(); ++niter) {
       if (m.iterations() != 1) {
-        const float g = gl < nv ? dof(D_GRAD, gl) : 0.0f;
+        const float g_ = dof(D_GRAD, gl < nv ? gl : 0);
+        const float g = gl < nv ? g_ : 0.0f;
         const float gn = gsum<G>(g * g);
         bool done = (fdiv(prev_cost - cost, m.scale()) < m.tolerance());
         done = done || (fdiv(sqrtf(gn), m.scale()) < m.tolerance());
