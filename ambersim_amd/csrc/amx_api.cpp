@@ -55,6 +55,14 @@ struct amx_model {
   int ncon, nefc, lds_bytes;
 };
 
+// AMX_NO_GENERIC (per-model builds, ambersim_amd/_spec.py): the library holds only the kernels compiled for its one model - the
+// generic kernels are two thirds of the compile time and such a library is loaded for that model's handle alone.
+#ifndef AMX_NO_GENERIC
+#define AMX_NO_GENERIC 0
+#endif
+#if AMX_NO_GENERIC
+static hipError_t set_lds_limit(int, int) { return hipSuccess; }
+#else
 template <int G> static hipError_t set_lds_limit_g(int bytes) {
   hipError_t e;
   if ((e = hipFuncSetAttribute((const void *)amx_rollout_kernel<G, DynSpec>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return e;
@@ -64,6 +72,7 @@ template <int G> static hipError_t set_lds_limit_g(int bytes) {
 static hipError_t set_lds_limit(int G, int bytes) {
   return G == 16 ? set_lds_limit_g<16>(bytes) : (G == 32 ? set_lds_limit_g<32>(bytes) : set_lds_limit_g<64>(bytes));
 }
+#endif
 
 // Runs f(Spec{}) for the spec with index `spec`; false when there is none (generic kernels).
 template <class F> static bool for_spec(int spec, F &&f) {
@@ -106,6 +115,7 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
   Image im;
   if (int rc = plan_model(d, m, im)) return rc;
   const int spec = find_spec(m, d, im);
+  if (AMX_NO_GENERIC && spec < 0) return fail(AMX_EUNSUPPORTED, "this build of the library holds only the kernels of the model it was compiled for");
   const int lds_bytes = (m.nconst + m.wpb * (AMX_WAVE / m.G) * m.env_floats) * (int)sizeof(float);
   amx_model *h = new (std::nothrow) amx_model();
   if (!h) return fail(AMX_ENOMEM, "out of host memory");
@@ -193,12 +203,16 @@ static int pre_launch(const amx_model *m, int nenv, dim3 *grid, int *wpb, int *l
   return AMX_OK;
 }
 // one instantiation per group width; the model picks its own at creation
+#if AMX_NO_GENERIC
+#define AMX_LAUNCH_G(kernel, m, grid, stream, ...) return fail(AMX_EUNSUPPORTED, "this build of the library holds only the kernels of the model it was compiled for")
+#else
 #define AMX_LAUNCH_G(kernel, m, grid, stream, ...)                                                                       \
   do {                                                                                                                   \
     if ((m)->dev.G == 16) hipLaunchKernelGGL((kernel<16, DynSpec>), grid, dim3(AMX_WAVE * wpb), lds_bytes, (hipStream_t)stream, __VA_ARGS__);      \
     else if ((m)->dev.G == 32) hipLaunchKernelGGL((kernel<32, DynSpec>), grid, dim3(AMX_WAVE * wpb), lds_bytes, (hipStream_t)stream, __VA_ARGS__); \
     else hipLaunchKernelGGL((kernel<64, DynSpec>), grid, dim3(AMX_WAVE * wpb), lds_bytes, (hipStream_t)stream, __VA_ARGS__);                       \
   } while (0)
+#endif
 
 extern "C" int amx_forward(const amx_model *m, int nenv, const float *qpos, const float *qvel, const float *ctrl,
                            const float *warm, const amx_forward_out *o, void *stream) {

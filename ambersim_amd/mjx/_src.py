@@ -148,7 +148,7 @@ class Data:
 
 def put_model(mj: MjModel, device=None, specialise: bool = False) -> Model:
     """Host model -> device model.  `specialise=True`: if the library holds no kernels compiled for this model's launch plan
-    (only the shipped models have them), compile csrc/ for it with hipcc - about a minute, cached by plan - and use that build:
+    (only the shipped models have them), compile csrc/ for it with hipcc - about ten seconds, cached by plan - and use that build:
     static loop bounds, immediate LDS offsets, tree-sparse eliminations, as for the shipped models."""
     if mj.opt.integrator != 0:
         raise NotImplementedError("only the Euler integrator is implemented")

@@ -187,7 +187,7 @@ def test_specialised_and_generic_kernels(cases, golden):
 def test_per_model_specialised_build_runs(cases, dev):
     """`mjx.put_model(mj, specialise=True)` on a model the library ships no kernels for (the quadruped with two solver
     iterations): a build of csrc/ compiled for exactly that launch plan is loaded (ambersim_amd/_spec.py; built by the CPU test
-    into csrc/jit/ or here, about half a minute), reports itself specialised, and agrees with the generic kernels and the fp64
+    into csrc/jit/ or here, about ten seconds), reports itself specialised, and agrees with the generic kernels and the fp64
     oracle; the C4 entry point works through it as well."""
     import time
     from test_abi import jit_test_model
