@@ -2,6 +2,7 @@ from __future__ import annotations
 
 import copy
 import ctypes as C
+import os
 import dataclasses
 from typing import Any, Optional
 
@@ -146,7 +147,7 @@ class Data:
         return self.qpos.dim() == 2
 
 
-def put_model(mj: MjModel, device=None, specialise: bool = False) -> Model:
+def put_model(mj: MjModel, device=None, specialise: Optional[bool] = None) -> Model:
     """Host model -> device model.  `specialise=True`: if the library holds no kernels compiled for this model's launch plan
     (only the shipped models have them), compile csrc/ for it with hipcc - about ten seconds, cached by plan - and use that build:
     static loop bounds, immediate LDS offsets, tree-sparse eliminations, as for the shipped models."""
@@ -157,6 +158,8 @@ def put_model(mj: MjModel, device=None, specialise: bool = False) -> Model:
             f"{mj.nunsupported_pairs} collision pairs are outside the implemented pair functions (condim != 3, a capsule "
             "against a box or mesh, or a convex hull beyond 32 vertices / 32 faces / 64 edges); disable contact "
             "(DisableBit.CONTACT), restrict contype/conaffinity or simplify the meshes")
+    if specialise is None:  # the default follows AMX_SPECIALISE (unset / 0: the library's own kernels)
+        specialise = os.environ.get("AMX_SPECIALISE", "0") not in ("", "0")
     return Model(mj, _dev(device), specialise=specialise)
 
 
