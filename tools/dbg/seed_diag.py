@@ -26,3 +26,10 @@ for e in range(8):
         a = o64.get(name); b = o32.get(name)
         line.append(f"{k} gpu {np.abs(f[k] - a).max():.1e}/cpu32 {np.abs(b - a).max():.1e} (scale {np.abs(a).max():.1e})")
     print("  ".join(line))
+e = int(np.argmax([np.abs(xs[k, 1] - ref[k, 1]).max() for k in range(8)]))
+d1, d32 = xs[e, 1] - ref[e, 1], r32[e, 1] - ref[e, 1]
+print("worst env", e, "component errors gpu (qpos | qvel):")
+print(np.array2string(d1[:mj.nq], precision=2), "|", np.array2string(d1[mj.nq:], precision=2))
+print("cpu32:")
+print(np.array2string(d32[:mj.nq], precision=2), "|", np.array2string(d32[mj.nq:], precision=2))
+print("ref qvel after step", np.array2string(ref[e, 1, mj.nq:], precision=3))
