@@ -214,3 +214,30 @@ def test_parity_per_horizon(dev):
         assert rows[1]["gpu_fp32_max"] <= 1e-5
         if not name.startswith("C3"):
             assert rows[10]["gpu_fp32_max"] <= 1e-5
+
+
+ON_BOX = """
+<mujoco><option timestep="0.002" iterations="50" ls_iterations="50" gravity="0 0 -9.81"/><worldbody>
+  <body name="table" pos="0 0 0"><geom type="box" size="0.5 0.4 0.3" mass="5"/></body>
+  <body name="top" pos="0.1 0.05 {z}"><freejoint/><geom {geom} mass="{mass}"/></body>
+</worldbody></mujoco>
+"""
+
+
+@pytest.mark.parametrize("geom,z,mass,fn,ncon", [('type="sphere" size="0.1"', 0.401, 0.5, 7, 1), ('type="box" size="0.15 0.1 0.05"', 0.3505, 0.8, 6, 4)])
+def test_resting_on_a_box_force_equals_weight(dev, geom, z, mass, fn, ncon):
+    """The two hull pair functions of round 2, on the GPU and without the oracle: a ball (sphere-convex) and a small box
+    (convex-convex) at rest on a fixed box - the constraint force on the free joint's vertical translation equals m g within
+    1 %, the body has stopped, the penetration is sub-millimetre."""
+    from ambersim_amd.mjcf import MjModel
+    mj = MjModel.from_xml_string(ON_BOX.format(geom=geom, z=z, mass=mass))
+    assert mj.pair_fn.tolist() == [fn]
+    g = Gpu(mj, dev)
+    assert g.model.ncon == ncon
+    x0 = np.concatenate([mj.qpos0, np.zeros(6)])
+    xs = g.rollout(x0, np.zeros((1, 1500, 0)))[0]
+    assert np.isfinite(xs).all() and np.abs(xs[-1, mj.nq:]).max() < 5e-3
+    fz = np.mean([g.forward(xs[t, :7], xs[t, 7:])["qfrc_constraint"][2] for t in (-2, -1)])
+    assert abs(fz - mass * G) / (mass * G) < 1e-2, (fz, mass * G)
+    dist = g.forward(xs[-1, :7], xs[-1, 7:])["dist"][:ncon]
+    assert (dist < 0).sum() >= min(ncon, 3) and (dist[dist < 0] > -1e-3).all()
