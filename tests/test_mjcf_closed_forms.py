@@ -1,0 +1,84 @@
+"""Host compiler (ambersim_amd/mjcf.py) against hand-computed values of MuJoCo's documented semantics - quantities the kernel and the
+oracle both take from the same descriptor, so an error here would be common-mode and invisible to every GPU-vs-oracle test
+("what's weak").  Nothing below is produced by code of this repository: the expected numbers are worked out in the
+docstrings."""
+import numpy as np
+import pytest
+
+from ambersim_amd.mjcf import MjModel
+
+
+def test_free_box_inertia_invweight_and_meaninertia():
+    """Free box, mass 2, half sizes (0.1, 0.2, 0.3): I = m/3 (b^2+c^2, a^2+c^2, a^2+b^2) = (0.0866667, 0.0666667, 0.0333333).
+    M = diag(m, m, m, I) at qpos0, so dof_invweight0 = (1/m x3, mean(1/I) x3) - MuJoCo averages the three translations and the
+    three rotations of a free joint - with mean(1/I) = (11.538462 + 15 + 30) / 3 = 18.846154; body_invweight0 = (1/m, mean(1/I));
+    stat.meaninertia = trace(M) / nv = (6 + 0.1866667) / 6 = 1.0311111."""
+    m = MjModel.from_xml_string('<mujoco><worldbody><body><freejoint/><geom type="box" size="0.1 0.2 0.3" mass="2"/></body></worldbody></mujoco>')
+    I = np.array([2 / 3 * (0.04 + 0.09), 2 / 3 * (0.01 + 0.09), 2 / 3 * (0.01 + 0.04)])
+    assert np.allclose(m.body_mass[1], 2) and np.allclose(np.sort(m.body_inertia[1]), np.sort(I), rtol=1e-12)
+    assert np.allclose(m.dof_invweight0[:3], 0.5, rtol=1e-12) and np.allclose(m.dof_invweight0[3:], np.mean(1 / I), rtol=1e-10)
+    assert np.allclose(m.body_invweight0[1], [0.5, np.mean(1 / I)], rtol=1e-10)
+    assert abs(m.stat.meaninertia - (6 + I.sum()) / 6) < 1e-12
+
+
+def test_geom_masses_from_density():
+    """Default density 1000: sphere r = 0.1 -> 4/3 pi r^3 rho = 4.1887902; capsule r = 0.05, half length 0.2 -> (pi r^2 2h + 4/3 pi
+    r^3) rho = 3.6651914; cylinder r = 0.05, half height 0.1 -> pi r^2 2h rho = 1.5707963; box 0.1^3 half sizes -> 8 rho / 1000 = 8."""
+    m = MjModel.from_xml_string('<mujoco><worldbody>'
+                                '<body><freejoint/><geom type="sphere" size="0.1"/></body>'
+                                '<body pos="1 0 0"><freejoint/><geom type="capsule" size="0.05 0.2"/></body>'
+                                '<body pos="2 0 0"><freejoint/><geom type="cylinder" size="0.05 0.1" contype="0" conaffinity="0"/></body>'
+                                '<body pos="3 0 0"><freejoint/><geom type="box" size="0.1 0.1 0.1"/></body></worldbody></mujoco>')
+    assert np.allclose(m.body_mass[1:], [4.18879020, 3.66519143, 1.57079633, 8.0], rtol=1e-8)
+    # sphere: I = 2/5 m r^2
+    assert np.allclose(m.body_inertia[1], 0.4 * 4.18879020 * 0.01, rtol=1e-8)
+
+
+PAIR = """<mujoco><worldbody>
+  <body pos="0 0 0.5"><freejoint/><geom name="a" type="sphere" size="0.1" friction="1.0 0.005 0.0001" solref="{ra}" solimp="0.9 0.95 0.001 0.5 2" solmix="{ma}" margin="0.01" gap="0.002" priority="{pa}"/></body>
+  <body pos="0 0 0.9"><freejoint/><geom name="b" type="sphere" size="0.1" friction="0.5 0.01 0.0002" solref="{rb}" solimp="0.8 0.99 0.002 0.5 2" solmix="{mb}" margin="0.03" gap="0.005" priority="{pb}"/></body>
+</worldbody></mujoco>"""
+
+
+def test_contact_parameter_mixing():
+    """mj_contactParam: equal priority - friction = elementwise max; solref, solimp = solmix-weighted average (weights 1 and 3 ->
+    0.25 a + 0.75 b); negative (direct) solref - elementwise min instead; margin, gap = max, and the contact is detected within
+    margin - gap.  Different priority - the higher-priority geom's friction, solref, solimp."""
+    m = MjModel.from_xml_string(PAIR.format(ra="0.02 1", rb="0.01 0.5", ma=1, mb=3, pa=0, pb=0))
+    assert m.npair == 1
+    assert np.allclose(m.pair_friction[0], [1.0, 0.01, 0.0002])
+    assert np.allclose(m.pair_solref[0], [0.25 * 0.02 + 0.75 * 0.01, 0.25 * 1 + 0.75 * 0.5])
+    assert np.allclose(m.pair_solimp[0], 0.25 * np.array([0.9, 0.95, 0.001, 0.5, 2]) + 0.75 * np.array([0.8, 0.99, 0.002, 0.5, 2]))
+    assert np.allclose(m.pair_margin[0], 0.03 - 0.005)
+    m = MjModel.from_xml_string(PAIR.format(ra="-100 -5", rb="-300 -2", ma=1, mb=1, pa=0, pb=0))
+    assert np.allclose(m.pair_solref[0], [-300, -5])
+    m = MjModel.from_xml_string(PAIR.format(ra="0.02 1", rb="0.01 0.5", ma=1, mb=3, pa=2, pb=1))
+    assert np.allclose(m.pair_friction[0], [1.0, 0.005, 0.0001]) and np.allclose(m.pair_solref[0], [0.02, 1])
+    assert np.allclose(m.pair_solimp[0], [0.9, 0.95, 0.001, 0.5, 2])
+
+
+def test_static_pair_filter():
+    """Candidate pairs: geoms of one body never collide; parent and child bodies do not (default filterparent), but a child of
+    the world does collide with world geoms; the bit test is (contype_a & conaffinity_b) || (contype_b & conaffinity_a);
+    two planes never pair."""
+    xml = """<mujoco><worldbody>
+      <geom name="floor" type="plane" size="1 1 0.1"/>
+      <geom name="wall" type="plane" size="1 1 0.1" pos="1 0 0" euler="0 90 0"/>
+      <body name="A" pos="0 0 0.5"><freejoint/>
+        <geom name="a1" type="sphere" size="0.1"/><geom name="a2" type="sphere" size="0.1" pos="0.3 0 0"/>
+        <body name="B" pos="0 0 0.3"><joint type="hinge" axis="0 1 0"/><geom name="b1" type="sphere" size="0.1"/>
+          <body name="C" pos="0 0 0.3"><joint type="hinge" axis="0 1 0"/><geom name="c1" type="sphere" size="0.1" contype="2" conaffinity="4"/></body>
+        </body>
+      </body>
+      <body name="D" pos="1 1 0.5"><freejoint/><geom name="d1" type="sphere" size="0.1" contype="4" conaffinity="0"/></body>
+    </worldbody></mujoco>"""
+    m = MjModel.from_xml_string(xml)
+    from ambersim_amd.utils.introspection_utils import get_geom_names
+    names = get_geom_names(m)
+    got = {frozenset((names[a], names[b])) for a, b in zip(m.pair_geom1, m.pair_geom2)}
+    want = {frozenset(p) for p in (("floor", "a1"), ("floor", "a2"), ("floor", "b1"), ("wall", "a1"), ("wall", "a2"), ("wall", "b1"),
+                                   ("c1", "d1"))}
+    # a1/a2 (same body), a*/b1 and b1/c1 (parent - child) are filtered; c1 (contype 2, conaffinity 4) meets d1 (contype 4) through
+    # contype_d & conaffinity_c; c1 does not meet the default geoms (1 & 4 = 0, 2 & 1 = 0), nor the planes; d1 (conaffinity 0,
+    # contype 4) meets nothing with conaffinity 1; floor / wall do not pair
+    assert got == want, (sorted(map(sorted, got)), sorted(map(sorted, want)))
