@@ -82,3 +82,88 @@ def test_static_pair_filter():
     # contype_d & conaffinity_c; c1 does not meet the default geoms (1 & 4 = 0, 2 & 1 = 0), nor the planes; d1 (conaffinity 0,
     # contype 4) meets nothing with conaffinity 1; floor / wall do not pair
     assert got == want, (sorted(map(sorted, got)), sorted(map(sorted, want)))
+
+
+LIMIT_HINGE = """<mujoco><compiler angle="radian"/><option gravity="0 0 0" timestep="0.002" iterations="20" ls_iterations="20"/><worldbody>
+  <body><joint name="j" type="hinge" axis="0 1 0" limited="true" range="-0.5 0.5"/>
+    <geom type="capsule" fromto="0 0 0 0 0 -0.4" size="0.03" mass="1.3"/></body>
+</worldbody></mujoco>"""
+
+# One hinge beyond its upper limit, no gravity, default solref (0.02, 1) and solimp (0.9, 0.95, 0.001, 0.5, 2).  The limit row has
+# J = -1, pos = 0.5 - q, diagApprox = dof_invweight0 = 1/M, so R = (1 - imp)/imp / M, D = imp/(1 - imp) M, and minimising
+# 1/2 M a^2 + 1/2 D (J a - aref)^2 gives a = -imp * aref whatever M is, with aref = -b (J v) - k imp pos, k = 1/(dmax^2 tc^2 dr^2)
+# = 1/(0.9025 * 0.0004) = 2770.0831, b = 2/(dmax tc) = 105.26316.
+#   q = 0.6,    v = 0: pos = -0.1 is past the 1 mm width, imp = dmax = 0.95, aref = 2770.0831 * 0.95 * 0.1 = 263.15789, qacc = -250
+#   q = 0.6,    v = 1: aref = 105.26316 + 263.15789 = 368.42105, qacc = -350
+#   q = 0.5 + 2^-11 (exact in fp32), v = 0: x = |pos|/width = 0.48828125 < midpoint, y = 2 x^2 = 0.47683716, imp = 0.9 + 0.05 y
+#                      = 0.92384186, aref = 2770.0831 * 0.92384186 * 0.00048828125 = 1.2495697, qacc = -imp * aref = -1.1544048
+LIMIT_CASES = [(0.6, 0.0, -250.0), (0.6, 1.0, -350.0), (0.5 + 2.0 ** -11, 0.0, -1.1544048)]
+
+
+def test_limit_row_closed_form_oracle():
+    """The CPU restatement's impedance, reference acceleration, regulariser and solve on the one-row case worked out above."""
+    from oracle.oracle import Oracle
+    mj = MjModel.from_xml_string(LIMIT_HINGE)
+    o = Oracle(mj, np.float64)
+    for q, v, want in LIMIT_CASES:
+        o.set_state(np.array([q]), np.array([v]), np.zeros(0)); o.forward()
+        assert abs(o.get("qacc")[0] - want) < 2e-6 * abs(want), (q, v, o.get("qacc")[0], want)
+
+
+@pytest.mark.gpu
+def test_limit_row_closed_form_gpu():
+    """The same three numbers from the HIP path (amx_forward): not through the oracle."""
+    import torch
+    from test_gpu_kat import Gpu
+    mj = MjModel.from_xml_string(LIMIT_HINGE)
+    g = Gpu(mj, torch.device("cuda", 0))
+    for q, v, want in LIMIT_CASES:
+        f = g.forward(np.array([q]), np.array([v]))
+        assert abs(f["qacc"][0] - want) < 2e-5 * abs(want), (q, v, f["qacc"][0], want)
+        assert f["nefc"] == 1
+
+
+BALL_ON_PLANE = """<mujoco><option timestep="0.002" iterations="30" ls_iterations="30"/><worldbody>
+  <geom type="plane" size="2 2 0.1" friction="1 0.005 0.0001"/>
+  <body pos="0 0 0.1"><freejoint/><geom type="sphere" size="0.1" mass="0.7" friction="1 0.005 0.0001"/></body>
+</worldbody></mujoco>"""
+
+# A ball pressed 2^-10 m into the plane, friction 1, pyramidal cone (4 rows J_n +- mu J_t), impratio 1.  Each row's regulariser uses
+# invweight = (tw + mu^2 tw) 2 mu^2 / impratio with tw = body_invweight0 (translation) of the ball + of the world = 1/m + 0, i.e.
+# 4/m: D = imp/(1 - imp) m/4 per row.  With no tangential motion the four rows all read J a = a_z and share aref, the tangential
+# forces cancel, and minimising 1/2 m (a_z + g)^2 + 4 * 1/2 D (a_z - aref)^2 gives a_z = (1 - imp)(-g) + imp aref:
+#   pos = -2^-10: x = 0.9765625 > midpoint, y = 1 - 2 (1 - x)^2 = 0.99890137, imp = 0.9 + 0.05 y = 0.94994507,
+#   v_z = 0:     aref = k imp |pos| = 2770.0831 * 0.94994507 * 0.0009765625 = 2.5697527,           a_z = 1.9500850
+#   v_z = -0.25: aref = 2.5697527 + b * 0.25 = 2.5697527 + 26.3157895 = 28.8855422,                a_z = 26.9486395
+BALL_CASES = [(0.0, 1.9500850), (-0.25, 26.9486395)]
+
+
+def _ball_state(vz):
+    q = np.array([0, 0, 0.1 - 2.0 ** -10, 1, 0, 0, 0.0]); v = np.zeros(6); v[2] = vz
+    return q, v
+
+
+def test_contact_row_closed_form_oracle():
+    """The CPU restatement on the pyramid case above: vertical acceleration as computed by hand, nothing else moves."""
+    from oracle.oracle import Oracle
+    mj = MjModel.from_xml_string(BALL_ON_PLANE)
+    o = Oracle(mj, np.float64)
+    for vz, want in BALL_CASES:
+        q, v = _ball_state(vz)
+        o.set_state(q, v, np.zeros(0)); o.forward()
+        a = o.get("qacc")
+        assert abs(a[2] - want) < 5e-6 * abs(want) and np.abs(np.delete(a, 2)).max() < 1e-6, (vz, a, want)
+
+
+@pytest.mark.gpu
+def test_contact_row_closed_form_gpu():
+    """The same two numbers from the HIP path."""
+    import torch
+    from test_gpu_kat import Gpu
+    mj = MjModel.from_xml_string(BALL_ON_PLANE)
+    g = Gpu(mj, torch.device("cuda", 0))
+    for vz, want in BALL_CASES:
+        q, v = _ball_state(vz)
+        f = g.forward(q, v)
+        assert abs(f["qacc"][2] - want) < 5e-5 * abs(want) and np.abs(np.delete(f["qacc"], 2)).max() < 1e-3, (vz, f["qacc"], want)
+        assert f["nefc"] == 4
