@@ -167,3 +167,55 @@ def test_contact_row_closed_form_gpu():
         f = g.forward(q, v)
         assert abs(f["qacc"][2] - want) < 5e-5 * abs(want) and np.abs(np.delete(f["qacc"], 2)).max() < 1e-3, (vz, f["qacc"], want)
         assert f["nefc"] == 4
+
+
+SPRING_HINGE = """<mujoco><compiler angle="radian"/><option gravity="0 0 0" timestep="0.002"/><worldbody>
+  <body><inertial pos="0 0 0" mass="1" diaginertia="0.1 0.2 0.3"/>
+    <joint type="hinge" axis="0 1 0" armature="0.05" damping="0.4" stiffness="3" springref="0.1"/></body>
+</worldbody></mujoco>"""
+# M = I_yy + armature = 0.25.  At q = 0.3, v = 2: qfrc_passive = -0.4 * 2 - 3 (0.3 - 0.1) = -1.4, so forward gives qacc = -5.6.  The
+# Euler step is implicit in the joint damping: (M + dt d) a = -1.4, a = -1.4 / 0.2508 = -5.5821372, v' = 2 + 0.002 a = 1.9888357,
+# q' = 0.3 + 0.002 v' = 0.3039777.
+
+EQUALITY = """<mujoco><compiler angle="radian"/><option gravity="0 0 0" timestep="0.002" iterations="20" ls_iterations="20"/><worldbody>
+  <body><inertial pos="0 0 0" mass="1" diaginertia="0.1 0.2 0.1"/><joint name="a" type="hinge" axis="0 1 0"/></body>
+  <body pos="1 0 0"><inertial pos="0 0 0" mass="1" diaginertia="0.1 0.3 0.1"/><joint name="b" type="hinge" axis="0 1 0"/></body>
+</worldbody><equality><joint joint1="a" joint2="b" polycoef="0.05 0.5 0 0 0"/></equality></mujoco>"""
+# q_a = 0.05 + 0.5 q_b is violated at (0.2, 0.1) by pos = 0.1 (beyond the impedance width: imp = 0.95).  J = (1, -0.5) on
+# M = diag(0.2, 0.3); aref = -k imp pos = -263.15789; J M^-1 J' = 5 + 0.25/0.3 = 5.8333333; the row's diagApprox is the SUM of the two
+# dofs' invweight0, 5 + 3.3333333, so R = (0.05/0.95) 8.3333333 = 0.43859649; lambda = aref / (5.8333333 + 0.43859649) = -41.958042;
+# qacc = M^-1 J' lambda = (-209.79021, 69.930070).
+
+
+def _spring_checks(fwd, step):
+    assert abs(fwd - (-5.6)) < 1e-5 * 5.6
+    assert abs(step[0] - 0.3039776715) < 2e-7 and abs(step[1] - 1.9888357257) < 2e-6
+
+
+def test_passive_forces_armature_and_implicit_damping_oracle():
+    from oracle.oracle import Oracle
+    mj = MjModel.from_xml_string(SPRING_HINGE)
+    o = Oracle(mj, np.float64)
+    o.set_state(np.array([0.3]), np.array([2.0]), np.zeros(0)); o.forward()
+    xs = o.rollout(np.array([0.3, 2.0]), np.zeros((1, 1, 0)))[0]
+    _spring_checks(o.get("qacc")[0], xs[1])
+
+
+def test_joint_equality_row_closed_form_oracle():
+    from oracle.oracle import Oracle
+    mj = MjModel.from_xml_string(EQUALITY)
+    o = Oracle(mj, np.float64)
+    o.set_state(np.array([0.2, 0.1]), np.zeros(2), np.zeros(0)); o.forward()
+    assert np.allclose(o.get("qacc"), [-209.79020979, 69.93006993], rtol=5e-6)
+
+
+@pytest.mark.gpu
+def test_passive_damping_and_equality_closed_forms_gpu():
+    """The two cases above from the HIP path."""
+    import torch
+    from test_gpu_kat import Gpu
+    dev = torch.device("cuda", 0)
+    g = Gpu(MjModel.from_xml_string(SPRING_HINGE), dev)
+    _spring_checks(g.forward(np.array([0.3]), np.array([2.0]))["qacc"][0], g.rollout(np.array([0.3, 2.0]), np.zeros((1, 1, 0)))[0][1])
+    g = Gpu(MjModel.from_xml_string(EQUALITY), dev)
+    assert np.allclose(g.forward(np.array([0.2, 0.1]), np.zeros(2))["qacc"], [-209.79020979, 69.93006993], rtol=5e-5)
