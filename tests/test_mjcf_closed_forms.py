@@ -219,3 +219,37 @@ def test_passive_damping_and_equality_closed_forms_gpu():
     _spring_checks(g.forward(np.array([0.3]), np.array([2.0]))["qacc"][0], g.rollout(np.array([0.3, 2.0]), np.zeros((1, 1, 0)))[0][1])
     g = Gpu(MjModel.from_xml_string(EQUALITY), dev)
     assert np.allclose(g.forward(np.array([0.2, 0.1]), np.zeros(2))["qacc"], [-209.79020979, 69.93006993], rtol=5e-5)
+
+
+DOUBLE_PENDULUM = """<mujoco><compiler angle="radian"/><option timestep="0.002"/><worldbody>
+  <body pos="0 0 1"><joint type="hinge" axis="0 1 0"/><inertial pos="0 0 -0.25" mass="1.2" diaginertia="0.03 0.03 0.03"/>
+    <body pos="0 0 -0.5"><joint type="hinge" axis="0 1 0"/><inertial pos="0 0 -0.2" mass="0.8" diaginertia="0.02 0.02 0.02"/></body>
+  </body>
+</worldbody></mujoco>"""
+# The textbook planar double pendulum (angles from the hanging position, second angle relative): m1 = 1.2, lc1 = 0.25, l1 = 0.5,
+# I1 = 0.03, m2 = 0.8, lc2 = 0.2, I2 = 0.02, g = 9.81, at theta = (0.3, 0.5), theta' = (1.1, -0.7):
+#   M11 = I1 + I2 + m1 lc1^2 + m2 (l1^2 + lc2^2 + 2 l1 lc2 cos t2) = 0.49741321, M12 = I2 + m2 (lc2^2 + l1 lc2 cos t2) = 0.12220660,
+#   M22 = I2 + m2 lc2^2 = 0.052;  h = m2 l1 lc2 sin t2: Coriolis c = (-h (2 w1 w2 + w2^2), h w1^2) = (0.04027175, 0.04640839);
+#   gravity G = ((m1 lc1 + m2 l1) g sin t1 + m2 lc2 g sin(t1 + t2), m2 lc2 g sin(t1 + t2)) = (3.15529938, 1.12596212);
+#   qfrc_bias = c + G = (3.19557112, 1.17237051).
+DP_M = np.array([[0.4974132099, 0.1222066050], [0.1222066050, 0.052]])
+DP_BIAS = np.array([3.1955711247, 1.1723705124])
+
+
+def test_double_pendulum_mass_matrix_and_bias_oracle():
+    """Composite-rigid-body mass matrix and recursive Newton-Euler bias of the CPU restatement against the textbook formulas."""
+    from oracle.oracle import Oracle
+    mj = MjModel.from_xml_string(DOUBLE_PENDULUM)
+    o = Oracle(mj, np.float64)
+    o.set_state(np.array([0.3, 0.5]), np.array([1.1, -0.7]), np.zeros(0)); o.forward()
+    assert np.allclose(o.get("qM", (2, 2)), DP_M, rtol=1e-9) and np.allclose(o.get("qfrc_bias"), DP_BIAS, rtol=1e-9)
+
+
+@pytest.mark.gpu
+def test_double_pendulum_mass_matrix_and_bias_gpu():
+    """The same from the HIP path (amx_forward's qM and qfrc_bias outputs), in fp32."""
+    import torch
+    from test_gpu_kat import Gpu
+    f = Gpu(MjModel.from_xml_string(DOUBLE_PENDULUM), torch.device("cuda", 0)).forward(np.array([0.3, 0.5]), np.array([1.1, -0.7]))
+    assert np.allclose(f["qM"], DP_M, rtol=2e-6) and np.allclose(f["qfrc_bias"], DP_BIAS, rtol=2e-6)
+    assert np.allclose(f["qacc"], -np.linalg.solve(DP_M, DP_BIAS), rtol=1e-5)  # free motion: M qacc = -bias
