@@ -32,6 +32,11 @@ def test_geom_masses_from_density():
     assert np.allclose(m.body_mass[1:], [4.18879020, 3.66519143, 1.57079633, 8.0], rtol=1e-8)
     # sphere: I = 2/5 m r^2
     assert np.allclose(m.body_inertia[1], 0.4 * 4.18879020 * 0.01, rtol=1e-8)
+    # capsule (cylinder m_c = 3.14159265 + two hemispheres m_s = 0.52359878): axial 1/2 m_c r^2 + 2/5 m_s r^2 = 0.00445059,
+    # transverse m_c (r^2/4 + h^2/3) + m_s (2/5 r^2 + h^2 + 3/4 h r) = 0.06924594
+    assert np.allclose(np.sort(m.body_inertia[2]), [0.00445058959, 0.06924593807, 0.06924593807], rtol=1e-8)
+    # cylinder: axial 1/2 m r^2 = 0.00196350, transverse m (3 r^2 + (2h)^2) / 12 = 0.00621774
+    assert np.allclose(np.sort(m.body_inertia[3]), [0.00196349541, 0.00621773546, 0.00621773546], rtol=1e-8)
 
 
 PAIR = """<mujoco><worldbody>
@@ -253,3 +258,37 @@ def test_double_pendulum_mass_matrix_and_bias_gpu():
     f = Gpu(MjModel.from_xml_string(DOUBLE_PENDULUM), torch.device("cuda", 0)).forward(np.array([0.3, 0.5]), np.array([1.1, -0.7]))
     assert np.allclose(f["qM"], DP_M, rtol=2e-6) and np.allclose(f["qfrc_bias"], DP_BIAS, rtol=2e-6)
     assert np.allclose(f["qacc"], -np.linalg.solve(DP_M, DP_BIAS), rtol=1e-5)  # free motion: M qacc = -bias
+
+
+FREE_BODY = """<mujoco><option gravity="0 0 0" timestep="0.002"/><worldbody>
+  <body><freejoint/><inertial pos="0 0 0" mass="2" diaginertia="0.1 0.2 0.3"/></body>
+</worldbody></mujoco>"""
+# Torque-free rigid body (Euler's equations; the free joint's angular velocity is in the body frame, the body frame is the principal
+# frame): w = (1, 2, 3), I w = (0.1, 0.4, 0.9), w x I w = (0.6, -0.6, 0.2), w' = -I^-1 (w x I w) = (-6, 3, -0.6666667); no linear
+# acceleration.  One semi-implicit Euler step from the identity orientation: w1 = w + dt w' = (0.988, 2.006, 2.9986667), the quaternion
+# turns by the angle dt |w1| about w1 / |w1|: q' = (cos(a/2), sin(a/2) w1 / |w1|) with a = 0.002 * 3.7406125 = 0.0074812250:
+# q' = (0.99999300, 0.00098800, 0.00200600, 0.00299866).
+FREE_QACC = np.array([0, 0, 0, -6.0, 3.0, -2.0 / 3.0])
+FREE_QUAT1 = np.array([0.9999930039173, 0.0009879976960, 0.0020059953220, 0.0029986596737])
+
+
+def test_free_body_euler_equations_oracle():
+    from oracle.oracle import Oracle
+    mj = MjModel.from_xml_string(FREE_BODY)
+    o = Oracle(mj, np.float64)
+    q, v = np.array([0, 0, 0, 1, 0, 0, 0.0]), np.array([0, 0, 0, 1, 2, 3.0])
+    o.set_state(q, v, np.zeros(0)); o.forward()
+    assert np.allclose(o.get("qacc"), FREE_QACC, atol=1e-9)
+    xs = o.rollout(np.concatenate([q, v]), np.zeros((1, 1, 0)))[0]
+    assert np.allclose(xs[1, 3:7], FREE_QUAT1, atol=2e-9) and np.allclose(xs[1, 10:], [0.988, 2.006, 3 - 0.002 * 2 / 3], atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_free_body_euler_equations_gpu():
+    import torch
+    from test_gpu_kat import Gpu
+    g = Gpu(MjModel.from_xml_string(FREE_BODY), torch.device("cuda", 0))
+    q, v = np.array([0, 0, 0, 1, 0, 0, 0.0]), np.array([0, 0, 0, 1, 2, 3.0])
+    assert np.allclose(g.forward(q, v)["qacc"], FREE_QACC, atol=2e-5)
+    xs = g.rollout(np.concatenate([q, v]), np.zeros((1, 1, 0)))[0]
+    assert np.allclose(xs[1, 3:7], FREE_QUAT1, atol=2e-7) and np.allclose(xs[1, 10:], [0.988, 2.006, 3 - 0.002 * 2 / 3], atol=2e-6)
