@@ -13,6 +13,9 @@
  * the reference call site that reaches it.  The oracle itself is pinned by closed-form
  * known-answer tests in tests/test_oracle_kat.py (pendulum closed form from
  * ambersim/models/pendulum/pendulum.xml:3-23, energy, momentum, free fall, resting contact).
+ * and, stage by stage, by hand-worked closed forms in tests/test_closed_forms.py (limit, contact-pyramid and joint-equality rows:
+ * impedance, reference acceleration, regulariser; spring / damping / armature and the implicit-damping step; textbook double
+ * pendulum for CRB and RNE; Euler's equations and the quaternion step of a free body) - numbers no code of this repository produced.
  *
  * Call sites restated:  mjx.forward / mjx.step  — ambersim/rl/base.py:85,93;
  *                       ambersim/trajopt/shooting.py:36,41.   shoot — trajopt/shooting.py:22-48.
