@@ -292,3 +292,43 @@ def test_free_body_euler_equations_gpu():
     assert np.allclose(g.forward(q, v)["qacc"], FREE_QACC, atol=2e-5)
     xs = g.rollout(np.concatenate([q, v]), np.zeros((1, 1, 0)))[0]
     assert np.allclose(xs[1, 3:7], FREE_QUAT1, atol=2e-7) and np.allclose(xs[1, 10:], [0.988, 2.006, 3 - 0.002 * 2 / 3], atol=2e-6)
+
+
+def _two_geoms(g1, p1, g2, p2, extra2=""):
+    return MjModel.from_xml_string(f'<mujoco><compiler angle="degree"/><worldbody><body pos="{p1}"><freejoint/><geom {g1}/></body>'
+                                   f'<body pos="{p2}" {extra2}><freejoint/><geom {g2}/></body></worldbody></mujoco>')
+
+
+# Primitive pair distances by elementary geometry (contact distance = centre / axis distance minus the radii):
+#   spheres r 0.1 and 0.2, centres 0.25 apart: 0.25 - 0.3 = -0.05
+#   sphere r 0.1 at the origin vs capsule r 0.05, half length 0.3 along x, centred at (0.1, 0.12, 0): nearest axis point (0, 0.12, 0):
+#     0.12 - 0.15 = -0.03
+#   capsule r 0.05 along z at the origin vs capsule r 0.04 along x centred at (0, 0.08, 0.1), half lengths 0.3: the axes' common
+#     perpendicular joins (0, 0, 0.1) and (0, 0.08, 0.1): 0.08 - 0.09 = -0.01
+#   sphere r 0.1 vs sphere r 0.1, 0.5 apart (separated): +0.3
+PRIM_CASES = [
+    (('type="sphere" size="0.1"', "0 0 1", 'type="sphere" size="0.2"', "0.25 0 1", ""), -0.05),
+    (('type="sphere" size="0.1"', "0 0 0", 'type="capsule" size="0.05 0.3"', "0.1 0.12 0", 'euler="0 90 0"'), -0.03),
+    (('type="capsule" size="0.05 0.3"', "0 0 0", 'type="capsule" size="0.04 0.3"', "0 0.08 0.1", 'euler="0 90 0"'), -0.01),
+    (('type="sphere" size="0.1"', "0 0 0", 'type="sphere" size="0.1"', "0.3 0.4 0", ""), 0.3),
+]
+
+
+def test_primitive_pair_distances_oracle():
+    from oracle.oracle import Oracle
+    for args, want in PRIM_CASES:
+        mj = _two_geoms(*args)
+        assert mj.npair == 1
+        o = Oracle(mj, np.float64)
+        o.set_state(mj.qpos0, np.zeros(mj.nv), np.zeros(0)); o.forward()
+        assert abs(o.get("con_dist")[0] - want) < 1e-12, (args, o.get("con_dist")[0], want)
+
+
+@pytest.mark.gpu
+def test_primitive_pair_distances_gpu():
+    import torch
+    from test_gpu_kat import Gpu
+    for args, want in PRIM_CASES:
+        mj = _two_geoms(*args)
+        d = Gpu(mj, torch.device("cuda", 0)).forward(mj.qpos0, np.zeros(mj.nv))["dist"][0]
+        assert abs(d - want) < 2e-7, (args, d, want)
