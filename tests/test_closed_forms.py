@@ -332,3 +332,36 @@ def test_primitive_pair_distances_gpu():
         mj = _two_geoms(*args)
         d = Gpu(mj, torch.device("cuda", 0)).forward(mj.qpos0, np.zeros(mj.nv))["dist"][0]
         assert abs(d - want) < 2e-7, (args, d, want)
+
+
+SLIDING_BOX = """<mujoco><option timestep="0.002" iterations="50" ls_iterations="50"/><worldbody>
+  <geom type="plane" size="5 5 0.1" friction="0.5 0.005 0.0001"/>
+  <body pos="0 0 0.05"><freejoint/><geom type="box" size="0.1 0.1 0.05" mass="1" friction="0.5 0.005 0.0001"/></body>
+</worldbody></mujoco>"""
+# Coulomb's law on the pyramid: a box sliding along a pyramid axis (first tangent = world x for a z normal) is held by the row n - mu t1,
+# whose force has tangential / normal = mu exactly; the rows n +- mu t2 add normal force only.  Over a window the impulses therefore
+# satisfy  -m dvx = ratio * m (g T + dvz)  with ratio <= mu = 0.5, and close to it while the box slides (it chatters on its corners, so
+# the instantaneous normal force is not m g - the impulse balance is what is exact).
+
+
+def _friction_impulse_ratio(rollout):
+    x0 = np.array([0, 0, 0.05, 1, 0, 0, 0, 2.5, 0, 0, 0, 0, 0.0])
+    xs = rollout(x0, 180)
+    assert xs[180, 7] > 0.5  # still sliding at the end of the window
+    return -(xs[180, 7] - xs[40, 7]) / (9.81 * 140 * 0.002 + (xs[180, 9] - xs[40, 9]))
+
+
+def test_sliding_friction_impulse_ratio_oracle():
+    from oracle.oracle import Oracle
+    o = Oracle(MjModel.from_xml_string(SLIDING_BOX), np.float64)
+    r = _friction_impulse_ratio(lambda x0, n: o.rollout(x0, np.zeros((1, n, 0)))[0])
+    assert 0.48 <= r <= 0.5 + 1e-4, r
+
+
+@pytest.mark.gpu
+def test_sliding_friction_impulse_ratio_gpu():
+    import torch
+    from test_gpu_kat import Gpu
+    g = Gpu(MjModel.from_xml_string(SLIDING_BOX), torch.device("cuda", 0))
+    r = _friction_impulse_ratio(lambda x0, n: g.rollout(x0, np.zeros((1, n, 0)))[0])
+    assert 0.48 <= r <= 0.5 + 1e-4, r
