@@ -365,3 +365,35 @@ def test_sliding_friction_impulse_ratio_gpu():
     g = Gpu(MjModel.from_xml_string(SLIDING_BOX), torch.device("cuda", 0))
     r = _friction_impulse_ratio(lambda x0, n: g.rollout(x0, np.zeros((1, n, 0)))[0])
     assert 0.48 <= r <= 0.5 + 1e-4, r
+
+SERVO = """<mujoco><compiler angle="radian"/><option gravity="0 0 0" timestep="0.002"/><worldbody>
+  <body><inertial pos="0 0 0" mass="1" diaginertia="0.1 0.25 0.1"/><joint name="j" type="hinge" axis="0 1 0"/></body>
+</worldbody><actuator>{act}</actuator></mujoco>"""
+# Actuation on one hinge with M = 0.25, q = 0.1, v = 0.4 (no gravity, no passive force):
+#   position kp = 20, ctrl 0.5:                         force = 20 (0.5 - 0.1) = 8            qacc = 32
+#   the same with ctrlrange +-0.3 (ctrl clamped to 0.3): force = 20 (0.3 - 0.1) = 4            qacc = 16
+#   velocity kv = 5, ctrl 1.0:                           force = 5 (1.0 - 0.4) = 3             qacc = 12
+#   motor gear 3, ctrl 0.7, forcerange +-1.5:            force = clamp(0.7) = 0.7, torque 2.1  qacc = 8.4
+#   motor gear 3, ctrl 2.0, forcerange +-1.5:            force clamped to 1.5, torque 4.5      qacc = 18
+SERVO_CASES = [('<position joint="j" kp="20"/>', 0.5, 32.0),
+               ('<position joint="j" kp="20" ctrllimited="true" ctrlrange="-0.3 0.3"/>', 0.5, 16.0),
+               ('<velocity joint="j" kv="5"/>', 1.0, 12.0),
+               ('<motor joint="j" gear="3" forcelimited="true" forcerange="-1.5 1.5"/>', 0.7, 8.4),
+               ('<motor joint="j" gear="3" forcelimited="true" forcerange="-1.5 1.5"/>', 2.0, 18.0)]
+
+
+def test_actuation_closed_forms_oracle():
+    from oracle.oracle import Oracle
+    for act, u, want in SERVO_CASES:
+        o = Oracle(MjModel.from_xml_string(SERVO.format(act=act)), np.float64)
+        o.set_state(np.array([0.1]), np.array([0.4]), np.array([u])); o.forward()
+        assert abs(o.get("qacc")[0] - want) < 1e-9, (act, o.get("qacc")[0], want)
+
+
+@pytest.mark.gpu
+def test_actuation_closed_forms_gpu():
+    import torch
+    from test_gpu_kat import Gpu
+    for act, u, want in SERVO_CASES:
+        f = Gpu(MjModel.from_xml_string(SERVO.format(act=act)), torch.device("cuda", 0)).forward(np.array([0.1]), np.array([0.4]), np.array([u]))
+        assert abs(f["qacc"][0] - want) < 1e-5 * want, (act, f["qacc"][0], want)
