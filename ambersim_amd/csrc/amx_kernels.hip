@@ -704,10 +704,14 @@ AMX_STATIC_SOLVE_ATTR void spd_solve_static(int A_off, int rhs_off, int x_off, i
 // GRADCOL (static, 32-lane groups, nv <= 31; see jtdj_rows_mfma COL31): the caller has not formed qfrc_constraint and the
 // gradient; they come out of the matrix cores' column 31 here - fcon = column + flim (the lane's limit-row force),
 // grad = Ma - qfrc_smooth - fcon - and are stored to fcon_off / rhs_off before the elimination uses grad as its right-hand side.
+// With GRADCOL the stopping test of the NEXT solver iteration can run here, before the elimination: imp_done is the group's
+// improvement test (already known to the caller), the gradient is in the registers.  When no group of the wave would iterate
+// again the elimination (two thirds of this routine) is skipped and the routine returns true; the caller stops iterating.
 template <class S, int N, int G, bool TREE, bool GRADCOL = false>
-AMX_STATIC_SOLVE_ATTR void newton_solve_fused(int M_off, int ld_, int n_, unsigned long long crows_, int row_base, int J_base, int ldc_, int slot_base_,
+AMX_STATIC_SOLVE_ATTR bool newton_solve_fused(int M_off, int ld_, int n_, unsigned long long crows_, int row_base, int J_base, int ldc_, int slot_base_,
                                                 int rhs_off, int x_off, float dlim, int gl, int gb4, int rot, int bt_off, float flim = 0.0f, int ma_off = 0,
-                                                int fs_off = 0, int fcon_off = 0, bool store_ok = true) {
+                                                int fs_off = 0, int fcon_off = 0, bool store_ok = true, bool early_out = false, bool imp_done = false,
+                                                float scale = 1.0f, float tol = 0.0f) {
   if constexpr (sym_elim_ok<S, G>() && G == 32) {
     // crossbar-free elimination (see sym_pivot): b reaches lane N as a row through the staging vector at bt_off
     constexpr int NS = S::nv, lds_ = S::ldm, nchs = lds_ / 4;
@@ -733,6 +737,15 @@ AMX_STATIC_SOLVE_ATTR void newton_solve_fused(int M_off, int ld_, int n_, unsign
       const float fcon = __uint_as_float(hi[3][3]) + flim;
       b = ma - fs - fcon;
       if (owner && store_ok) { lds[fcon_off + gl * DOF_E] = fcon; lds[rhs_off + gl * DOF_E] = b; }
+      if (early_out) {
+        const float gn = gsum<G>(owner ? b * b : 0.0f);
+        const bool done = imp_done || (fdiv(sqrtf(gn), scale) < tol);
+        if (!wave_any(store_ok && !done)) {  // store_ok is the group's `alive`
+          if (owner) lds[dg] = d0;
+          WSYNC();
+          return true;
+        }
+      }
     } else {
       jtdj_rows_mfma<G>(crows_u, row_base, J_base, S::ldc, S::c_slot, gl, lo, hi);
       b = lds[rhs_off + li * DOF_E];
@@ -765,7 +778,7 @@ AMX_STATIC_SOLVE_ATTR void newton_solve_fused(int M_off, int ld_, int n_, unsign
     else SymDense<S, G, 0, true>::run(a, gle, d);
     if (owner) lds[x_off + gl * DOF_E] = fdiv(a[NS], d);
     WSYNC();
-    return;
+    return false;
   }
   const int ld = S::is_static ? S::ldm : __builtin_amdgcn_readfirstlane(ld_), n = S::is_static ? S::nv : __builtin_amdgcn_readfirstlane(n_);
   const int ldc = S::is_static ? S::ldc : __builtin_amdgcn_readfirstlane(ldc_), slot_base = S::is_static ? S::c_slot : __builtin_amdgcn_readfirstlane(slot_base_);
@@ -800,6 +813,7 @@ AMX_STATIC_SOLVE_ATTR void newton_solve_fused(int M_off, int ld_, int n_, unsign
   for (int k = 0; k < N; ++k) d = (k == gl) ? a[k] : d;
   if (owner) lds[x_off + gl * DOF_E] = fdiv(b, d);
   WSYNC();
+  return false;
 }
 template <int G>
 __device__ __noinline__ void newton_fused_dyn(int nchol, int M_off, int ld, int n, unsigned long long crows, int row_base, int J_base, int ldc, int slot_base,
@@ -2224,7 +2238,9 @@ struct Env {
   // G >= 32: the contact rows' J'DJ comes from the matrix cores and lands in H together with M (build_H_mfma); equality and
   // limit rows, rarely active and one or two entries each, are added with LDS atomics only when one of them is active.
   // G = 16 (four environments per wave do not map onto the two MFMA blocks): copy of M + atomics for every row kind.
-  DEV void newton_direction(bool alive = true) {
+  // returns true when (specialised fused path) the stopping test of the next iteration, evaluated inside, stops every group of the
+  // wave: the direction was not computed and the caller must not iterate again
+  DEV bool newton_direction(bool alive = true, bool early_out = false, bool imp_done = false) {
     const int nv = m.nv(), Mo = eb + m.e_M(), Ho = eb + m.e_H(), Jo = eb + m.e_J(), ldc = m.ldc(), ldm = m.ldm();
     const int row0 = m.neq() + m.nlim();
     if constexpr (G >= 32) {
@@ -2236,15 +2252,17 @@ struct Env {
         float dlim = __int_as_float(__builtin_amdgcn_ds_bpermute(gb4 + 4 * (d_limrow < 0 ? 0 : d_limrow), __float_as_int(dsrc)));
         dlim = (gl < nv && d_limrow >= 0 && nA() > 0) ? dlim : 0.0f;
         PROF(19);
+        bool stop = false;
         if constexpr (grad_in_solve())
-          newton_solve_fused<S, S::nv, G, S::tree_H, true>(Mo, ldm, nv, rows, eb + m.e_row() + row0 * ROW_E, Jo, ldc, m.c_slot(), dofoff(D_GRAD), dofoff(D_MGRAD), dlim, gl, gb4, m_rot, eb + m.e_H(),
-                                                          pend_flim, dofoff(D_MA), dofoff(D_FSMOOTH), dofoff(D_FCON), alive);
+          stop = newton_solve_fused<S, S::nv, G, S::tree_H, true>(Mo, ldm, nv, rows, eb + m.e_row() + row0 * ROW_E, Jo, ldc, m.c_slot(), dofoff(D_GRAD), dofoff(D_MGRAD), dlim, gl, gb4, m_rot,
+                                                                 eb + m.e_H(), pend_flim, dofoff(D_MA), dofoff(D_FSMOOTH), dofoff(D_FCON), alive, early_out, imp_done, m.scale(),
+                                                                 m.tolerance());
         else if constexpr (S::is_static)
           newton_solve_fused<S, S::nv, G, S::tree_H>(Mo, ldm, nv, rows, eb + m.e_row() + row0 * ROW_E, Jo, ldc, m.c_slot(), dofoff(D_GRAD), dofoff(D_MGRAD), dlim, gl, gb4, m_rot, eb + m.e_H());
         else
           newton_fused_dyn<G>(m.nchol(), Mo, ldm, nv, rows, eb + m.e_row() + row0 * ROW_E, Jo, ldc, m.c_slot(), dofoff(D_GRAD), dofoff(D_MGRAD), dlim, gl, gb4, m_rot);
         PROF(14);
-        return;
+        return stop;
       }
     }
     bool scalar_rows = true;  // wave-uniform: some equality / limit row is active
@@ -2292,6 +2310,7 @@ struct Env {
     PROF(14);
     if constexpr (S::is_static) spd_solve_static<S, G, S::tree_H>(Ho, dofoff(D_GRAD), dofoff(D_MGRAD), gl, m_rot, -1);
     else spd_solve<G>(m.nchol(), Ho, ldm, nv, dofoff(D_GRAD), dofoff(D_MGRAD), gl, gb4, m_rot);
+    return false;
   }
 
   // One trial step length: the quadratic model of the cost along the search direction under the active set at alpha.
@@ -2421,7 +2440,9 @@ struct Env {
     WSYNC();
     PROF(11);
     bool alive = true;  // per group: still iterating
+    bool stop = false;  // wave-uniform: the stopping test evaluated inside newton_direction ended the solve
     for (int niter = 0; niter < m.iterations(); ++niter) {
+      if (stop) break;
       if (m.iterations() != 1) {
         const float g_ = dof(D_GRAD, gl < nv ? gl : 0);
         const float g = gl < nv ? g_ : 0.0f;
@@ -2450,7 +2471,10 @@ struct Env {
       if (m.solver() == 2) {
         // the search direction of an iteration that will not run is never read: skip its factorisation
         if (niter + 1 < m.iterations()) {
-          newton_direction(alive);
+          // the next iteration's stopping test needs this point's improvement (known) and gradient (formed inside the fused
+          // solve): evaluated there, it saves the elimination when the wave is finished
+          const bool imp_done = fdiv(prev_cost - cost, m.scale()) < m.tolerance();
+          stop = newton_direction(alive, m.iterations() != 1, imp_done);
           PROF(11);
           if (gl < nv) dof(D_SEARCH, gl) = -dof(D_MGRAD, gl);
         }
