@@ -16,13 +16,45 @@ from pathlib import Path
 _CSRC = Path(__file__).resolve().parent / "csrc"
 
 
+_PLAN_LIB = None
+
+
+def _plan_library():
+    """csrc/libamx_plan.so (host C++, no HIP), loaded once per process.  build() makes it; if it is missing (a source checkout
+    that has not been built) it is compiled here into the cache directory under the build lock - never `make` in the package
+    directory on every call: that fails on a read-only install and races between ranks."""
+    global _PLAN_LIB
+    if _PLAN_LIB is not None:
+        return _PLAN_LIB
+    path = _CSRC / "libamx_plan.so"
+    srcs = [_CSRC / f for f in ("amx_plan.cpp", "amx_plan.h", "amx_dev.h")] + [_CSRC.parent.parent / "include" / "amx.h"]
+    stale = (not path.exists()) or any(f.stat().st_mtime > path.stat().st_mtime for f in srcs)
+    if stale:
+        h = hashlib.sha256()
+        for f in srcs:
+            h.update(f.read_bytes())
+        path = cache_dir() / f"libamx_plan_{h.hexdigest()[:16]}.so"
+        if not path.exists():
+            with _build_lock():
+                if not path.exists():
+                    tmp = _unique_tmp(path)
+                    cxx = os.environ.get("CXX", "g++")
+                    r = subprocess.run([cxx, "-O1", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-function", "-o", str(tmp), str(_CSRC / "amx_plan.cpp")],
+                                       capture_output=True, text=True, cwd=str(_CSRC))
+                    if r.returncode != 0:
+                        raise RuntimeError(f"planner build failed:\n{r.stderr[-2000:]}")
+                    os.replace(tmp, path)
+    L = C.CDLL(str(path))
+    L.amx_model_plan_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.amx_plan_last_error.restype = C.c_char_p
+    _PLAN_LIB = L
+    return L
+
+
 def plan(mj) -> dict:
     """The launch plan of a host model as {name: text}, from the planner built alone (csrc/libamx_plan.so: host C++, no HIP)."""
     from ._desc import build_desc
-    subprocess.run(["make", "-s", "-C", str(_CSRC), "libamx_plan.so"], check=True)
-    L = C.CDLL(str(_CSRC / "libamx_plan.so"))
-    L.amx_model_plan_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
-    L.amx_plan_last_error.restype = C.c_char_p
+    L = _plan_library()
     d = build_desc(mj)
     buf = C.create_string_buffer(1 << 16)
     if L.amx_model_plan_describe(C.byref(d), buf, len(buf)) != 0:
@@ -63,28 +95,87 @@ def cache_dir() -> Path:
     return d
 
 
-def build_specialised_library(mj, verbose: bool = False) -> Path:
-    """Compiles csrc/ with a single specialisation record - this model's - and returns the library's path (cached by the hash of
-    the record and of the sources).  Needs hipcc (ROCm) on the machine; raises RuntimeError otherwise."""
+def _unique_tmp(out: Path) -> Path:
+    """A temporary name next to `out` that no other process uses: pid + random suffix (ranks of one job share the cache)."""
+    import uuid
+    return out.with_name(f"{out.name}.{os.getpid()}.{uuid.uuid4().hex[:8]}.tmp")
+
+
+class _build_lock:
+    """Exclusive advisory lock on <cache>/.build.lock: one compile per cache directory at a time.  A rank that finds the
+    library already there when it gets the lock does nothing (torchrun / bench.py --gpus N with AMX_SPECIALISE=1: every rank
+    asks for the same build at once)."""
+
+    def __enter__(self):
+        import fcntl
+        self.f = open(cache_dir() / ".build.lock", "w")
+        fcntl.flock(self.f, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+        fcntl.flock(self.f, fcntl.LOCK_UN)
+        self.f.close()
+        return False
+
+
+ARCH = os.environ.get("AMX_ARCH", "gfx950")
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
+         "-Wno-unused-function", "-Wno-unused-variable"]
+_HIPCC_ID = {}
+
+
+def _hipcc_id(hipcc: str) -> str:
+    """`hipcc --version`, cached: a compiler upgrade must not reuse the old compiler's libraries."""
+    if hipcc not in _HIPCC_ID:
+        try:
+            _HIPCC_ID[hipcc] = subprocess.run([hipcc, "--version"], capture_output=True, text=True, timeout=60).stdout
+        except Exception as e:
+            raise RuntimeError(f"{hipcc} is not runnable ({e}): a per-model build needs ROCm's hipcc on this machine")
+    return _HIPCC_ID[hipcc]
+
+
+def specialised_library_path(mj):
+    """(path, header text) of the per-model build of `mj`: keyed by the record, the sources, the compile flags, the
+    architecture and the compiler's version string."""
     header = render_header([("model", mj)], "// generated by ambersim_amd._spec.build_specialised_library for one model; do not edit.")
     srcs = [_CSRC / f for f in ("amx_api.cpp", "amx_kernels.hip", "amx_plan.h", "amx_dev.h")] + [_CSRC.parent.parent / "include" / "amx.h"]
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     h = hashlib.sha256(header.encode())
     for f in srcs:
         h.update(f.read_bytes())
-    tag = h.hexdigest()[:16]
-    out = cache_dir() / f"libamx_{tag}.so"
+    h.update(" ".join(FLAGS).encode())
+    h.update(_hipcc_id(hipcc).encode())
+    return cache_dir() / f"libamx_{h.hexdigest()[:16]}.so", header
+
+
+def build_specialised_library(mj, verbose: bool = False) -> Path:
+    """Compiles csrc/ with a single specialisation record - this model's - and returns the library's path (cached; see
+    specialised_library_path).  Safe when several processes ask for the same build at once: the compile runs under a file
+    lock, writes to a name of its own and is renamed into place; a process that finds the library there uses it.
+    Needs hipcc (ROCm) on the machine; raises RuntimeError otherwise."""
+    out, header = specialised_library_path(mj)
     if out.exists():
         return out
-    hdr = cache_dir() / f"amx_spec_{tag}.h"
-    hdr.write_text(header)
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
-           "-Wno-unused-function", "-Wno-unused-variable", f'-DAMX_SPECS_HEADER="{hdr}"', "-DAMX_NO_GENERIC=1", "-no-hip-rt", "-shared", "-o", str(out) + ".tmp", "-x", "hip",
-           str(_CSRC / "amx_api.cpp")]
-    r = subprocess.run(cmd, capture_output=True, text=True, cwd=str(_CSRC))
-    if r.returncode != 0:
-        raise RuntimeError(f"specialised build failed ({' '.join(cmd)}):\n{r.stderr[-2000:]}")
-    os.replace(str(out) + ".tmp", out)
+    with _build_lock():
+        if out.exists():  # another rank built it while this one waited
+            return out
+        tag = out.stem.split("_")[-1]
+        hdr = cache_dir() / f"amx_spec_{tag}.h"
+        tmp_h = _unique_tmp(hdr)
+        tmp_h.write_text(header)
+        os.replace(tmp_h, hdr)
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        tmp = _unique_tmp(out)
+        cmd = [hipcc] + FLAGS + [f'-DAMX_SPECS_HEADER="{hdr}"', "-DAMX_NO_GENERIC=1", "-no-hip-rt", "-shared", "-o", str(tmp), "-x", "hip", str(_CSRC / "amx_api.cpp")]
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=str(_CSRC))
+        if r.returncode != 0:
+            try:
+                tmp.unlink()
+            except OSError:
+                pass
+            raise RuntimeError(f"specialised build failed ({' '.join(cmd)}):\n{r.stderr[-2000:]}")
+        os.replace(tmp, out)
     if verbose:
         print(f"built {out}")
     return out

@@ -117,6 +117,10 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
   const int spec = find_spec(m, d, im);
   if (AMX_NO_GENERIC && spec < 0) return fail(AMX_EUNSUPPORTED, "this build of the library holds only the kernels of the model it was compiled for");
   const int lds_bytes = (m.nconst + m.wpb * (AMX_WAVE / m.G) * m.env_floats) * (int)sizeof(float);
+  // The dynamic-LDS limit is an attribute of the KERNEL, shared by every model handle of the process (the generic kernels
+  // serve any number of models): it is set to the device's 160 KiB, never to this model's own size - a smaller model created
+  // after a larger one must not lower the limit under the earlier handle.  (plan_model has checked that lds_bytes fits.)
+  const int lds_limit = 160 * 1024;
   amx_model *h = new (std::nothrow) amx_model();
   if (!h) return fail(AMX_ENOMEM, "out of host memory");
   h->ncu = 0;
@@ -126,8 +130,8 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
   DeviceGuard guard(device);
   if ((e = guard.ok() ? hipSuccess : hipErrorInvalidDevice) != hipSuccess || (e = hipMalloc((void **)&h->d_image, im.v.size() * sizeof(float))) != hipSuccess ||
       (e = hipMemcpy(h->d_image, im.v.data(), im.v.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess ||
-      (e = set_lds_limit(m.G, lds_bytes)) != hipSuccess ||
-      (for_spec(spec, [&](auto sp) { e = set_lds_limit_spec<decltype(sp)>(lds_bytes); }) && e != hipSuccess)) {
+      (e = set_lds_limit(m.G, lds_limit)) != hipSuccess ||
+      (for_spec(spec, [&](auto sp) { e = set_lds_limit_spec<decltype(sp)>(lds_limit); }) && e != hipSuccess)) {
     if (h->d_image) (void)hipFree(h->d_image);
     delete h;
     return fail(AMX_EHIP, "model upload failed: %s", hipGetErrorString(e));

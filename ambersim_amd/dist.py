@@ -62,15 +62,52 @@ def gather_trajectories(xs_local: torch.Tensor, nenv_total: int | None = None, e
     return torch.cat([out[r * nmax: r * nmax + sizes[r]] for r in range(world)], dim=0)
 
 
-def gather_trajectories_async(xs_local: torch.Tensor):
-    """Equal-block all-gather started asynchronously: returns (gathered tensor, work handle).  The collective is ordered
-    after the kernels already queued on the current stream (the rollout that produced `xs_local`) and runs on the
-    communication stream, so the next rollout overlaps with it; `work.wait()` orders the current stream after it.
+class PendingGather:
+    """An all-gather in flight.  Holds the gathered tensor, the work handle AND the rank's own block: the collective reads
+    `src` on the communication stream after the caller has moved on, so the block must stay allocated (and must not be
+    handed back to the caching allocator for reuse by the compute stream) until `wait()` - the caller may rebind its own
+    name for it right away (bench.py does, on the next rollout)."""
+    __slots__ = ("out", "work", "src")
+
+    def __init__(self, out, work, src):
+        self.out, self.work, self.src = out, work, src
+
+    def wait(self) -> torch.Tensor:
+        """Orders the current stream after the collective, releases the source block, returns the gathered tensor."""
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        self.src = None
+        return self.out
+
+    def __iter__(self):  # (out, work) unpacking, as the first version of this function returned
+        return iter((self.out, self))
+
+
+def gather_trajectories_async(xs_local: torch.Tensor) -> PendingGather:
+    """Equal-block all-gather started asynchronously.  The collective is ordered after the kernels already queued on the
+    current stream (the rollout that produced `xs_local`) and runs on the communication stream, so the next rollout
+    overlaps with it; `PendingGather.wait()` orders the current stream after it and returns the gathered tensor.
     Every rank must pass the same block shape (bench.py's weak-scaling layout)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return xs_local, None
+        return PendingGather(xs_local, None, None)
     world = dist.get_world_size()
     xs_local = xs_local.contiguous()
     out = torch.empty((world * xs_local.shape[0],) + tuple(xs_local.shape[1:]), dtype=xs_local.dtype, device=xs_local.device)
     work = dist.all_gather_into_tensor(out, xs_local, async_op=True)
-    return out, work
+    return PendingGather(out, work, xs_local)
+
+
+def backend_report() -> dict:
+    """What the communication backend says about itself (bench.py's scaling_report): backend name, world size as the process
+    group reports it, RCCL's version when the backend is nccl (= RCCL on ROCm)."""
+    rep = {"backend": None, "world_size_reported": 1}
+    if dist.is_available() and dist.is_initialized():
+        rep["backend"] = dist.get_backend()
+        rep["world_size_reported"] = dist.get_world_size()
+        if rep["backend"] == "nccl":
+            try:
+                rep["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as e:  # a report field must not take the run down
+                rep["rccl_version"] = f"unavailable ({type(e).__name__})"
+    return rep

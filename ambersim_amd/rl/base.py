@@ -63,8 +63,12 @@ class MjxEnv(ABC):
 
     def pipeline_init(self, qpos: torch.Tensor, qvel: torch.Tensor) -> mjx.Data:
         """device data <- (qpos, qvel, ctrl=0), then one forward (reference :81-86)."""
-        data = mjx.device_put(self.data, self.sys.device)
-        data = data.replace(qpos=qpos, qvel=qvel, ctrl=torch.zeros(self.sys.nu))  # unbatched leaves broadcast to qpos' batch
+        # the device image of the host MjData is made once per env (eleven small host-to-device copies otherwise, on every reset);
+        # Data is functional - replace() returns a new record - so sharing the template's untouched leaves is safe
+        if getattr(self, "_data_template", None) is None:
+            self._data_template = mjx.device_put(self.data, self.sys.device)
+            self._zero_ctrl = torch.zeros(self.sys.nu, dtype=torch.float32, device=self.sys.device)
+        data = self._data_template.replace(qpos=qpos, qvel=qvel, ctrl=self._zero_ctrl)  # unbatched leaves broadcast to qpos' batch
         data = mjx.forward(self.sys, data)
         return data
 

@@ -26,9 +26,33 @@ class FDGradResult:
 
 
 def fd_eps(m: mjx.Model, eps_rel: float = 1e-3) -> torch.Tensor:
-    """eps_i = eps_rel * (ctrlrange width of actuator i) (eps = 1e-3 * range)."""
-    lim = m.actuator_ctrlrange
-    return (eps_rel * (lim[:, 1] - lim[:, 0])).to(torch.float32).contiguous()
+    """eps_i = eps_rel * (ctrlrange width of actuator i) (eps = 1e-3 * range).  Validated on the HOST range
+    (no device round trip) and cached per model and eps_rel."""
+    cache = m.__dict__.setdefault("_fd_eps_cache", {})
+    if eps_rel not in cache:
+        import numpy as np
+        lim = np.asarray(m.mj_model.actuator_ctrlrange, dtype=np.float64).reshape(-1, 2)
+        if eps_rel <= 0 or bool((lim[:, 1] - lim[:, 0] <= 0).any()):
+            raise ValueError("fd_eps: every actuator needs a ctrlrange of positive width (or pass eps explicitly)")
+        eps = (eps_rel * (m.actuator_ctrlrange[:, 1] - m.actuator_ctrlrange[:, 0])).to(torch.float32).contiguous()
+        eps._amx_positive = True  # checked on the host above
+        cache[eps_rel] = eps
+    return cache[eps_rel]
+
+
+def _fd_buffers(m: mjx.Model, nsamples: int, N: int):
+    """Workspace and outputs of one (nsamples, N) launch shape, allocated once per model: the C4 loop calls this path hundreds of
+    times per second and an allocation + a workspace query per call sat inside its timed region."""
+    cache = m.__dict__.setdefault("_fd_buf_cache", {})
+    key = (nsamples, N)
+    if key not in cache:
+        L = m._h.L
+        need = C.c_size_t()
+        _lib.check(L.amx_fd_workspace_bytes(m._h.ptr, nsamples, N, C.byref(need)), L)
+        cache[key] = torch.empty(max(need.value, 4) // 4 + 1, dtype=torch.float32, device=m.device)
+        if len(cache) > 8:  # a handful of shapes at most: drop the oldest
+            cache.pop(next(iter(cache)))
+    return cache[key]
 
 
 def fd_grad_terminal_cost(m: mjx.Model, x0: torch.Tensor, us_nominal: torch.Tensor, Qf: torch.Tensor, xg: torch.Tensor,
@@ -47,13 +71,13 @@ def fd_grad_terminal_cost(m: mjx.Model, x0: torch.Tensor, us_nominal: torch.Tens
                          f"xg {tuple(xg.shape)}, eps {tuple(eps.shape)} do not match nx={nx}, nu={nu}")
     if nsamples < 2 or coord0 < 0:
         raise ValueError("fd_grad_terminal_cost: need nsamples >= 2 and coord0 >= 0")
-    if bool((eps <= 0).any()):
-        raise ValueError("fd_grad_terminal_cost: eps must be positive (actuators need a ctrlrange, or pass eps)")
+    if not getattr(eps, "_amx_positive", False):  # fd_eps() has validated its own result on the host; a caller's eps costs one sync, once
+        if bool((eps <= 0).any()):
+            raise ValueError("fd_grad_terminal_cost: eps must be positive (actuators need a ctrlrange, or pass eps)")
+        eps._amx_positive = True
     N = us_nominal.shape[0]
     L = m._h.L  # the library build the model lives in
-    need = C.c_size_t()
-    _lib.check(L.amx_fd_workspace_bytes(m._h.ptr, nsamples, N, C.byref(need)), L)
-    ws = torch.empty(max(need.value, 4) // 4 + 1, dtype=torch.float32, device=dev)
+    ws = _fd_buffers(m, nsamples, N)  # reused across calls; stream-ordered, so back-to-back launches on one stream are safe
     J = torch.empty(nsamples, dtype=torch.float32, device=dev)
     g = torch.empty(nsamples - 1, dtype=torch.float32, device=dev)
     xf = torch.empty((nsamples, nx), dtype=torch.float32, device=dev)

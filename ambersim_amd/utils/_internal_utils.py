@@ -14,13 +14,3 @@ def _check_filepath(filepath: Union[str, Path]) -> str:
         if not path.exists():
             raise ValueError("The model file doesn't exist at the specified path!")
     return str(path)
-
-
-def _rmtree(f: Path):
-    """Recursively deletes a directory (reference ambersim/utils/_internal_utils.py:22-33)."""
-    if f.is_file():
-        f.unlink()
-    else:
-        for child in f.iterdir():
-            _rmtree(child)
-        f.rmdir()

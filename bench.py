@@ -3,13 +3,16 @@
 
 One "step" = one amx_rollout launch over one batch: NENV envs x HORIZON physics steps, inputs resident in HBM.
 
-  N = 1   headline = BASELINE.md C2 (build-authored quadruped, 4096 envs, random ctrl, 1000-step rollout); the same JSON
-          line carries `secondary`: C3 (the ~30-DoF biped, 4096 x 1000, north_star's target config) with its own roofline,
-          C4 (1024 x 64 forward-difference gradient through amx_fd_grad) and the FP32 figure (recorded flop census,
+The workload is the SAME at every N: north_star's target, BASELINE.md C3 per GPU / C5 sharded - the build-authored ~30-DoF
+biped (models/biped/biped.xml), 4096 envs per GPU, random ctrl, 1000-step fused rollout.
+  N = 1   the JSON line also carries `secondary`: C2 (the quadruped, 4096 x 1000, with its own roofline and CPU baseline),
+          C4 (1024 x 64 forward-difference gradient through amx_fd_grad), the biped at other solver options (MuJoCo's defaults
+          100 / 50 with the tolerance exit; the reference pendulum's 5 / 10) so that the headline is not tied to the model
+          file's Newton 3 / 5, A8 (trajectory cost) and the FP32 figure (recorded flop census,
           profiles/rNN_flop_census.json, / 157.3 TFLOP/s; VALU-busy from the committed PMC pass); `cpu_baseline`; the MJX-CPU probe.
-  N > 1   C5: every rank runs its own 4096 envs of the biped (weak scaling, no collective in the data path) and the
-          returned trajectories are all-gathered over RCCL once per step, overlapped with the next rollout; the line
-          carries `scaling_report` (rollout alone, gather alone, with / without overlap).
+  N > 1   every rank runs its own 4096 envs (weak scaling, no collective in the data path) and the returned trajectories
+          are all-gathered over RCCL once per step, overlapped with the next rollout; the line carries `scaling_report`
+          (rollout alone, gather alone, with / without overlap, RCCL version, world size as the backend reports it).
 
 `python bench.py --gpus N` is self-contained: with WORLD_SIZE unset and N > 1 the parent - which has not imported torch
 or touched the GPU - starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process, relays
@@ -38,14 +41,14 @@ BIPED = "models/biped/biped.xml"
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--nenv", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--horizon", type=int, default=1000)
-    ap.add_argument("--model", default=None, help=f"default: {QUADRUPED} (C2) at N=1, {BIPED} (C5) at N>1")
+    ap.add_argument("--model", default=None, help=f"default: {BIPED} (C3 / C5) at every N")
     ap.add_argument("--gather", choices=["traj", "none"], default="traj", help="N>1: all-gather returned trajectories")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="N=1: skip the C3 / C4 / FP32 secondary measurements")
+    ap.add_argument("--no-secondary", action="store_true", help="N=1: skip the C2 / C4 / solver-option / FP32 secondary measurements")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: wait for each all-gather before the next rollout")
     ap.add_argument("--no-scaling-report", action="store_true", help="N>1: skip the extra rollout-only / gather-only timings")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: zero trajectories on the CPU, gloo collectives")
@@ -192,7 +195,7 @@ def worker(args):
     import numpy as np
     import torch
     import torch.distributed as dist
-    from ambersim_amd.dist import gather_trajectories, gather_trajectories_async, init_from_env
+    from ambersim_amd.dist import backend_report, gather_trajectories, gather_trajectories_async, init_from_env
     from ambersim_amd.utils.io_utils import load_mj_model_from_file
 
     rank, world, local = init_from_env("gloo" if args.dry_run else None)
@@ -206,7 +209,7 @@ def worker(args):
         dev = torch.device("cuda", local)
     sync = (lambda: None) if dry else torch.cuda.synchronize
 
-    model_path = args.model or (QUADRUPED if world == 1 else BIPED)
+    model_path = args.model or BIPED  # one workload at every N (north_star's target)
     mj = load_mj_model_from_file(model_path)
     nx = mj.nq + mj.nv
     if dry:
@@ -232,14 +235,13 @@ def worker(args):
             if events is not None:
                 events[k][1].record()
             if world > 1 and mode == "overlap":
-                pending.append(gather_trajectories_async(xs))
+                pending.append(gather_trajectories_async(xs))  # holds xs until waited for: the name is rebound by the next rollout
                 if len(pending) > 2:
-                    pending.pop(0)[1].wait()
+                    pending.pop(0).wait()
             elif world > 1 and mode == "serial":
                 xs = gather_trajectories(xs, equal_blocks=True)
-        for out, work in pending:
-            work.wait()
-            xs = out
+        for pg in pending:
+            xs = pg.wait()
         return xs
 
     def timed(nsteps, mode, with_events=False):
@@ -296,7 +298,8 @@ def worker(args):
         report = {"rollout_only_env_steps_per_s": es / t_roll, "with_gather_serial_env_steps_per_s": es / t_serial,
                   "with_gather_overlapped_env_steps_per_s": es / t_over, "gather_alone_ms": 1e3 * t_gather / k,
                   "gathered_GB_per_rank": gb, "gather_GBps_per_rank_received": gb * (world - 1) / world / (t_gather / k),
-                  "note": "single-GPU throughput of this workload = the C3 entry under `secondary` of the N=1 line"}
+                  "note": "single-GPU throughput of this workload = `value` of the N=1 line (same model, same envs per GPU)",
+                  **backend_report()}
 
     if rank == 0:
         env_steps = args.nenv * args.horizon * args.steps * world
@@ -329,8 +332,21 @@ def worker(args):
         dist.destroy_process_group()
 
 
+def solver_variant(mj, iterations, ls_iterations):
+    """The host model with other solver iteration caps (everything else, tolerances included, as loaded)."""
+    import copy
+    from ambersim_amd.mjcf import recompile_options
+    mv = copy.copy(mj)
+    mv.opt = mj.opt.replace(iterations=int(iterations), ls_iterations=int(ls_iterations))
+    return recompile_options(mv)
+
+
+SOLVER_VARIANTS = ((100, 50), (5, 10))  # MuJoCo's defaults; the reference pendulum's (models/pendulum/pendulum.xml:3)
+
+
 def secondary(args, model, mj, model_path, x0_np, us_np, kern_ms, dev):
-    """N = 1 extras: C3 (biped rollout, its own roofline + CPU baseline), C4 (FD gradient), the FP32 figure."""
+    """N = 1 extras: C2 (quadruped rollout, its own roofline + CPU baseline), the biped at other solver options, C4 (FD gradient),
+    A8 (trajectory cost), the FP32 figure."""
     import numpy as np
     import torch
     from ambersim_amd import mjx
@@ -378,34 +394,70 @@ def secondary(args, model, mj, model_path, x0_np, us_np, kern_ms, dev):
         out.append({"name": "A8 quadcost", "error": f"{type(e).__name__}: {e}"})
     out.append({"name": "fp32_valu", "workload": os.path.basename(model_path), **fp32(mj, x0_np, us_np, steps_per_s, model_path)})
 
-    if model_path != BIPED:
-        mjb = load_mj_model_from_file(BIPED)
-        mb = mjx.put_model(mjb, dev)
-        x0b, usb = make_inputs(mjb, args.nenv, args.horizon, 1, 2, dev)
-        mjx.rollout(mb, x0b, usb)
+    def timed_rollouts(mdl, x0_, us_, k):
+        mjx.rollout(mdl, x0_, us_)
         torch.cuda.synchronize()
-        k = 3
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(k)]
         t0 = time.perf_counter()
         for a, b in ev:
             a.record()
-            xs = mjx.rollout(mb, x0b, usb)
+            xs_ = mjx.rollout(mdl, x0_, us_)
             b.record()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        kms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-        x0bn, usbn = x0b.cpu().numpy(), usb.cpu().numpy()
-        entry = {"name": "C3", "metric": "env-steps/sec, 4096 envs x 1000-step rollout", "value": args.nenv * args.horizon * k / el, "unit": "env-steps/s",
-                 "steps": k, "ms_per_step": 1e3 * el / k,
-                 "config": {"workload": f"biped.xml (build-authored ~30-DoF biped, two 12-vertex convex-mesh feet on a plane; BASELINE.md C3, north_star's target), "
-                                        f"{args.nenv} envs x {args.horizon}-step fused rollout, random ctrl", "nq": mjb.nq, "nv": mjb.nv, "nu": mjb.nu,
-                            "outputs_finite": bool(torch.isfinite(xs).all().item())},
-                 "roofline": roofline(mjb, args.nenv, args.horizon, kms, BIPED),
-                 "fp32_valu": fp32(mjb, x0bn, usbn, args.nenv * args.horizon / (kms * 1e-3), BIPED)}
-        if not args.no_cpu_baseline:
-            entry["cpu_baseline"] = cpu_baseline(mjb, x0bn, usbn, target_s=6.0)
-        out.append(entry)
-        del xs, usb
+        return el, float(np.mean([a.elapsed_time(b) for a, b in ev])), bool(torch.isfinite(xs_).all().item())
+
+    if model_path != QUADRUPED:
+        # C2: the quadruped, 4096 x 1000 (BASELINE.json configs[1])
+        try:
+            mjq = load_mj_model_from_file(QUADRUPED)
+            mq = mjx.put_model(mjq, dev)
+            x0q, usq = make_inputs(mjq, args.nenv, args.horizon, 1, 2, dev)
+            k = 5
+            el, kms, fin = timed_rollouts(mq, x0q, usq, k)
+            x0qn, usqn = x0q.cpu().numpy(), usq.cpu().numpy()
+            entry = {"name": "C2", "metric": "env-steps/sec, 4096 envs x 1000-step rollout", "value": args.nenv * args.horizon * k / el, "unit": "env-steps/s",
+                     "steps": k, "ms_per_step": 1e3 * el / k,
+                     "config": {"workload": f"quadruped.xml (build-authored, BASELINE.md C2: free base + 12 hinges, sphere feet), {args.nenv} envs x {args.horizon}-step fused rollout, "
+                                            f"random ctrl, Newton {mjq.opt.iterations} it / {mjq.opt.ls_iterations} ls", "nq": mjq.nq, "nv": mjq.nv, "nu": mjq.nu, "outputs_finite": fin},
+                     "roofline": roofline(mjq, args.nenv, args.horizon, kms, QUADRUPED),
+                     "fp32_valu": fp32(mjq, x0qn, usqn, args.nenv * args.horizon / (kms * 1e-3), QUADRUPED)}
+            if not args.no_cpu_baseline:
+                entry["cpu_baseline"] = cpu_baseline(mjq, x0qn, usqn, target_s=6.0)
+            out.append(entry)
+            del usq, mq
+        except Exception as e:
+            out.append({"name": "C2", "error": f"{type(e).__name__}: {e}"})
+
+    if model_path == BIPED:
+        # the headline's cost is set by the model file's solver options (Newton 3 iterations / 5 line-search iterations).  The same
+        # workload at MuJoCo's defaults (100 / 50: the tolerance exit decides) and at the reference pendulum's 5 / 10
+        # (reference ambersim/models/pendulum/pendulum.xml:3).  Each variant runs its own per-model build of the kernels
+        # (mjx.put_model(specialise=True): prebuilt by __graft_entry__.build(), compiled here if absent).
+        x0_t, us_t = torch.tensor(x0_np, device=dev), torch.tensor(us_np, device=dev)
+        for it, ls in SOLVER_VARIANTS:
+            name = f"C3 solver options {it}/{ls}"
+            try:
+                t0 = time.perf_counter()
+                mv = solver_variant(mj, it, ls)
+                mdl = mjx.put_model(mv, dev, specialise=True)
+                t_build = time.perf_counter() - t0
+                k = 3
+                el, kms, fin = timed_rollouts(mdl, x0_t, us_t, k)
+                out.append({"name": name, "metric": "env-steps/sec, 4096 envs x 1000-step rollout", "value": args.nenv * args.horizon * k / el, "unit": "env-steps/s",
+                            "steps": k, "ms_per_step": 1e3 * el / k, "kernel_ms": kms,
+                            "config": {"workload": f"biped.xml with <option iterations={it} ls_iterations={ls}> (tolerance {mv.opt.tolerance:g}: the solver leaves its loop when the "
+                                                   f"scaled improvement or gradient falls below it), {args.nenv} envs x {args.horizon} steps, same x0 / ctrl as the headline",
+                                       "specialised_build": bool(mdl._h.query("specialised")), "model_setup_s": t_build, "outputs_finite": fin}})
+                del mdl
+            except Exception as e:
+                out.append({"name": name, "error": f"{type(e).__name__}: {e}"})
+        del x0_t, us_t
+
+    if True:
+        mjb = mj if model_path == BIPED else load_mj_model_from_file(BIPED)
+        mb = model if model_path == BIPED else mjx.put_model(mjb, dev)
+        x0b = torch.tensor(x0_np[:1], device=dev) if model_path == BIPED else make_inputs(mjb, 1, 1, 1, 2, dev)[0]
         # C4: 1024 rollouts x 64 knots from one x0, forward-difference gradient of the terminal cost (amx_fd_grad)
         S, N = 1024, 64
         nxb = mjb.nq + mjb.nv

@@ -33,10 +33,11 @@ def _worker(rank, world, port, nenv_total, out_dir):
     np.save(os.path.join(out_dir, f"rank{rank}.npy"), full.numpy())
     if nenv_total % world == 0:  # the overlapped path of bench.py: two equal-block gathers in flight, then waited
         from ambersim_amd.dist import gather_trajectories_async
-        pend = [gather_trajectories_async(xs_local + k) for k in range(2)]
-        for k, (out, work) in enumerate(pend):
-            work.wait()
-            assert torch.equal(out, full + k)
+        pend = [gather_trajectories_async(xs_local + k) for k in range(2)]  # the temporaries xs_local + k live on in the handles
+        for k, pg in enumerate(pend):
+            assert pg.src is not None  # the rank's own block is held until the collective has been waited for
+            out = pg.wait()
+            assert pg.src is None and torch.equal(out, full + k)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -85,7 +86,8 @@ def test_bench_self_launch_dry_run(extra):
     assert len(lines) == 1, p.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak" and out["value"] > 0
-    assert "biped.xml" in out["config"]["workload"] and out["config"]["nenv_per_gpu"] == 6  # C5 default for N > 1
+    assert "biped.xml" in out["config"]["workload"] and out["config"]["nenv_per_gpu"] == 6  # one workload at every N
+    assert out["scaling_report"]["backend"] == "gloo" and out["scaling_report"]["world_size_reported"] == 2
     want = {"": "traj+overlapped", "--no-overlap": "traj", "--gather": "none"}[extra[0] if extra else ""]
     assert out["config"]["gather"] == want
     rep = out["scaling_report"]
@@ -112,3 +114,20 @@ def test_bench_self_launch_dry_run_four_ranks():
     assert p.returncode == 0, p.stderr[-2000:]
     out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
     assert out["n_gpus"] == 4 and out["config"]["gather"] == "traj+overlapped" and out["scaling_report"]["gathered_GB_per_rank"] > 0
+
+
+def test_bench_workload_is_the_same_at_every_n():
+    """The headline is north_star's target (the ~30-DoF biped, 4096 envs per GPU x 1000 steps) at N = 1 and at N > 1: a 1 -> 8
+    scaling curve compares one workload with itself."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    loads = []
+    for n in (1, 2):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0", "--dry-run", "--no-scaling-report"]
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+        assert out["n_gpus"] == n and out["config"]["nenv_per_gpu"] == 4096 and out["config"]["horizon"] == 1000
+        loads.append(out["config"]["workload"])
+    assert loads[0] == loads[1] and "biped.xml" in loads[0]

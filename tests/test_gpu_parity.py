@@ -216,8 +216,8 @@ def test_per_model_specialised_build_runs(cases, dev):
             mjx.rollout(mdl, X0, U)
         torch.cuda.synchronize()
         t[name] = (time.perf_counter() - t0) / 3
+    # a printed figure, not an assertion: wall-clock comparisons inside a test are a flake source (profiles/ hold the measured ones)
     print(f"per-model build: 4096 x 50 rollout generic {1e3 * t['generic']:.2f} ms, specialised {1e3 * t['specialised']:.2f} ms")
-    assert t["specialised"] < t["generic"]
 
 
 def test_per_model_build_with_equality_rows(cases, dev):
