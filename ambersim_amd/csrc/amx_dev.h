@@ -53,7 +53,7 @@ enum { CX_MAXV = 32, CX_MAXP = 16, CX_VA = 0, CX_VB = 96, CX_POLY = 192, CX_SCRA
   X(c_jac) /* packed contact|slot<<6|dof<<11|chain sign<<16|pair<<18 */                                                    \
   X(c_hent) /* [nhent] terms: packed dof_i|dof_j<<5|first contact row<<10|slot_i<<18|slot_j<<23 (dof_j <= dof_i) */         \
   X(c_dofmemadr) /* [nv+1] */ X(c_dofmem) /* terms: packed first contact row|slot<<8 */ X(c_conpair) /* [ncon] */           \
-  X(c_vert) X(c_rootbody) X(c_slot) /* [ncon][32]: position of dof j in the contact's dof chain, -1 if absent */ X(c_zero) /* one all-zero matrix row (ldm floats, 16-byte aligned): what the lanes without a matrix row load */ X(c_anc) /* [nb][max(nlevel-2,1)]: ancestors of a body, root first, itself and the world excluded, padded with 0 */            \
+  X(c_vert) X(c_rootbody) X(c_slot) /* [ncon][32]: position of dof j in the contact's dof chain, -1 if absent */ X(c_zero) /* one all-zero matrix row (ldm floats, 16-byte aligned): what the lanes without a matrix row load */ X(c_anc) /* [nb][max(nlevel-2,1)]: ancestors of a body, root first, itself and the world excluded, padded with 0 */ X(c_vchdof) /* [npair][ldc]: dof of slot t of the pair's dof list, -1 past its end */            \
   /* bases inside one environment slab (float offsets from the slab start) */                                              \
   X(e_qpos) X(e_qvel) X(e_ctrl)                                                                                            \
   X(e_body) /* records [nb][BODY_E]: xpos 0-2 xquat 3-6 cinert 7-16 (then cfrc 7-12) crb 17-26 (then cvel 17-22 cacc 23-28) */ \
@@ -62,7 +62,7 @@ enum { CX_MAXV = 32, CX_MAXP = 16, CX_VA = 0, CX_VB = 96, CX_POLY = 192, CX_SCRA
   X(e_M) /* full symmetric [nv][ldm], 16-byte aligned rows */ X(e_H) /* the same for H when it is stored; else the M*v staging vector */                                                       \
   X(e_Lb) /* packed lower-triangular Cholesky factor, only allocated for the CG solver */                                  \
   X(e_row) /* records [nefc][ROW_E]: Dact 0 frow 1 */                                                                      \
-  X(e_J) /* contact rows only, chain-compressed: [4*ncon][ldc] */                                                          \
+  X(e_J) /* contact rows only, chain-compressed: [4*ncon][ldc] */ X(e_vch) /* [npair][ldc]: the vector of the current J*v products gathered in the order of each pair's dof list (0 past its end) */                                                          \
   X(e_con) /* records [ncon][CON_E]: dist 0 pos 1-3 */ X(e_frame) /* [npair][9] */                                         \
   X(e_geom) /* records [ngc][GEO_E]: pos 0-2 mat 3-11 */                                                                   \
   X(e_cx) /* convex-convex scratch [CX_SCRATCH], only when ncx > 0 */                                                                   \

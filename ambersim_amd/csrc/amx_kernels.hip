@@ -242,6 +242,71 @@ template <int G> DEV float gsum(float x) {  // every lane gets the sum over its 
   if (G >= 64) x += __shfl_xor(x, 32);
   return x;
 }
+// ---- packed group sums (r03).  A group sum costs five cross-lane additions whatever it sums, and the line search needs six
+// at a time (two per trial point, three trial points per bracketing iteration).  Packed butterfly: DPP bank masks enable the
+// four QUADS (lanes 4q..4q+3) of a 16-lane row separately, so the first stage (row_half_mirror: quad 0 <-> 1, 2 <-> 3) adds
+// value A into quads 0 and 3 and value B into quads 1 and 2 of ONE register, the second stage (row_mirror: quad 0 <-> 3,
+// 1 <-> 2) folds two such registers into one - quad q of a row then carries one of four values - and the stages inside the quad
+// (xor 1, xor 2) and the row exchange run once per register instead of once per value: 15 vector instructions + 2 crossbar
+// operations for six sums instead of 30 + 6.  On return every lane holds the group total of the value its quad selects;
+// quad_value<q> reads quad q's (a row broadcast, folded into the consuming add).
+// The DPP additions are inline assembly (the compiler's DPP combiner does not form bank-masked additions); the two wait states
+// a DPP read needs after a vector write of its source are spelled out: a leading s_nop 1 for the inputs, and inside the block
+// every source was written at least two instructions earlier (s_nop 0 where a chain has only one independent neighbour).
+template <int Q> DEV float quad_value(float x) { return dpp_f<0x150 + 4 * Q>(x); }  // row_newbcast: lane 4Q of the lane's row
+template <int G> DEV float rows_total(float x) {  // the cross-row steps of gsum
+  if (G >= 32) x += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x401F));
+  if (G >= 64) x += __shfl_xor(x, 32);
+  return x;
+}
+// u: quads 0, 1, 2, 3 -> sums of a0, b0, b1, a1;  w: quads 0, 1 -> sums of a2, b2 (quads 3, 2 mirror them)
+#define AMX_PACK6_ASM(TAIL)                                                                          \
+  asm("s_nop 1\n\t"                                                                                    \
+      "v_add_f32_dpp %[ra], %[a0], %[a0] row_half_mirror row_mask:0xf bank_mask:0x9\n\t"               \
+      "v_add_f32_dpp %[rb], %[a1], %[a1] row_half_mirror row_mask:0xf bank_mask:0x9\n\t"               \
+      "v_add_f32_dpp %[rc], %[a2], %[a2] row_half_mirror row_mask:0xf bank_mask:0x9\n\t"               \
+      "v_add_f32_dpp %[ra], %[b0], %[b0] row_half_mirror row_mask:0xf bank_mask:0x6\n\t"               \
+      "v_add_f32_dpp %[rb], %[b1], %[b1] row_half_mirror row_mask:0xf bank_mask:0x6\n\t"               \
+      "v_add_f32_dpp %[rc], %[b2], %[b2] row_half_mirror row_mask:0xf bank_mask:0x6\n\t"               \
+      "v_add_f32_dpp %[u], %[ra], %[ra] row_mirror row_mask:0xf bank_mask:0x3\n\t"                     \
+      "v_add_f32_dpp %[u], %[rb], %[rb] row_mirror row_mask:0xf bank_mask:0xc\n\t"                     \
+      "v_add_f32_dpp %[w], %[rc], %[rc] row_mirror row_mask:0xf bank_mask:0xf\n\t"                     \
+      "s_nop 0\n\t"                                                                                    \
+      "v_add_f32_dpp %[u], %[u], %[u] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"              \
+      "v_add_f32_dpp %[w], %[w], %[w] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"              \
+      "s_nop 0\n\t"                                                                                    \
+      "v_add_f32_dpp %[u], %[u], %[u] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"              \
+      "v_add_f32_dpp %[w], %[w], %[w] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" TAIL               \
+      : [ra] "=&v"(ra), [rb] "=&v"(rb), [rc] "=&v"(rc), [u] "=&v"(u), [w] "=&v"(w)                      \
+      : [a0] "v"(a0), [b0] "v"(b0), [a1] "v"(a1), [b1] "v"(b1), [a2] "v"(a2), [b2] "v"(b2))
+#define AMX_PACK2_ASM(TAIL)                                                                          \
+  asm("s_nop 1\n\t"                                                                                    \
+      "v_add_f32_dpp %[r], %[a], %[a] row_half_mirror row_mask:0xf bank_mask:0x9\n\t"                  \
+      "v_add_f32_dpp %[r], %[b], %[b] row_half_mirror row_mask:0xf bank_mask:0x6\n\t"                  \
+      "s_nop 1\n\t"                                                                                    \
+      "v_add_f32_dpp %[r], %[r], %[r] row_mirror row_mask:0xf bank_mask:0xf\n\t"                       \
+      "s_nop 1\n\t"                                                                                    \
+      "v_add_f32_dpp %[r], %[r], %[r] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"              \
+      "s_nop 1\n\t"                                                                                    \
+      "v_add_f32_dpp %[r], %[r], %[r] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" TAIL               \
+      : [r] "=&v"(r) : [a] "v"(a), [b] "v"(b))
+// 16-lane groups have no row exchange behind the block: its results go straight to the consumers' DPP reads (quad_value), which
+// the compiler cannot pad for - it does not know the block's last instructions wrote them - so the block ends with the two
+// wait states itself
+template <int G> DEV void gsum_pack6(float a0, float b0, float a1, float b1, float a2, float b2, float &u, float &w) {
+  float ra, rb, rc;
+  if constexpr (G == 16) AMX_PACK6_ASM("\n\ts_nop 1");
+  else AMX_PACK6_ASM("");
+  u = rows_total<G>(u);
+  w = rows_total<G>(w);
+}
+// r: quads 0, 1 -> sums of a, b (quads 3, 2 mirror them)
+template <int G> DEV float gsum_pack2(float a, float b) {
+  float r;
+  if constexpr (G == 16) AMX_PACK2_ASM("\n\ts_nop 1");
+  else AMX_PACK2_ASM("");
+  return rows_total<G>(r);
+}
 // value of lane `j` of my group (j compile-time or wave-uniform); gb4 = 4 * (first lane of my group)
 template <int G> DEV float gbcast(float x, int j, int gb4) {
   if (G == 64) return readlane_f(x, j);
@@ -587,16 +652,57 @@ template <class S, int G, int K> struct SymRest {  // dense order: every column 
     }
   }
 };
-template <class S, int G, int J, bool TREE, bool BCOL> DEV void sym_pivot(float (&a)[S::nv + 1], int gl, float &diag) {
+#ifndef AMX_PIVOT_VCMP
+#define AMX_PIVOT_VCMP 0  // 1: the pivot-lane test as v_cmp per pivot (r02), A/B switch
+#endif
+#ifndef AMX_PIVOT_ASM_MAX
+#define AMX_PIVOT_ASM_MAX 1  // 0: the pivot broadcast as builtins (the compiler does not fold the DPP move into v_max here: +1 VALU per pivot, measured)
+#endif
+// lanes of the wave that are lane J of their group, as the 64-bit constant a v_cndmask takes from a scalar register pair:
+// the pivot-lane test of a pivot costs two s_mov of literals (scalar unit, rematerialised at will) instead of a v_cmp
+template <int G, int J> constexpr unsigned long long lane_mask() {
+  return (G == 16 ? 0x0001000100010001ull : (G == 32 ? 0x0000000100000001ull : 1ull)) << J;
+}
+DEV float sel_zero(unsigned long long mask, float x) {  // masked lanes 0, the others x
+  float o;
+  asm("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(o) : "v"(x), "s"(mask));
+  return o;
+}
+DEV float sel_mask(unsigned long long mask, float yes, float no) {  // masked lanes `yes`, the others `no`
+  float o;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(o) : "v"(no), "v"(yes), "s"(mask));
+  return o;
+}
+template <class S, int G, int J, bool TREE, bool BCOL> DEV void sym_pivot(float (&a)[S::nv + 1], int gl, float &diag, unsigned long long pm0, unsigned long long &pm) {
   constexpr int N = S::nv;
   const float c = a[J];
   const RowPair p = row_pair<G>(c);
-  // max(lane J of p, MINVAL) in one instruction; the leading s_nop 1 is the 2 wait states after the swap / the last writer
   float piv;
+#if AMX_PIVOT_ASM_MAX
+  // max(lane J of p, MINVAL) in one instruction; the leading s_nop 1 is the 2 wait states after the swap / the last writer
   asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(piv) : "v"(J < 16 ? p.r0 : p.r1), "v"(MINVAL), "n"(J & 15));
+#else
+  // max(lane J of p, MINVAL): the compiler folds the DPP move into v_max_f32_dpp and pads only the wait states the distance to
+  // the swap leaves open (the assembly form carried a fixed s_nop 1).  Every assembly multiply-add below depends on it through
+  // nf and reads a register written by the same swap, so their two wait states hold by construction as before.
+  piv = fmaxf(bcast_row<J>(p), MINVAL);
+#endif
   float nf = -c * __builtin_amdgcn_rcpf(piv);
+#if AMX_PIVOT_VCMP
   nf = gl == J ? 0.0f : nf;  // the pivot row itself is left alone
   diag = gl == J ? piv : diag;  // ... and its diagonal is final: kept for the last division (same test, no pass over the row at the end)
+#else
+  // the lanes that are lane J of their group: pm0 (lane 0 of every group, opaque to the optimiser) shifted by J on the scalar
+  // unit - a pure function of pm0, so the pivots of different limbs still interleave freely
+  // volatile: the pivot headers keep their program order.  Left free, the scheduler interleaves every limb's chain for
+  // instruction-level parallelism and pays for it in registers: the biped kernel spilled 22 vector and 75 scalar registers
+  // and ran 3 % slower than with the pivots in the order written (r03 A/B: profiles/r03_ab_pivot_order.txt)
+  // The mask lives in ONE scalar register pair for the whole elimination (the output is tied to the previous pivot's mask): the
+  // selects of pivot k must read it before pivot k+1 overwrites it, which pins every pivot's header behind its predecessor's.
+  asm volatile("s_lshl_b64 %0, %2, %3" : "=s"(pm) : "0"(pm), "s"(pm0), "n"(J) : "scc");
+  nf = sel_zero(pm, nf);           // the pivot row itself is left alone
+  diag = sel_mask(pm, piv, diag);  // ... and its diagonal is final: kept for the last division
+#endif
   if constexpr (BCOL) {
     fmac_bcast<N>(a[N], p, nf);
   } else {
@@ -606,21 +712,51 @@ template <class S, int G, int J, bool TREE, bool BCOL> DEV void sym_pivot(float 
   if constexpr (TREE) SymAnc<S, G, S::dof_parent[J]>::run(a, p, nf);
   else SymRest<S, G, J + 1>::run(a, p, nf);
 }
-template <class S, int G, int J, bool BCOL> struct SymTree {  // leaves before their ancestors
-  static DEV void run(float (&a)[S::nv + 1], int gl, float &diag) {
-    sym_pivot<S, G, J, true, BCOL>(a, gl, diag);
-    SymTree<S, G, J - 1, BCOL>::run(a, gl, diag);
-  }
-};
-template <class S, int G, bool BCOL> struct SymTree<S, G, -1, BCOL> { static DEV void run(float (&)[S::nv + 1], int, float &) {} };
-template <class S, int G, int J, bool BCOL> struct SymDense {
-  static DEV void run(float (&a)[S::nv + 1], int gl, float &diag) {
-    if constexpr (J < S::nv) {
-      sym_pivot<S, G, J, false, BCOL>(a, gl, diag);
-      SymDense<S, G, J + 1, BCOL>::run(a, gl, diag);
+#ifndef AMX_ELIM_ORDER
+#define AMX_ELIM_ORDER 1  // 0: pivots from the last dof to the first; 1: by rounds of leaves (A/B switch)
+#endif
+// Order of the tree elimination: any order that pivots a dof after all its descendants is fill-free.  Round by round, the
+// current leaves of the tree (highest index first): consecutive pivots then belong to different limbs and their short
+// dependent headers (swap, broadcast, reciprocal) overlap in program order, without asking the scheduler to reorder.
+template <class S> struct ElimOrder {
+  int seq[32];
+  constexpr ElimOrder() : seq{} {
+    constexpr int N = S::nv;
+    bool done[32] = {};
+    int n = 0;
+    if (AMX_ELIM_ORDER == 0) { for (int j = N - 1; j >= 0; --j) seq[n++] = j; }
+    while (n < N) {
+      bool leaf[32] = {};
+      for (int j = 0; j < N; ++j) leaf[j] = !done[j];
+      for (int j = 0; j < N; ++j) if (!done[j] && S::dof_parent[j] >= 0) leaf[S::dof_parent[j]] = false;
+      for (int j = N - 1; j >= 0; --j) if (leaf[j]) { seq[n++] = j; done[j] = true; }
     }
   }
 };
+template <class S, int G, int I, bool BCOL> struct SymTree {  // leaves before their ancestors
+  static DEV void run(float (&a)[S::nv + 1], int gl, float &diag, unsigned long long pm0, unsigned long long &pm) {
+    if constexpr (I < S::nv) {
+      constexpr ElimOrder<S> ord{};
+      sym_pivot<S, G, ord.seq[I], true, BCOL>(a, gl, diag, pm0, pm);
+      SymTree<S, G, I + 1, BCOL>::run(a, gl, diag, pm0, pm);
+    }
+  }
+};
+template <class S, int G, int J, bool BCOL> struct SymDense {
+  static DEV void run(float (&a)[S::nv + 1], int gl, float &diag, unsigned long long pm0, unsigned long long &pm) {
+    if constexpr (J < S::nv) {
+      sym_pivot<S, G, J, false, BCOL>(a, gl, diag, pm0, pm);
+      SymDense<S, G, J + 1, BCOL>::run(a, gl, diag, pm0, pm);
+    }
+  }
+};
+// entry point
+template <class S, int G, bool TREE, bool BCOL> DEV void sym_eliminate(float (&a)[S::nv + 1], int gl, float &diag) {
+  unsigned long long pm0 = lane_mask<G, 0>(), pm = 0;
+  asm volatile("" : "+s"(pm0), "+s"(pm));  // opaque: thirty constant masks would be hoisted out of the step loop and spilled
+  if constexpr (TREE) SymTree<S, G, 0, BCOL>::run(a, gl, diag, pm0, pm);
+  else SymDense<S, G, 0, BCOL>::run(a, gl, diag, pm0, pm);
+}
 template <class S, int G> constexpr bool sym_elim_ok() { return S::is_static && G <= 32 && S::nv < G && !AMX_NO_SYM_ELIM; }
 
 template <class S, int G, bool TREE>
@@ -660,13 +796,8 @@ AMX_STATIC_SOLVE_ATTR void spd_solve_static(int A_off, int rhs_off, int x_off, i
     }
     a[N] = b;
     float d = 1.0f;
-    if (BCOL && bt_off >= 0) {
-      if (TREE) SymTree<S, G, N - 1, true>::run(a, gle, d);
-      else SymDense<S, G, 0, true>::run(a, gle, d);
-    } else {
-      if (TREE) SymTree<S, G, N - 1, false>::run(a, gle, d);
-      else SymDense<S, G, 0, false>::run(a, gle, d);
-    }
+    if (BCOL && bt_off >= 0) sym_eliminate<S, G, TREE, true>(a, gle, d);
+    else sym_eliminate<S, G, TREE, false>(a, gle, d);
     if (gl < N) lds[x_off + gl * DOF_E] = fdiv(a[N], d);
     WSYNC();
     return;
@@ -774,8 +905,7 @@ AMX_STATIC_SOLVE_ATTR bool newton_solve_fused(int M_off, int ld_, int n_, unsign
     if (owner) lds[dg] = d0;  // M's own diagonal back (after the loads above: one wave's LDS operations execute in order)
     a[NS] = b;
     float d = 1.0f;
-    if constexpr (TREE) SymTree<S, G, NS - 1, true>::run(a, gle, d);
-    else SymDense<S, G, 0, true>::run(a, gle, d);
+    sym_eliminate<S, G, TREE, true>(a, gle, d);
     if (owner) lds[x_off + gl * DOF_E] = fdiv(a[NS], d);
     WSYNC();
     return false;
@@ -863,7 +993,6 @@ DEV float row_impedance(int rec, float pos) {
   return x > 1.0f ? dmax : v;
 }
 
-struct LSPoint { float alpha, cost, d0, d1; };
 
 // Diagnostic build only (-DAMX_PROFILE, libamx_prof.so): per-phase cycle shares via s_memtime.  Never in the product build.
 #ifdef AMX_PROFILE
@@ -1255,7 +1384,9 @@ struct Env {
   // Row r of the reference's row table is A row r, or B row r - nA.
   float aD, aAref, aJaref, aJv;  // slot A solver state
   float cD, cAref, cJaref, cJv;  // slot B solver state
-  int rchain[4], rdn;  // contact row `gl`: its pair's dof list (<=16 dofs, one byte each) and its length
+  // contact row `gl`: J*v reads v from the pair's gathered copy (stage_chain) - vch_base: where that copy starts;
+  // staging item `gl` (slot t of pair p, gl = p*ldc + t): vch_dof = its dof, -1 past the list's end
+  int vch_base, vch_dof;
   float rJ1, rJ2;      // equality / limit row `gl`: Jacobian entries on dofs rd1, rd2
   int rd1, rd2;
   bool aact, cact;  // the slot's row is active at the current iterate (set by constraint_force_and_grad)
@@ -1283,20 +1414,12 @@ struct Env {
     rd1 = 0; rd2 = -1;
     if (lane < m.neq()) { const int er = m.c_eq() + lane * EQ_S; rd1 = CI(er + 1); rd2 = CI(er + 3); }
     else if (lane < m.neq() + m.nlim()) rd1 = CI(m.c_lim() + (lane - m.neq()) * LIM_S + 1);
-    rchain[0] = rchain[1] = rchain[2] = rchain[3] = 0; rdn = 0;
-    if (lane < 4 * m.ncon()) {
-      const int prec = m.c_pair() + CI(m.c_conpair() + (lane >> 2)) * PAIR_S, d0 = CI(prec + 9);
-      rdn = CI(prec + 10);
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {  // static register indices only (a runtime-indexed array would live in scratch)
-        int pk = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int t = 4 * w + q;
-          if (t < rdn) pk |= (CI(m.c_pairdof() + d0 + t) & 255) << (8 * q);
-        }
-        rchain[w] = pk;
-      }
+    vch_base = eb + m.e_vch();
+    if (lane < 4 * m.ncon()) vch_base += CI(m.c_conpair() + (lane >> 2)) * m.ldc();
+    {
+      const int nvch = m.npair() * m.ldc();
+      vch_dof = CI(m.c_vchdof() + (lane < nvch ? lane : 0));
+      vch_dof = lane < nvch ? vch_dof : -1;
     }
   }
 
@@ -2004,6 +2127,7 @@ struct Env {
           return JEnt{Jo + (4 * c) * ldc + slot, jn + mu * j1, jn - mu * j1, jn + mu * j2, jn - mu * j2};
         },
         [&](int, const JEnt &r) { lds[r.at] = r.r0; lds[r.at + ldc] = r.r1; lds[r.at + 2 * ldc] = r.r2; lds[r.at + 3 * ldc] = r.r3; });
+      stage_chain(qv, 1);  // for the rows' J * qvel below
     }
     WSYNC();
     // slot A: equality / limit row gl
@@ -2064,7 +2188,7 @@ struct Env {
       const float mu = CF(prec + 11), tw = CF(prec + 22);
       const float f = (k & 1) ? -mu : mu;
       const float invw = fdiv((tw + f * f * tw) * 2 * f * f, m.impratio());
-      const float jv = chain_dot(Jo + cr * ldc, qv, 1);
+      const float jv = chain_dot(Jo + cr * ldc);  // qvel was staged with the Jacobian entries above
       if (dist < margin) {
         const int rec = prec + 12;
         const float imp = row_impedance(rec, pos);
@@ -2084,6 +2208,7 @@ struct Env {
     const int nv = m.nv(), ldm = m.ldm(), i = gl < nv ? gl : 0, Vo = eb + m.e_H();
     const float dv_ = dof(vf, gl < nv ? gl : 0);  // unconditional load, then selects
     if (gl < ldm) lds[Vo + gl] = gl < nv ? dv_ : 0.0f;
+    if (nB() > 0) stage_chain(dofoff(vf), DOF_E);  // the same vector in the order of the contact rows' dof lists (row_dot_B follows every M*v)
     WSYNC();
     const float4 *mr = reinterpret_cast<const float4 *>(lds + eb + m.e_M() + i * ldm), *vv = reinterpret_cast<const float4 *>(lds + Vo);
     float acc0 = 0, acc1 = 0;
@@ -2118,34 +2243,39 @@ struct Env {
     a = rd2 >= 0 ? a2 : a;
     return gl < nA() ? a : 0.0f;
   }
-  // sum over the contact row's dof list of J[t] * v[dof_t] (J at Jr, v at vo with stride vs).  Branch-free: every term of
-  // the row's ldc slots is loaded (slots past the list hold stale floats of the slab, dof index 0) and a select keeps
-  // the listed ones, so all the loads are in flight together - one LDS latency per dot product instead of one per term
-  // behind a divergent branch (r02b: 56 such branches per step, each with its own wait).  Two partial sums.
-  DEV float chain_dot(int Jr, int vo, int vs) const {
+  // Gathers v (element i at vo + i*vs) in the order of every pair's dof list, zeros past a list's end: [npair][ldc] at e_vch.
+  // The contact rows' dots then read J and v side by side with immediate offsets (chain_dot) - in place of this pass every row
+  // lane extracted a dof index, formed an address and masked the entry for each of its ldc terms (r02: 5 vector instructions per
+  // term, 13 terms, five dots per step).  The caller orders the pass before the dots (WSYNC).
+  DEV void stage_chain(int vo, int vs) const {
+    const int nvch = m.npair() * m.ldc(), out = eb + m.e_vch();
+    {
+      const float v = lds[vo + (vch_dof < 0 ? 0 : vch_dof) * vs];
+      if (gl < nvch) lds[out + gl] = vch_dof < 0 ? 0.0f : v;
+    }
+    for (int t = gl + G; t < nvch; t += G) {  // more slots than lanes (quadruped: 4 pairs x 9): the dof comes from the constants
+      const int d_ = CI(m.c_vchdof() + t);
+      const float v = lds[vo + (d_ < 0 ? 0 : d_) * vs];
+      lds[out + t] = d_ < 0 ? 0.0f : v;
+    }
+  }
+  // sum over the contact row's dof list of J[t] * v[dof_t]: J at Jr, v staged by stage_chain.  Every term of the row's ldc
+  // slots is loaded (slots past the list hold stale - finite - floats of the slab and meet a staged zero), so all the loads are in
+  // flight together and each term is one fused multiply-add.  Two partial sums.
+  DEV float chain_dot(int Jr) const {
     float a0 = 0, a1 = 0;
-    int rdn_ = rdn;  // recomputed tests (t < rdn) per call: as loop invariants the masks lived in spilled scalar registers
-    asm volatile("" : "+v"(rdn_));
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {  // dof list from registers: no metadata loads on this path
-      const int pk = rchain[w];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int t = 4 * w + q;
-        if (t < m.ldc()) {  // static in the specialised kernels, wave-uniform otherwise
-          // the select sits on the Jacobian entry (stale slots become 0; v is always a live dof value), so each term stays
-          // one fused multiply-add as in the branchy loop
-          const float jraw = lds[Jr + t], vt = lds[vo + ((pk >> (8 * q)) & 255) * vs];  // loaded unconditionally, then selected
-          const float jt = t < rdn_ ? jraw : 0.0f;
-          if (t & 1) a1 = __builtin_fmaf(jt, vt, a1); else a0 = __builtin_fmaf(jt, vt, a0);
-        }
+    for (int t = 0; t < 16; ++t) {
+      if (t < m.ldc()) {  // static in the specialised kernels, wave-uniform otherwise
+        const float jt = lds[Jr + t], vt = lds[vch_base + t];
+        if (t & 1) a1 = __builtin_fmaf(jt, vt, a1); else a0 = __builtin_fmaf(jt, vt, a0);
       }
     }
     return a0 + a1;
   }
   DEV float row_dot_B(int vf) const {
     const bool valid = gl < nB();
-    const float a = chain_dot(eb + m.e_J() + (valid ? gl : 0) * m.ldc(), dofoff(vf), DOF_E);
+    const float a = chain_dot(eb + m.e_J() + (valid ? gl : 0) * m.ldc());  // the caller has staged v = dof field vf (mul_M_row does)
     return valid ? a : 0.0f;
   }
   // Ma = M v, Jaref = J v - aref  (v = dof field vf)
@@ -2313,28 +2443,25 @@ struct Env {
     return false;
   }
 
-  // One trial step length: the quadratic model of the cost along the search direction under the active set at alpha.
-  // `derivs` fills d0, d1 (first and second derivative); `full` also the cost.  The bracketing loop below only ever compares
-  // derivatives, so it evaluates `derivs` (two group reductions instead of three, three-field selects instead of four) and
-  // the two bracket ends are evaluated in full once, after the loop - the same expressions as inside MJX's loop, evaluated
-  // at the same alphas, so the accepted step is the one the reference's search takes.
-  DEV LSPoint ls_point(float alpha, bool validA, bool validB, bool iseq, float g0, float g1, float g2, bool full) const {
+  // One trial step length alpha: the quadratic model of the cost along the search direction under the active set at alpha,
+  //   cost(alpha) = alpha^2 q2 + alpha q1 + q0,  q_k = sum over the active rows (+ the Gauss terms g_k).
+  // ls_terms gives THIS LANE's share of q1 and q2 (both row slots); the group sums of the three trial points of a bracketing
+  // iteration are formed together (gsum_pack6).  The bracketing loop only ever compares derivatives, so it needs q1 and q2
+  // only; the two bracket ends are evaluated in full (q0 too) once, after the loop - the same expressions as inside MJX's loop,
+  // evaluated at the same alphas, so the accepted step is the one the reference's search takes.
+  struct LSTerms { float q1, q2; };
+  DEV LSTerms ls_terms(float alpha, bool validA, bool validB, bool iseq, float *q0 = nullptr) const {
     const bool actA = validA && (aJaref + alpha * aJv < 0 || iseq), actB = validB && (cJaref + alpha * cJv < 0);
-    float q1 = (actA ? aJv * aJaref * aD : 0.0f) + (actB ? cJv * cJaref * cD : 0.0f);
-    float q2 = (actA ? 0.5f * aJv * aJv * aD : 0.0f) + (actB ? 0.5f * cJv * cJv * cD : 0.0f);
-    q1 = gsum<G>(q1) + g1; q2 = gsum<G>(q2) + g2;
-    LSPoint r;
-    r.alpha = alpha;
-    r.cost = 0.0f;
-    if (full) {
-      float q0 = (actA ? 0.5f * aJaref * aJaref * aD : 0.0f) + (actB ? 0.5f * cJaref * cJaref * cD : 0.0f);
-      q0 = gsum<G>(q0) + g0;
-      r.cost = alpha * alpha * q2 + alpha * q1 + q0;
-    }
-    r.d0 = 2 * alpha * q2 + q1;
-    r.d1 = 2 * q2 + (q2 == 0.0f ? MINVAL : 0.0f);
+    LSTerms r;
+    r.q1 = (actA ? aJv * aJaref * aD : 0.0f) + (actB ? cJv * cJaref * cD : 0.0f);
+    r.q2 = (actA ? 0.5f * aJv * aJv * aD : 0.0f) + (actB ? 0.5f * cJv * cJv * cD : 0.0f);
+    if (q0) *q0 = (actA ? 0.5f * aJaref * aJaref * aD : 0.0f) + (actB ? 0.5f * cJaref * cJaref * cD : 0.0f);
     return r;
   }
+  struct LSD { float alpha, d0, d1; };
+  // first and second derivative from the summed q1, q2 (Gauss terms included).  q2 is a sum of non-negative terms: the
+  // reference's `2 q2 + (q2 == 0) * MINVAL` is max(2 q2, MINVAL) for every q2 a float can hold above 5e-16
+  static DEV LSD ls_derivs(float alpha, float q1, float q2) { return LSD{alpha, __builtin_fmaf(alpha + alpha, q2, q1), fmaxf(q2 + q2, MINVAL)}; }
 
   // MJX's bracketing line search.  `alive` freezes the state of a group that has already converged.
   DEV void linesearch(float gauss, bool alive) {
@@ -2349,18 +2476,31 @@ struct Env {
       const float sn_ = si * si, g1_ = si * ma_ - si * fs_, g2_ = 0.5f * si * mv;
       sn = gl < nv ? sn_ : 0.0f; g1 = gl < nv ? g1_ : 0.0f; g2 = gl < nv ? g2_ : 0.0f;
     }
-    sn = gsum<G>(sn); g1 = gsum<G>(g1); g2 = gsum<G>(g2);
+    const bool validA = gl < nA(), validB = gl < nB(), iseq = gl < m.neq();
+    // the three dof sums and the three row sums of the starting point alpha = 0, in one packed reduction
+    float p0_cost;
+    LSD p0d;
+    {
+      float q0;
+      const LSTerms t = ls_terms(0.0f, validA, validB, iseq, &q0);
+      float u, w;
+      gsum_pack6<G>(g1, g2, t.q1, t.q2, sn, q0, u, w);
+      g1 = quad_value<0>(u); g2 = quad_value<1>(u); sn = quad_value<0>(w);
+      const float q1 = quad_value<3>(u) + g1, q2 = quad_value<2>(u) + g2;
+      p0_cost = quad_value<1>(w) + gauss;  // alpha = 0: the cost is q0
+      p0d = ls_derivs(0.0f, q1, q2);
+    }
     PROF(21);
     const float gtol = m.tolerance() * m.ls_tolerance() * sqrtf(sn) * m.scale();
-    const bool validA = gl < nA(), validB = gl < nB(), iseq = gl < m.neq();
-    struct LSD { float alpha, d0, d1; };
-#define POINT(al) ls_point((al), validA, validB, iseq, gauss, g1, g2, true)
-#define DERIV(al) [&](float a_) { const LSPoint t_ = ls_point(a_, validA, validB, iseq, gauss, g1, g2, false); return LSD{t_.alpha, t_.d0, t_.d1}; }(al)
 #define PICK(c, a, b) { (c) ? (a).alpha : (b).alpha, (c) ? (a).d0 : (b).d0, (c) ? (a).d1 : (b).d1 }
-    const LSPoint p0 = POINT(0.0f);
-    const LSD p0d = {p0.alpha, p0.d0, p0.d1};
-    const LSD p1 = DERIV(p0.alpha - fdiv(p0.d0, p0.d1));
-    const bool first = p1.d0 < p0.d0;
+    LSD p1;
+    {
+      const float a1 = p0d.alpha - fdiv(p0d.d0, p0d.d1);
+      const LSTerms t = ls_terms(a1, validA, validB, iseq);
+      const float r = gsum_pack2<G>(t.q1, t.q2);
+      p1 = ls_derivs(a1, quad_value<0>(r) + g1, quad_value<1>(r) + g2);
+    }
+    const bool first = p1.d0 < p0d.d0;
     LSD lo = PICK(first, p1, p0d), hi = PICK(first, p0d, p1);
     bool swap = true;
     // one bracketing iteration; returns false when every group of the wave has finished its search
@@ -2369,22 +2509,25 @@ struct Env {
       done = done || ((lo.d0 < 0) && (lo.d0 > -gtol));
       done = done || ((hi.d0 > 0) && (hi.d0 < gtol));
       if (!wave_any(!done && alive)) return false;
-      const LSD lo_next = DERIV(lo.alpha - fdiv(lo.d0, lo.d1));
-      const LSD hi_next = DERIV(hi.alpha - fdiv(hi.d0, hi.d1));
-      const LSD mid = DERIV(0.5f * (lo.alpha + hi.alpha));
-      LSD nlo = lo, nhi = hi;
-      const bool s_lo_next = (nlo.d0 > 0) || (nlo.d0 < lo_next.d0);
-      { const LSD t = PICK(s_lo_next, lo_next, nlo); nlo = t; }
-      const bool s_lo_mid = (mid.d0 < 0) && (nlo.d0 < mid.d0);
+      const float a_lo = lo.alpha - fdiv(lo.d0, lo.d1), a_hi = hi.alpha - fdiv(hi.d0, hi.d1), a_mid = 0.5f * (lo.alpha + hi.alpha);
+      const LSTerms t_lo = ls_terms(a_lo, validA, validB, iseq), t_hi = ls_terms(a_hi, validA, validB, iseq), t_mid = ls_terms(a_mid, validA, validB, iseq);
+      float u, w;
+      gsum_pack6<G>(t_lo.q1, t_lo.q2, t_hi.q1, t_hi.q2, t_mid.q1, t_mid.q2, u, w);
+      const LSD lo_next = ls_derivs(a_lo, quad_value<0>(u) + g1, quad_value<1>(u) + g2);
+      const LSD hi_next = ls_derivs(a_hi, quad_value<3>(u) + g1, quad_value<2>(u) + g2);
+      const LSD mid = ls_derivs(a_mid, quad_value<0>(w) + g1, quad_value<1>(w) + g2);
+      // a group whose search has ended keeps its bracket: `done` is part of every replacement test (scalar logic) instead of a
+      // second round of selects
+      const bool s_lo_next = !done && ((lo.d0 > 0) || (lo.d0 < lo_next.d0));
+      LSD nlo = PICK(s_lo_next, lo_next, lo);
+      const bool s_lo_mid = !done && (mid.d0 < 0) && (nlo.d0 < mid.d0);
       { const LSD t = PICK(s_lo_mid, mid, nlo); nlo = t; }
-      const bool s_hi_next = (nhi.d0 < 0) || (nhi.d0 > hi_next.d0);
-      { const LSD t = PICK(s_hi_next, hi_next, nhi); nhi = t; }
-      const bool s_hi_mid = (mid.d0 > 0) && (nhi.d0 > mid.d0);
+      const bool s_hi_next = !done && ((hi.d0 < 0) || (hi.d0 > hi_next.d0));
+      LSD nhi = PICK(s_hi_next, hi_next, hi);
+      const bool s_hi_mid = !done && (mid.d0 > 0) && (nhi.d0 > mid.d0);
       { const LSD t = PICK(s_hi_mid, mid, nhi); nhi = t; }
-      // a group whose search has ended keeps its bracket
-      { const LSD t = PICK(done, lo, nlo); lo = t; }
-      { const LSD t = PICK(done, hi, nhi); hi = t; }
-      swap = done ? false : (s_lo_next || s_lo_mid || s_hi_next || s_hi_mid);
+      lo = nlo; hi = nhi;
+      swap = s_lo_next || s_lo_mid || s_hi_next || s_hi_mid;
       return true;
     };
     // static trip count in the specialised kernels: fully unrolled (+1 %) while the body stays small (the reference pendulum's
@@ -2398,12 +2541,20 @@ struct Env {
       for (int it = 0; it < m.ls_iterations(); ++it) if (!bracket_step()) break;
     }
     PROF(22);
-    const LSPoint lo_f = POINT(lo.alpha), hi_f = POINT(hi.alpha);  // costs of the two bracket ends
-#undef POINT
-#undef DERIV
 #undef PICK
-    const bool improved = alive && ((lo_f.cost < p0.cost) || (hi_f.cost < p0.cost));
-    const float alpha = lo_f.cost < hi_f.cost ? lo.alpha : hi.alpha;
+    // costs of the two bracket ends
+    float lo_cost, hi_cost;
+    {
+      float q0l, q0h;
+      const LSTerms tl = ls_terms(lo.alpha, validA, validB, iseq, &q0l), th = ls_terms(hi.alpha, validA, validB, iseq, &q0h);
+      float u, w;
+      gsum_pack6<G>(tl.q1, tl.q2, th.q1, th.q2, q0l, q0h, u, w);
+      const float q1l = quad_value<0>(u) + g1, q2l = quad_value<1>(u) + g2, q1h = quad_value<3>(u) + g1, q2h = quad_value<2>(u) + g2;
+      lo_cost = lo.alpha * lo.alpha * q2l + lo.alpha * q1l + (quad_value<0>(w) + gauss);
+      hi_cost = hi.alpha * hi.alpha * q2h + hi.alpha * q1h + (quad_value<1>(w) + gauss);
+    }
+    const bool improved = alive && ((lo_cost < p0_cost) || (hi_cost < p0_cost));
+    const float alpha = lo_cost < hi_cost ? lo.alpha : hi.alpha;
     if (improved) {
       if (gl < nv) { dof(D_QACC, gl) += alpha * dof(D_SEARCH, gl); dof(D_MA, gl) += alpha * mv; }
       aJaref += alpha * aJv;

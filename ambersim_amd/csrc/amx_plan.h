@@ -432,6 +432,15 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
     m.c_dofmemadr = add_ints(adr); m.c_dofmem = add_ints(flat);
   }
   m.ldc = maxchain | 1;
+  {
+    // dof of every slot of every pair's dof list: the row dots J*v read v gathered in this order (amx_kernels.hip, stage_chain)
+    std::vector<int> vd((size_t)std::max(np, 1) * m.ldc, -1);
+    for (int p = 0; p < np; p++) {
+      const int o = m.c_pair + p * PAIR_S, d0 = im.geti(o + 9), dn = im.geti(o + 10);
+      for (int t = 0; t < dn; t++) vd[(size_t)p * m.ldc + t] = pairdof[d0 + t] & 255;
+    }
+    m.c_vchdof = add_ints(vd);
+  }
   // Newton on 32- and 64-lane groups without equality rows never stores H: the matrix cores' J'DJ, the lane's row of M and the
   // limit rows' diagonal terms meet in registers and are eliminated there (amx_kernels.hip, newton_solve_fused).
   m.fusedH = (m.G >= 32 && d->solver == 2 && m.neq == 0) ? 1 : 0;
@@ -487,6 +496,7 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
     m.e_row = o2; o2 += std::max(ROW_E * m.nefc, 1);
     o2 = (o2 + 3) & ~3;
     const int vstage = o2; o2 += std::max(m.ldm, nv + 8);
+    m.e_vch = o2; o2 += std::max(np * m.ldc, 1);
     off = std::max(r1 + BODY_E * nb, o2);
     off = (off + 3) & ~3;
     // H: stored only when it is not eliminated in registers; it doubles as the staging vector and as CG scratch

@@ -23,7 +23,7 @@ for line in open(path):
     if not line.startswith("\t") or t.startswith((".", ";")) or not t: continue
     op, _, rest = t.partition(" ")
     ops = [o.strip() for o in rest.split(",")]
-    if "_dpp" in op and op.startswith("v_fmac"):
+    if "_dpp" in op and op.startswith("v_"):  # every DPP instruction: the inline-assembly ones (v_fmac, v_add, v_max) are the ones the compiler cannot pad
         checked += 1
         src0 = regs(ops[1].split()[0])
         ws = 0
@@ -42,5 +42,5 @@ for line in open(path):
     elif op.startswith(("s_cbranch", "s_branch", "s_setpc", "s_swappc")): hist = []  # label targets: start over (conservative enough: producers are in-block)
     else: hist.append((set(), 1))
     hist = hist[-4:]
-print(f"{checked} inline-assembly DPP multiply-adds checked, {bad} hazards")
+print(f"{checked} DPP instructions checked (inline assembly and compiler-emitted), {bad} hazards")
 sys.exit(1 if bad else 0)
