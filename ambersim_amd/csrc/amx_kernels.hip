@@ -292,19 +292,38 @@ template <int G> DEV float rows_total(float x) {  // the cross-row steps of gsum
       : [r] "=&v"(r) : [a] "v"(a), [b] "v"(b))
 // 16-lane groups have no row exchange behind the block: its results go straight to the consumers' DPP reads (quad_value), which
 // the compiler cannot pad for - it does not know the block's last instructions wrote them - so the block ends with the two
-// wait states itself
+// wait states itself; likewise in front of the lane swaps of the 32-lane row exchange
+#ifndef AMX_PACK_SWIZZLE
+#define AMX_PACK_SWIZZLE 0  // 1: the packed sums exchange their rows through the LDS crossbar like gsum (A/B switch)
+#endif
 template <int G> DEV void gsum_pack6(float a0, float b0, float a1, float b1, float a2, float b2, float &u, float &w) {
   float ra, rb, rc;
-  if constexpr (G == 16) AMX_PACK6_ASM("\n\ts_nop 1");
+  if constexpr (G == 16 || (G == 32 && !AMX_PACK_SWIZZLE)) AMX_PACK6_ASM("\n\ts_nop 1");  // the consumer is a DPP read / a lane swap: see above
   else AMX_PACK6_ASM("");
-  u = rows_total<G>(u);
-  w = rows_total<G>(w);
+  if constexpr (G == 32 && !AMX_PACK_SWIZZLE) {
+    // Row exchange on the vector unit: the line search is a chain of dependent latencies (r03 phase profile: 1250 cycles per
+    // bracketing iteration for 100 vector instructions), and a crossbar round trip is the longest link in it.  One swap packs
+    // the two registers by row - (u.row0, w.row0) and (u.row1, w.row1) - one add gives u's total in row 0 and w's in row 1,
+    // a second swap hands both totals to both rows.
+    auto s1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(u), __float_as_uint(w), false, false);
+    const float t = __uint_as_float(s1[0]) + __uint_as_float(s1[1]);
+    auto s2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+    u = __uint_as_float(s2[0]);
+    w = __uint_as_float(s2[1]);
+  } else {
+    u = rows_total<G>(u);
+    w = rows_total<G>(w);
+  }
 }
 // r: quads 0, 1 -> sums of a, b (quads 3, 2 mirror them)
 template <int G> DEV float gsum_pack2(float a, float b) {
   float r;
-  if constexpr (G == 16) AMX_PACK2_ASM("\n\ts_nop 1");
+  if constexpr (G == 16 || (G == 32 && !AMX_PACK_SWIZZLE)) AMX_PACK2_ASM("\n\ts_nop 1");
   else AMX_PACK2_ASM("");
+  if constexpr (G == 32 && !AMX_PACK_SWIZZLE) {
+    auto s1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(r), __float_as_uint(r), false, false);  // (row 0, row 0), (row 1, row 1)
+    return __uint_as_float(s1[0]) + __uint_as_float(s1[1]);
+  }
   return rows_total<G>(r);
 }
 // value of lane `j` of my group (j compile-time or wave-uniform); gb4 = 4 * (first lane of my group)
@@ -2117,12 +2136,17 @@ struct Env {
           const f3 fn_ = mk3(lds[fo], lds[fo + 1], lds[fo + 2]), ft1 = mk3(lds[fo + 3], lds[fo + 4], lds[fo + 5]),
                    ft2 = mk3(lds[fo + 6], lds[fo + 7], lds[fo + 8]);
           const f3 w = mk3(dof(0, i), dof(1, i), dof(2, i)), l = mk3(dof(3, i), dof(4, i), dof(5, i));
-          const f3 com1 = ld_com(root1), com2 = ld_com(root2);  // unconditional loads, selected below
-          // both arms computed and selected (as `if`s the loads above sank into two branches, each with its own waits)
-          const f3 a2 = l + cross(w, pt - com2), a1 = l + cross(w, pt - com1);
-          const bool s1 = sg & 1, s2 = sg & 2;
-          f3 jp = mk3(s1 ? a2.x : 0.0f, s1 ? a2.y : 0.0f, s1 ? a2.z : 0.0f);
-          jp = mk3(s2 ? jp.x - a1.x : jp.x, s2 ? jp.y - a1.y : jp.y, s2 ? jp.z - a1.z : jp.z);
+          f3 jp;
+          if (m.jac_one_sided()) {  // a property of the model: contacts with the ground only - one arm, no selects
+            jp = l + cross(w, pt - ld_com(root2));
+          } else {
+            const f3 com1 = ld_com(root1), com2 = ld_com(root2);  // unconditional loads, selected below
+            // both arms computed and selected (as `if`s the loads above sank into two branches, each with its own waits)
+            const f3 a2 = l + cross(w, pt - com2), a1 = l + cross(w, pt - com1);
+            const bool s1 = sg & 1, s2 = sg & 2;
+            jp = mk3(s1 ? a2.x : 0.0f, s1 ? a2.y : 0.0f, s1 ? a2.z : 0.0f);
+            jp = mk3(s2 ? jp.x - a1.x : jp.x, s2 ? jp.y - a1.y : jp.y, s2 ? jp.z - a1.z : jp.z);
+          }
           const float jn = dot(fn_, jp), j1 = dot(ft1, jp), j2 = dot(ft2, jp);
           return JEnt{Jo + (4 * c) * ldc + slot, jn + mu * j1, jn - mu * j1, jn + mu * j2, jn - mu * j2};
         },
@@ -2292,8 +2316,9 @@ struct Env {
     const int li = gl < m.nv() ? gl : 0;  // unconditional loads, then a select (a lazily evaluated ?: is a branch with its own wait)
     const float gv = (dof(D_MA, li) - dof(D_FSMOOTH, li)) * (dof(vf, li) - dof(D_ASMOOTH, li));
     float g = gl < m.nv() ? gv : 0.0f;
-    c = gsum<G>(c);
-    g = 0.5f * gsum<G>(g);
+    const float r = gsum_pack2<G>(c, g);  // both sums in one packed reduction
+    c = quad_value<0>(r);
+    g = 0.5f * quad_value<1>(r);
     *gauss_out = g;
     return c + g;
   }
@@ -2789,6 +2814,11 @@ amx_rollout_kernel(const DevModel m_in, int nenv, int nsteps, int x0_batched, co
   env.prof_t = (unsigned)__builtin_amdgcn_s_memtime();
   env.prof_row = (prof && live) ? prof + (size_t)e * PROF_N : nullptr;
 #endif
+#if defined(AMX_STAGGER) && AMX_STAGGER > 0
+  // A/B experiment: the two waves of a SIMD (waves w and w + 4 of the workgroup) start half a step apart, so that one's
+  // latency-bound phases meet the other's issue-bound ones
+  if (wave >= 4) for (int i_ = 0; i_ < AMX_STAGGER; ++i_) __builtin_amdgcn_s_sleep(127);
+#endif
   const float *x0 = x0g + ((x0_batched && live) ? (size_t)e * nx : 0);
   if (live) {
     for (int i = gl; i < nx; i += G) {
@@ -2802,7 +2832,22 @@ amx_rollout_kernel(const DevModel m_in, int nenv, int nsteps, int x0_batched, co
   float unext = (live && gl < nu && nsteps > 0) ? us[gl] : 0.0f;
   WSYNC();
   // t = -1 is shoot()'s forward before the scan (ctrl = 0): it only seeds qacc_warmstart
+#ifndef AMX_FAIR_SIMD
+#define AMX_FAIR_SIMD 1  // 0: the two waves of a SIMD are left to the hardware's arbitration (A/B switch)
+#endif
+  // Waves w and w + 4 of an 8-wave workgroup share a SIMD.  With equal priorities its arbiter favours the older one on every
+  // contested issue slot: measured (r03, per-wave phase clocks) the older four waves of every workgroup ran a biped step in
+  // 81 k cycles and the younger four in 99 k, and a launch ends with its slowest wave.  Each wave posts its step counter in
+  // LDS; whichever of the pair is behind runs at raised priority for the step, so both advance at the same pace (~90 k).
+  const bool paired = AMX_FAIR_SIMD && wpb == 8;
   for (int t = -1; t < nsteps; ++t) {
+    if (paired) {
+      const int mine_ = t + 1;
+      if (lane == 0) lds[m.c_prog() + wave] = __int_as_float(mine_);
+      const int other_ = __builtin_amdgcn_readfirstlane(CI(m.c_prog() + (wave ^ 4)));
+      if (other_ > mine_) __builtin_amdgcn_s_setprio(3);
+      else __builtin_amdgcn_s_setprio(0);
+    }
     if (t >= 0) {
       if (gl < nu) lds[eb + m.e_ctrl() + gl] = unext;
       if (live) for (int i = gl + G; i < nu; i += G) lds[eb + m.e_ctrl() + i] = us[(size_t)t * nu + i];

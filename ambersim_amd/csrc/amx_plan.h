@@ -330,6 +330,8 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
   for (int t = 0; t < nv * (nv + 1) / 2; t++)
     for (int w : hmembers[t]) hent.push_back(w);  // one term per (H entry, contact)
   m.ncon = ncon; m.njac = (int)jac_items.size(); m.nhent = (int)hent.size();
+  m.jac_one_sided = 1;
+  for (int it : jac_items) if (((it >> 16) & 3) != 1) m.jac_one_sided = 0;
   if (ncon > 16) return fail(AMX_ECAPACITY, "%d contact slots exceed 16 (4 pyramid rows each, one row per lane of a 64-lane group)", ncon);
   {
     int first = -1, last = -1, cnt = 0;
@@ -468,6 +470,7 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
   while (im.size() & 3) im.reserve(1);
   m.c_zero = im.reserve(m.ldm);  // stays zero: Image::reserve clears
   for (int k = 0; k < m.ldm; k++) im.setf(m.c_zero + k, 0.0f);
+  m.c_prog = im.reserve(AMX_WAVES_PER_BLOCK);  // zeros; written in LDS only (the waves' step counters)
   while (im.size() & 3) im.reserve(1);  // environment slabs start 16-byte aligned
   m.nconst = im.size();
 

@@ -39,6 +39,18 @@ tot = p.sum(axis=1).mean()
 print(f"{model_path}: {nenv} envs x {steps} steps  kernel {ms:.2f} ms  -> {nenv*steps/ms*1e3/1e6:.2f} M env-steps/s")
 print(f"kernel: {'specialised' if model._h.query('specialised') else 'generic'}, lane group {model._h.query('lanes_per_env')}, {model._h.query('envs_per_block')} envs per workgroup")
 print(f"mean cycles per env-step per wave: {tot/steps:.0f}")
+# load balance: a wave's time is fixed by its slower environment, the launch ends with the slowest wave of the slowest workgroup
+per_env = p.sum(axis=1) / steps
+G = model._h.query("lanes_per_env"); epw = 64 // G; epb = model._h.query("envs_per_block")
+per_wave = per_env[: (nenv // epw) * epw].reshape(-1, epw).max(axis=1)
+per_wg = per_env[: (nenv // epb) * epb].reshape(-1, epb).max(axis=1)
+q = lambda a: " ".join(f"{np.percentile(a, x):.0f}" for x in (0, 10, 50, 90, 100))
+print(f"cycles per step, percentiles 0/10/50/90/100 - per env: {q(per_env)} | per wave: {q(per_wave)} | per workgroup (max of its waves): {q(per_wg)}")
+print(f"slowest workgroup / mean wave: {per_wg.max() / per_wave.mean():.3f}")
+wpb = epb // epw
+if wpb > 1 and nenv % epb == 0:  # by position of the wave inside its workgroup: waves w and w + 4 share a SIMD
+    by_idx = per_wave.reshape(-1, wpb).mean(axis=0)
+    print("mean cycles per step by wave index in the workgroup: " + " ".join(f"{v:.0f}" for v in by_idx))
 for i in range(24):
     v = p[:, i].mean()
     if v > 0:
