@@ -342,6 +342,23 @@ template <int G, int J> DEV float gbcast_s(float x) {
 }
 DEV bool wave_any(bool p) { return __ballot(p) != 0ull; }
 
+// Diagnostic build only (-DAMX_PROFILE, libamx_prof.so): per-phase cycle shares via s_memtime.  Never in the product build.
+#ifdef AMX_PROFILE
+#define PROF_N 32
+// The counters live in HBM (one row per environment, fire-and-forget atomic adds from the group's lane 0): the slab and the
+// launch plan are those of the product build, so the specialised kernels are the ones profiled.
+#define PROF_DECL unsigned prof_t; float *prof_row;
+#define PROF(id) do { unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); if (gl == 0 && prof_row) unsafeAtomicAdd(prof_row + (id), (float)(t_ - prof_t)); prof_t = t_; } while (0)
+// inside the free solve routines: the caller's clock and counter row travel through a context pointer (last argument)
+struct ProfCtx { unsigned *t; float *row; };
+#define PROF_CTX(pc, id) do { if (pc) { unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); if (gl == 0 && (pc)->row) unsafeAtomicAdd((pc)->row + (id), (float)(t_ - *(pc)->t)); *(pc)->t = t_; } } while (0)
+#else
+#define PROF_DECL
+#define PROF(id)
+struct ProfCtx {};
+#define PROF_CTX(pc, id)
+#endif
+
 // ---- register-row dense Cholesky: lane i holds row i of the matrix at lds[A_off] (lower part).
 // A is full symmetric [n][ld]; the factor is packed lower-triangular (row i at TRI(i)).  Solves A x = rhs.  L is written to lds[L_off] (may equal A_off: each lane overwrites only
 // its own row after reading it); the two substitutions re-read it masked (strict lower rows, then
@@ -439,6 +456,9 @@ template <int N, int G, int J> struct GJ {
 template <int N, int G> struct GJ<N, G, N> { static DEV void run(float (&)[N], float &, int, int) {} };
 
 typedef float v32f __attribute__((ext_vector_type(32)));
+#ifndef AMX_MFMA_ALL_ROWS
+#define AMX_MFMA_ALL_ROWS 0  // 1: every pyramid row of an active contact goes through the matrix cores (A/B switch)
+#endif
 
 // H = M + J' D J on the matrix cores, for one wave (G = 32: the wave's two environments are the two 32x32 blocks of
 // v_mfma_f32_32x32x1_2b_f32; G = 64: block 1 idles).  Lane (b, j) feeds block b with column j of one contact-Jacobian row
@@ -477,12 +497,15 @@ DEV void jtdj_rows_mfma(unsigned long long crows, int row_base, int J_base, int 
         d[r] = lds[Dr + r * ROW_E]; jv[r] = lds[Jr + r * ldc];
         if (COL31) g[r] = lds[Dr + r * ROW_E + 1];
       }
+      // a pyramid row that is inactive in both environments has D = 0 and f = 0 everywhere: its instruction (64 cycles of the
+      // matrix pipe, on the dependent chain) is skipped on a scalar test of its bit - except the one that starts the accumulator
+      const unsigned rbits = (unsigned)(crows >> (4 * c)) & 15u;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float v = has ? jv[r] : 0.0f;
         const float aop = (COL31 && j == 31) ? g[r] : d[r] * v;
         if (decltype(first)::value && r == 0) { const v32f Z = {}; C = __builtin_amdgcn_mfma_f32_32x32x1f32(aop, v, Z, 0, 0, 0); }
-        else C = __builtin_amdgcn_mfma_f32_32x32x1f32(aop, v, C, 0, 0, 0);
+        else if (AMX_MFMA_ALL_ROWS || ((rbits >> r) & 1u)) C = __builtin_amdgcn_mfma_f32_32x32x1f32(aop, v, C, 0, 0, 0);
       }
     };
     if (cm != 0ull) {
@@ -861,7 +884,7 @@ template <class S, int N, int G, bool TREE, bool GRADCOL = false>
 AMX_STATIC_SOLVE_ATTR bool newton_solve_fused(int M_off, int ld_, int n_, unsigned long long crows_, int row_base, int J_base, int ldc_, int slot_base_,
                                                 int rhs_off, int x_off, float dlim, int gl, int gb4, int rot, int bt_off, float flim = 0.0f, int ma_off = 0,
                                                 int fs_off = 0, int fcon_off = 0, bool store_ok = true, bool early_out = false, bool imp_done = false,
-                                                float scale = 1.0f, float tol = 0.0f) {
+                                                float scale = 1.0f, float tol = 0.0f, ProfCtx *pc = nullptr) {
   if constexpr (sym_elim_ok<S, G>() && G == 32) {
     // crossbar-free elimination (see sym_pivot): b reaches lane N as a row through the staging vector at bt_off
     constexpr int NS = S::nv, lds_ = S::ldm, nchs = lds_ / 4;
@@ -883,14 +906,16 @@ AMX_STATIC_SOLVE_ATTR bool newton_solve_fused(int M_off, int ld_, int n_, unsign
     if constexpr (GRADCOL) {
       static_assert(NS <= 31, "column 31 must be spare");
       const float ma = lds[ma_off + li * DOF_E], fs = lds[fs_off + li * DOF_E];
+      PROF_CTX(pc, 24);
       jtdj_rows_mfma<G, true>(crows_u, row_base, J_base, S::ldc, S::c_slot, gl, lo, hi);
+      PROF_CTX(pc, 25);
       const float fcon = __uint_as_float(hi[3][3]) + flim;
       b = ma - fs - fcon;
       if (owner && store_ok) { lds[fcon_off + gl * DOF_E] = fcon; lds[rhs_off + gl * DOF_E] = b; }
       if (early_out) {
         const float gn = gsum<G>(owner ? b * b : 0.0f);
-        const bool done = imp_done || (fdiv(sqrtf(gn), scale) < tol);
-        if (!wave_any(store_ok && !done)) {  // store_ok is the group's `alive`
+        const bool done = imp_done | (fdiv(sqrtf(gn), scale) < tol);  // `|`, `&`: no exec-mask branches (see linesearch)
+        if (!wave_any(store_ok & !done)) {  // store_ok is the group's `alive`
           if (owner) lds[dg] = d0;
           WSYNC();
           return true;
@@ -924,7 +949,9 @@ AMX_STATIC_SOLVE_ATTR bool newton_solve_fused(int M_off, int ld_, int n_, unsign
     if (owner) lds[dg] = d0;  // M's own diagonal back (after the loads above: one wave's LDS operations execute in order)
     a[NS] = b;
     float d = 1.0f;
+    PROF_CTX(pc, 26);
     sym_eliminate<S, G, TREE, true>(a, gle, d);
+    PROF_CTX(pc, 27);
     if (owner) lds[x_off + gl * DOF_E] = fdiv(a[NS], d);
     WSYNC();
     return false;
@@ -1012,18 +1039,6 @@ DEV float row_impedance(int rec, float pos) {
   return x > 1.0f ? dmax : v;
 }
 
-
-// Diagnostic build only (-DAMX_PROFILE, libamx_prof.so): per-phase cycle shares via s_memtime.  Never in the product build.
-#ifdef AMX_PROFILE
-#define PROF_N 24
-// The counters live in HBM (one row per environment, fire-and-forget atomic adds from the group's lane 0): the slab and the
-// launch plan are those of the product build, so the specialised kernels are the ones profiled.
-#define PROF_DECL unsigned prof_t; float *prof_row;
-#define PROF(id) do { unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); if (gl == 0 && prof_row) unsafeAtomicAdd(prof_row + (id), (float)(t_ - prof_t)); prof_t = t_; } while (0)
-#else
-#define PROF_DECL
-#define PROF(id)
-#endif
 
 // Item loops (one lane per item, items t = gl, gl+G, ...): `fetch(t)` only loads and computes, `commit(t, v)` stores.
 // Two items are fetched before either commits, so the LDS round trips of consecutive items overlap instead of
@@ -2311,7 +2326,7 @@ struct Env {
     WSYNC();
   }
   DEV float constraint_cost(int vf, float *gauss_out) const {
-    const bool actA = gl < nA() && (aJaref < 0 || gl < m.neq()), actB = gl < nB() && cJaref < 0;
+    const bool actA = (gl < nA()) & ((aJaref < 0) | (gl < m.neq())), actB = (gl < nB()) & (cJaref < 0);
     float c = (actA ? 0.5f * aD * aJaref * aJaref : 0.0f) + (actB ? 0.5f * cD * cJaref * cJaref : 0.0f);
     const int li = gl < m.nv() ? gl : 0;  // unconditional loads, then a select (a lazily evaluated ?: is a branch with its own wait)
     const float gv = (dof(D_MA, li) - dof(D_FSMOOTH, li)) * (dof(vf, li) - dof(D_ASMOOTH, li));
@@ -2333,8 +2348,8 @@ struct Env {
   // and which of the two ran last must not depend on the wave mate)
   DEV void constraint_force_and_grad(bool defer = false, bool alive = true) {
     const int Jo = eb + m.e_J(), ldc = m.ldc(), row0 = m.neq() + m.nlim();
-    aact = gl < nA() && (aJaref < 0 || gl < m.neq()) && aD > 0;
-    cact = gl < nB() && cJaref < 0 && cD > 0;
+    aact = (gl < nA()) & ((aJaref < 0) | (gl < m.neq())) & (aD > 0);
+    cact = (gl < nB()) & (cJaref < 0) & (cD > 0);
     const float f = aact ? -aD * aJaref : 0.0f, fc = cact ? -cD * cJaref : 0.0f;
     if (gl < nA()) { row(0, gl) = aact ? aD : 0.0f; row(1, gl) = f; }
     if (gl < nB()) { row(0, row0 + gl) = cact ? cD : 0.0f; row(1, row0 + gl) = fc; }
@@ -2408,10 +2423,15 @@ struct Env {
         dlim = (gl < nv && d_limrow >= 0 && nA() > 0) ? dlim : 0.0f;
         PROF(19);
         bool stop = false;
+#ifdef AMX_PROFILE
+        ProfCtx pctx{&prof_t, prof_row}, *pc = &pctx;
+#else
+        ProfCtx *pc = nullptr;
+#endif
         if constexpr (grad_in_solve())
           stop = newton_solve_fused<S, S::nv, G, S::tree_H, true>(Mo, ldm, nv, rows, eb + m.e_row() + row0 * ROW_E, Jo, ldc, m.c_slot(), dofoff(D_GRAD), dofoff(D_MGRAD), dlim, gl, gb4, m_rot,
                                                                  eb + m.e_H(), pend_flim, dofoff(D_MA), dofoff(D_FSMOOTH), dofoff(D_FCON), alive, early_out, imp_done, m.scale(),
-                                                                 m.tolerance());
+                                                                 m.tolerance(), pc);
         else if constexpr (S::is_static)
           newton_solve_fused<S, S::nv, G, S::tree_H>(Mo, ldm, nv, rows, eb + m.e_row() + row0 * ROW_E, Jo, ldc, m.c_slot(), dofoff(D_GRAD), dofoff(D_MGRAD), dlim, gl, gb4, m_rot, eb + m.e_H());
         else
@@ -2476,7 +2496,7 @@ struct Env {
   // evaluated at the same alphas, so the accepted step is the one the reference's search takes.
   struct LSTerms { float q1, q2; };
   DEV LSTerms ls_terms(float alpha, bool validA, bool validB, bool iseq, float *q0 = nullptr) const {
-    const bool actA = validA && (aJaref + alpha * aJv < 0 || iseq), actB = validB && (cJaref + alpha * cJv < 0);
+    const bool actA = validA & ((aJaref + alpha * aJv < 0) | iseq), actB = validB & (cJaref + alpha * cJv < 0);
     LSTerms r;
     r.q1 = (actA ? aJv * aJaref * aD : 0.0f) + (actB ? cJv * cJaref * cD : 0.0f);
     r.q2 = (actA ? 0.5f * aJv * aJv * aD : 0.0f) + (actB ? 0.5f * cJv * cJv * cD : 0.0f);
@@ -2530,10 +2550,11 @@ struct Env {
     bool swap = true;
     // one bracketing iteration; returns false when every group of the wave has finished its search
     auto bracket_step = [&]() {
-      bool done = !swap;
-      done = done || ((lo.d0 < 0) && (lo.d0 > -gtol));
-      done = done || ((hi.d0 > 0) && (hi.d0 < gtol));
-      if (!wave_any(!done && alive)) return false;
+      // `|` and `&` on purpose, here and below: the short-circuit forms compile to nested exec-mask branches (s_and_saveexec,
+      // s_cbranch_execz per operand - a dozen per iteration, each a scalar round trip on the critical path); the operands are
+      // comparisons of values already in registers, so there is nothing to skip
+      const bool done = !swap | ((lo.d0 < 0) & (lo.d0 > -gtol)) | ((hi.d0 > 0) & (hi.d0 < gtol));
+      if (!wave_any(!done & alive)) return false;
       const float a_lo = lo.alpha - fdiv(lo.d0, lo.d1), a_hi = hi.alpha - fdiv(hi.d0, hi.d1), a_mid = 0.5f * (lo.alpha + hi.alpha);
       const LSTerms t_lo = ls_terms(a_lo, validA, validB, iseq), t_hi = ls_terms(a_hi, validA, validB, iseq), t_mid = ls_terms(a_mid, validA, validB, iseq);
       float u, w;
@@ -2543,16 +2564,16 @@ struct Env {
       const LSD mid = ls_derivs(a_mid, quad_value<0>(w) + g1, quad_value<1>(w) + g2);
       // a group whose search has ended keeps its bracket: `done` is part of every replacement test (scalar logic) instead of a
       // second round of selects
-      const bool s_lo_next = !done && ((lo.d0 > 0) || (lo.d0 < lo_next.d0));
+      const bool s_lo_next = !done & ((lo.d0 > 0) | (lo.d0 < lo_next.d0));
       LSD nlo = PICK(s_lo_next, lo_next, lo);
-      const bool s_lo_mid = !done && (mid.d0 < 0) && (nlo.d0 < mid.d0);
+      const bool s_lo_mid = !done & (mid.d0 < 0) & (nlo.d0 < mid.d0);
       { const LSD t = PICK(s_lo_mid, mid, nlo); nlo = t; }
-      const bool s_hi_next = !done && ((hi.d0 < 0) || (hi.d0 > hi_next.d0));
+      const bool s_hi_next = !done & ((hi.d0 < 0) | (hi.d0 > hi_next.d0));
       LSD nhi = PICK(s_hi_next, hi_next, hi);
-      const bool s_hi_mid = !done && (mid.d0 > 0) && (nhi.d0 > mid.d0);
+      const bool s_hi_mid = !done & (mid.d0 > 0) & (nhi.d0 > mid.d0);
       { const LSD t = PICK(s_hi_mid, mid, nhi); nhi = t; }
       lo = nlo; hi = nhi;
-      swap = s_lo_next || s_lo_mid || s_hi_next || s_hi_mid;
+      swap = s_lo_next | s_lo_mid | s_hi_next | s_hi_mid;
       return true;
     };
     // static trip count in the specialised kernels: fully unrolled (+1 %) while the body stays small (the reference pendulum's
@@ -2578,7 +2599,7 @@ struct Env {
       lo_cost = lo.alpha * lo.alpha * q2l + lo.alpha * q1l + (quad_value<0>(w) + gauss);
       hi_cost = hi.alpha * hi.alpha * q2h + hi.alpha * q1h + (quad_value<1>(w) + gauss);
     }
-    const bool improved = alive && ((lo_cost < p0_cost) || (hi_cost < p0_cost));
+    const bool improved = alive & ((lo_cost < p0_cost) | (hi_cost < p0_cost));
     const float alpha = lo_cost < hi_cost ? lo.alpha : hi.alpha;
     if (improved) {
       if (gl < nv) { dof(D_QACC, gl) += alpha * dof(D_SEARCH, gl); dof(D_MA, gl) += alpha * mv; }
@@ -2634,9 +2655,8 @@ struct Env {
         const float g_ = dof(D_GRAD, gl < nv ? gl : 0);
         const float g = gl < nv ? g_ : 0.0f;
         const float gn = gsum<G>(g * g);
-        bool done = (fdiv(prev_cost - cost, m.scale()) < m.tolerance());
-        done = done || (fdiv(sqrtf(gn), m.scale()) < m.tolerance());
-        alive = alive && !done;
+        const bool done = (fdiv(prev_cost - cost, m.scale()) < m.tolerance()) | (fdiv(sqrtf(gn), m.scale()) < m.tolerance());
+        alive = alive & !done;
       }
       if (!wave_any(alive)) break;
       PROF(12);

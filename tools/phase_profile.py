@@ -15,7 +15,7 @@ from bench import make_inputs
 NAMES = {0: "step head/ctrl", 1: "kinematics", 2: "com_pos+cinert+cdof", 3: "crb+M", 4: "collision", 5: "make_constraint",
          6: "com_vel+rne", 7: "smooth forces", 8: "factor M + qacc_smooth", 9: "solver init (warm/smooth cost)",
          10: "constraint force+grad", 11: "newton: chol H + solve", 12: "iter cond", 13: "linesearch", 14: "newton: assemble H",
-         15: "solve tail", 16: "euler: damp solve", 17: "euler: integrate", 18: "write xs row", 19: "  H: copy M", 20: "  crb: subtree up-scan", 21: "  ls: Mv, Jv, gauss sums", 22: "  ls: bracketing loop", 23: "  vel: joint sums + down-scan"}
+         15: "solve tail", 16: "euler: damp solve", 17: "euler: integrate", 18: "write xs row", 19: "  H: copy M", 20: "  crb: subtree up-scan", 21: "  ls: Mv, Jv, gauss sums", 22: "  ls: bracketing loop", 23: "  vel: joint sums + down-scan", 24: "  newton: before the matrix cores", 25: "  newton: J'DJ on the matrix cores", 26: "  newton: row assembly", 27: "  newton: elimination"}
 
 model_path = sys.argv[1] if len(sys.argv) > 1 else "models/quadruped/quadruped.xml"
 nenv = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
@@ -24,7 +24,7 @@ dev = torch.device("cuda", 0)
 mj = load_mj_model_from_file(model_path)
 model = mjx.put_model(mj, dev)
 x0, us = make_inputs(mj, nenv, steps, 1, 2, dev)
-prof = torch.zeros((nenv, 24), dtype=torch.float32, device=dev)
+prof = torch.zeros((nenv, 32), dtype=torch.float32, device=dev)
 L = _lib.lib()
 L.amx_prof_set.argtypes = [C.c_void_p]
 L.amx_prof_set(prof.data_ptr())
@@ -51,7 +51,7 @@ wpb = epb // epw
 if wpb > 1 and nenv % epb == 0:  # by position of the wave inside its workgroup: waves w and w + 4 share a SIMD
     by_idx = per_wave.reshape(-1, wpb).mean(axis=0)
     print("mean cycles per step by wave index in the workgroup: " + " ".join(f"{v:.0f}" for v in by_idx))
-for i in range(24):
+for i in range(32):
     v = p[:, i].mean()
     if v > 0:
         print(f"  {i:2d} {NAMES.get(i, '?'):34s} {v/steps:10.0f} cyc/step  {100*v/tot:5.1f}%")
