@@ -10,6 +10,14 @@
 #ifndef AMX_MIN_WAVES_PER_SIMD
 #define AMX_MIN_WAVES_PER_SIMD 2  // launch bound: 256 VGPRs.  4096 envs give at most 2 waves/SIMD at G=32 and LDS allows no more at G=64, and 168/128 spill
 #endif
+// Rotation of row i of a matrix stored with rotated 16-byte chunks (mrot; nch chunks per row): chunk c of row i sits at position
+// (c + AMX_ROW_ROT(i, nch)) mod nch.  A ds_read_b128 of a wave is served in four groups of sixteen lanes that are NOT
+// consecutive - {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 - and the sixteen rows of a group must fall into
+// sixteen different 4-bank slots.  With 32-float rows (nch = 8) the slot of lane i is 8 (i & 1) + (c + rot) mod 8: the rotation
+// (i >> 1) mod 8 makes the eight even and the eight odd lanes of every such group distinct; the plain i mod 8 of round 2 was
+// designed for eight CONSECUTIVE lanes and collided two ways in every group (r03 PMC: LDS bank-conflict cycles 12.8 % -> see
+// profiles/r03_rocprofv3_pmc_biped.csv).
+#define AMX_ROW_ROT(i, nch) ((((nch) == 8) ? ((i) >> 1) : (i)) % (nch))
 #define AMX_MAX_NV 32           // register-row solve capacity (one matrix row per lane, <=32 columns; one 32x32 MFMA block)
 
 // Record strides (floats) of the constant image.  All odd, so lane-per-record LDS reads are conflict free.

@@ -293,6 +293,9 @@ template <int G> DEV float rows_total(float x) {  // the cross-row steps of gsum
 // 16-lane groups have no row exchange behind the block: its results go straight to the consumers' DPP reads (quad_value), which
 // the compiler cannot pad for - it does not know the block's last instructions wrote them - so the block ends with the two
 // wait states itself; likewise in front of the lane swaps of the 32-lane row exchange
+#ifndef AMX_TREE_PACK
+#define AMX_TREE_PACK 7  // bits: 1 COM, 2 composite inertia, 4 force totals; 0: the tree phases' root sums (COM, composite inertia, force totals) as plain group sums (A/B switch)
+#endif
 #ifndef AMX_PACK_SWIZZLE
 #define AMX_PACK_SWIZZLE 0  // 1: the packed sums exchange their rows through the LDS crossbar like gsum (A/B switch)
 #endif
@@ -314,6 +317,32 @@ template <int G> DEV void gsum_pack6(float a0, float b0, float a1, float b1, flo
     u = rows_total<G>(u);
     w = rows_total<G>(w);
   }
+}
+#define AMX_PACK4_ASM(TAIL)                                                                          \
+  asm("s_nop 1\n\t"                                                                                    \
+      "v_add_f32_dpp %[ra], %[a0], %[a0] row_half_mirror row_mask:0xf bank_mask:0x9\n\t"               \
+      "v_add_f32_dpp %[rb], %[a1], %[a1] row_half_mirror row_mask:0xf bank_mask:0x9\n\t"               \
+      "v_add_f32_dpp %[ra], %[b0], %[b0] row_half_mirror row_mask:0xf bank_mask:0x6\n\t"               \
+      "v_add_f32_dpp %[rb], %[b1], %[b1] row_half_mirror row_mask:0xf bank_mask:0x6\n\t"               \
+      "s_nop 0\n\t"                                                                                    \
+      "v_add_f32_dpp %[u], %[ra], %[ra] row_mirror row_mask:0xf bank_mask:0x3\n\t"                     \
+      "v_add_f32_dpp %[u], %[rb], %[rb] row_mirror row_mask:0xf bank_mask:0xc\n\t"                     \
+      "s_nop 1\n\t"                                                                                    \
+      "v_add_f32_dpp %[u], %[u], %[u] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"              \
+      "s_nop 1\n\t"                                                                                    \
+      "v_add_f32_dpp %[u], %[u], %[u] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" TAIL               \
+      : [ra] "=&v"(ra), [rb] "=&v"(rb), [u] "=&v"(u)                                                    \
+      : [a0] "v"(a0), [b0] "v"(b0), [a1] "v"(a1), [b1] "v"(b1))
+// u: quads 0, 1, 2, 3 -> sums of a0, b0, b1, a1
+template <int G> DEV float gsum_pack4(float a0, float b0, float a1, float b1) {
+  float ra, rb, u;
+  if constexpr (G == 16 || (G == 32 && !AMX_PACK_SWIZZLE)) AMX_PACK4_ASM("\n\ts_nop 1");
+  else AMX_PACK4_ASM("");
+  if constexpr (G == 32 && !AMX_PACK_SWIZZLE) {
+    auto s1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(u), __float_as_uint(u), false, false);
+    return __uint_as_float(s1[0]) + __uint_as_float(s1[1]);
+  }
+  return rows_total<G>(u);
 }
 // r: quads 0, 1 -> sums of a, b (quads 3, 2 mirror them)
 template <int G> DEV float gsum_pack2(float a, float b) {
@@ -884,7 +913,7 @@ template <class S, int N, int G, bool TREE, bool GRADCOL = false>
 AMX_STATIC_SOLVE_ATTR bool newton_solve_fused(int M_off, int ld_, int n_, unsigned long long crows_, int row_base, int J_base, int ldc_, int slot_base_,
                                                 int rhs_off, int x_off, float dlim, int gl, int gb4, int rot, int bt_off, float flim = 0.0f, int ma_off = 0,
                                                 int fs_off = 0, int fcon_off = 0, bool store_ok = true, bool early_out = false, bool imp_done = false,
-                                                float scale = 1.0f, float tol = 0.0f, ProfCtx *pc = nullptr) {
+                                                float scale = 1.0f, float tol = 0.0f, ProfCtx *pc = nullptr, bool *group_done = nullptr) {
   if constexpr (sym_elim_ok<S, G>() && G == 32) {
     // crossbar-free elimination (see sym_pivot): b reaches lane N as a row through the staging vector at bt_off
     constexpr int NS = S::nv, lds_ = S::ldm, nchs = lds_ / 4;
@@ -915,6 +944,7 @@ AMX_STATIC_SOLVE_ATTR bool newton_solve_fused(int M_off, int ld_, int n_, unsign
       if (early_out) {
         const float gn = gsum<G>(owner ? b * b : 0.0f);
         const bool done = imp_done | (fdiv(sqrtf(gn), scale) < tol);  // `|`, `&`: no exec-mask branches (see linesearch)
+        if (group_done) *group_done = done;  // the caller's next iteration starts with this very test: it need not re-read the gradient
         if (!wave_any(store_ok & !done)) {  // store_ok is the group's `alive`
           if (owner) lds[dg] = d0;
           WSYNC();
@@ -1440,7 +1470,7 @@ struct Env {
     d_body = CI(dr); d_jnt = CI(dr + 1); d_kind = CI(dr + 2); d_axis = CI(dr + 3); d_root = CI(dr + 8); d_jadr = CI(dr + 9); d_limrow = CI(dr + 10);
     {
       const int nch = m.ldm() >> 2, i = lane < m.nv() ? lane : 0;
-      m_rot = m.mrot() ? i % nch : 0;
+      m_rot = m.mrot() ? AMX_ROW_ROT(i, nch) : 0;
       m_diag = moff(i, i);
     }
     aD = aAref = aJaref = aJv = cD = cAref = cJaref = cJv = rJ1 = rJ2 = 0.0f;
@@ -1466,7 +1496,7 @@ struct Env {
   DEV float &jnt(int f, int da) const { return lds[ebD + da * DOF_E + 6 + f]; }
   // float offset of M[i][j] inside the matrix block (rows may store their 16-byte chunks rotated, see amx_plan.h)
   DEV int moff(int i, int j) const {
-    const int nch = m.ldm() >> 2, rot = m.mrot() ? i % nch : 0;
+    const int nch = m.ldm() >> 2, rot = m.mrot() ? AMX_ROW_ROT(i, nch) : 0;
     return i * m.ldm() + 4 * (((j >> 2) + rot) % nch) + (j & 3);
   }
   DEV float &dof(int f, int i) const { return lds[ebD + i * DOF_E + f]; }
@@ -1636,8 +1666,13 @@ struct Env {
     }
     for (int r = 0; r < m.nroot(); ++r) {
       const bool mine = isb && b_root == r;
+#if AMX_TREE_PACK & 1
+      const float u_ = gsum_pack4<G>(mine ? xi.x * ms : 0.0f, mine ? xi.y * ms : 0.0f, mine ? ms : 0.0f, mine ? xi.z * ms : 0.0f);  // one packed reduction
+      const float sx = quad_value<0>(u_), sy = quad_value<1>(u_), sz = quad_value<2>(u_), sm = quad_value<3>(u_);
+#else
       float sx = gsum<G>(mine ? xi.x * ms : 0.0f), sy = gsum<G>(mine ? xi.y * ms : 0.0f), sz = gsum<G>(mine ? xi.z * ms : 0.0f),
             sm = gsum<G>(mine ? ms : 0.0f);
+#endif
       const int rb = CI(m.c_rootbody() + r);
       if (b == rb) {  // the root body itself writes the tree's COM
         const int o = eb + m.e_com() + 3 * r;
@@ -1723,7 +1758,19 @@ struct Env {
         const bool part = isb && b_root == rt && b_level <= 2;
         float tot[10];
 #pragma unroll
-        for (int k = 0; k < 10; ++k) tot[k] = gsum<G>(part ? r[k] : 0.0f);
+        for (int k = 0; k < 10; ++k) tot[k] = part ? r[k] : 0.0f;
+#if !(AMX_TREE_PACK & 2)
+        for (int k = 0; k < 10; ++k) tot[k] = gsum<G>(tot[k]);
+#else
+        {  // ten group sums as a packed six and a packed four
+          float u_, w_;
+          gsum_pack6<G>(tot[0], tot[1], tot[2], tot[3], tot[4], tot[5], u_, w_);
+          const float v_ = gsum_pack4<G>(tot[6], tot[7], tot[8], tot[9]);
+          tot[0] = quad_value<0>(u_); tot[1] = quad_value<1>(u_); tot[3] = quad_value<2>(u_); tot[2] = quad_value<3>(u_);
+          tot[4] = quad_value<0>(w_); tot[5] = quad_value<1>(w_);
+          tot[6] = quad_value<0>(v_); tot[7] = quad_value<1>(v_); tot[9] = quad_value<2>(v_); tot[8] = quad_value<3>(v_);
+        }
+#endif
         if (isb && !inner && b_root == rt) {
 #pragma unroll
           for (int k = 0; k < 10; ++k) r[k] = tot[k];
@@ -1898,7 +1945,17 @@ struct Env {
         const bool part = isb && b_root == rt && b_level <= 2;
         sv tot;
 #pragma unroll
-        for (int e = 0; e < 6; ++e) tot.v[e] = gsum<G>(part ? f.v[e] : 0.0f);
+        for (int e = 0; e < 6; ++e) tot.v[e] = part ? f.v[e] : 0.0f;
+#if !(AMX_TREE_PACK & 4)
+        for (int e = 0; e < 6; ++e) tot.v[e] = gsum<G>(tot.v[e]);
+#else
+        {
+          float u_, w_;
+          gsum_pack6<G>(tot.v[0], tot.v[1], tot.v[2], tot.v[3], tot.v[4], tot.v[5], u_, w_);
+          tot.v[0] = quad_value<0>(u_); tot.v[1] = quad_value<1>(u_); tot.v[3] = quad_value<2>(u_); tot.v[2] = quad_value<3>(u_);
+          tot.v[4] = quad_value<0>(w_); tot.v[5] = quad_value<1>(w_);
+        }
+#endif
         if (isb && !inner && b_root == rt) f = tot;
       }
       WSYNC();
@@ -2410,7 +2467,7 @@ struct Env {
   // G = 16 (four environments per wave do not map onto the two MFMA blocks): copy of M + atomics for every row kind.
   // returns true when (specialised fused path) the stopping test of the next iteration, evaluated inside, stops every group of the
   // wave: the direction was not computed and the caller must not iterate again
-  DEV bool newton_direction(bool alive = true, bool early_out = false, bool imp_done = false) {
+  DEV bool newton_direction(bool alive = true, bool early_out = false, bool imp_done = false, bool *group_done = nullptr) {
     const int nv = m.nv(), Mo = eb + m.e_M(), Ho = eb + m.e_H(), Jo = eb + m.e_J(), ldc = m.ldc(), ldm = m.ldm();
     const int row0 = m.neq() + m.nlim();
     if constexpr (G >= 32) {
@@ -2431,7 +2488,7 @@ struct Env {
         if constexpr (grad_in_solve())
           stop = newton_solve_fused<S, S::nv, G, S::tree_H, true>(Mo, ldm, nv, rows, eb + m.e_row() + row0 * ROW_E, Jo, ldc, m.c_slot(), dofoff(D_GRAD), dofoff(D_MGRAD), dlim, gl, gb4, m_rot,
                                                                  eb + m.e_H(), pend_flim, dofoff(D_MA), dofoff(D_FSMOOTH), dofoff(D_FCON), alive, early_out, imp_done, m.scale(),
-                                                                 m.tolerance(), pc);
+                                                                 m.tolerance(), pc, group_done);
         else if constexpr (S::is_static)
           newton_solve_fused<S, S::nv, G, S::tree_H>(Mo, ldm, nv, rows, eb + m.e_row() + row0 * ROW_E, Jo, ldc, m.c_slot(), dofoff(D_GRAD), dofoff(D_MGRAD), dlim, gl, gb4, m_rot, eb + m.e_H());
         else
@@ -2649,13 +2706,19 @@ struct Env {
     PROF(11);
     bool alive = true;  // per group: still iterating
     bool stop = false;  // wave-uniform: the stopping test evaluated inside newton_direction ended the solve
+    bool next_done = false, have_next = false;  // the stopping test of the coming iteration, when the fused solve has already made it
     for (int niter = 0; niter < m.iterations(); ++niter) {
       if (stop) break;
       if (m.iterations() != 1) {
-        const float g_ = dof(D_GRAD, gl < nv ? gl : 0);
-        const float g = gl < nv ? g_ : 0.0f;
-        const float gn = gsum<G>(g * g);
-        const bool done = (fdiv(prev_cost - cost, m.scale()) < m.tolerance()) | (fdiv(sqrtf(gn), m.scale()) < m.tolerance());
+        bool done;
+        if (grad_in_solve() && have_next) {
+          done = next_done;
+        } else {
+          const float g_ = dof(D_GRAD, gl < nv ? gl : 0);
+          const float g = gl < nv ? g_ : 0.0f;
+          const float gn = gsum<G>(g * g);
+          done = (fdiv(prev_cost - cost, m.scale()) < m.tolerance()) | (fdiv(sqrtf(gn), m.scale()) < m.tolerance());
+        }
         alive = alive & !done;
       }
       if (!wave_any(alive)) break;
@@ -2681,7 +2744,8 @@ struct Env {
           // the next iteration's stopping test needs this point's improvement (known) and gradient (formed inside the fused
           // solve): evaluated there, it saves the elimination when the wave is finished
           const bool imp_done = fdiv(prev_cost - cost, m.scale()) < m.tolerance();
-          stop = newton_direction(alive, m.iterations() != 1, imp_done);
+          stop = newton_direction(alive, m.iterations() != 1, imp_done, &next_done);
+          have_next = m.iterations() != 1;
           PROF(11);
           if (gl < nv) dof(D_SEARCH, gl) = -dof(D_MGRAD, gl);
         }

@@ -454,7 +454,7 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
   m.mrot = 0;
   if ((m.ldm / 4) % 2 == 0) { if (m.fusedH) m.mrot = 1; else m.ldm += 4; }
   auto moff = [&](int i, int j) {  // float offset of M[i][j] inside the matrix block
-    const int nch = m.ldm / 4, rot = m.mrot ? i % nch : 0;
+    const int nch = m.ldm / 4, rot = m.mrot ? AMX_ROW_ROT(i, nch) : 0;
     return i * m.ldm + 4 * ((j / 4 + rot) % nch) + (j & 3);
   };
   {

@@ -606,6 +606,21 @@ def test_random_models_vs_oracle(dev):
         ref32 = Oracle(mj, np.float32).rollout(x0, us)
         if not (np.isfinite(ref).all() and np.isfinite(ref32).all()) or np.abs(ref).max() > 100:
             continue
+        # Ill-posed environments are left out: where the fp64 oracle itself moves by more than 1e-3 under a 3e-7 relative change of
+        # its input (three draws), no fp32 result means anything - r03: seed 26, environment 4 jumps between |x| = 4 and 9.5 in
+        # fp64 and to NaN in the fp32 oracle under such a change (tools/dbg/dbg_seed2.py); which side of it an fp32 run lands
+        # on depends on its summation order.
+        prng = np.random.default_rng(1000 + seed)
+        sens = np.zeros(x0.shape[0])
+        for _ in range(3):
+            xp = (x0 * (1 + 3e-7 * prng.standard_normal(x0.shape))).astype(np.float32)
+            rp = Oracle(mj, np.float64).rollout(xp, us)
+            d = np.abs(np.nan_to_num(rp, nan=1e30) - ref).reshape(len(ref), -1).max(axis=1) / max(1.0, np.abs(ref).max())
+            sens = np.maximum(sens, d)
+        keep = sens < 1e-3
+        if keep.sum() < 4:
+            continue
+        x0, us, ref, ref32 = x0[keep], us[keep], ref[keep], ref32[keep]
         # every fifth draw runs on a 64-lane group (one environment per wave) whatever it needs: with two row slots per
         # lane no draw is large enough to ask for it by itself
         if seed % 5 == 0:
