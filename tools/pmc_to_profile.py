@@ -4,9 +4,9 @@ means plus the derived figures bench.py and DESIGN.md quote.  python tools/pmc_t
 import os, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
 G, waves, passes = 32, 2048, 1001  # 4096 envs x 1000 steps, two environments per wave
-model_arg = "" if tag == "quadruped" else f" --model models/{tag}/{tag}.xml"
+model_arg = "" if tag == "biped" else f" --model models/{tag}/{tag}.xml"  # the biped is bench.py's default workload since r03
 v = {}
 for line in open(os.path.join(root, "gpurun_out", f"pmc_{tag}_summary.csv")):
     p = line.strip().split(",")
@@ -24,6 +24,10 @@ cyc = v["GRBM_GUI_ACTIVE"] / 8
 out.append(f"valu_busy_frac,{4 * v['SQ_ACTIVE_INST_VALU'] / (1024 * cyc):.4f}")
 out.append(f"lds_busy_frac,{v['SQ_LDS_IDX_ACTIVE'] / (256 * cyc):.4f}")
 out.append(f"executed_fp32_flops,{64 * (2 * v['SQ_INSTS_VALU_FMA_F32'] + v['SQ_INSTS_VALU_ADD_F32'] + v['SQ_INSTS_VALU_MUL_F32'] + v['SQ_INSTS_VALU_TRANS_F32']):g}")
+if "SQ_LDS_BANK_CONFLICT" in v:
+    out.append(f"lds_bank_conflict_frac,{v['SQ_LDS_BANK_CONFLICT'] / v['SQ_LDS_IDX_ACTIVE']:.4f}")
+if "SQC_ICACHE_MISSES" in v and v.get("SQC_ICACHE_REQ"):
+    out.append(f"icache_miss_frac,{v['SQC_ICACHE_MISSES'] / v['SQC_ICACHE_REQ']:.2e}")
 for k in ("VALU", "SALU", "LDS", "VMEM"):
     out.append(f"insts_{k.lower()}_per_wave_step,{v['SQ_INSTS_' + k] / (waves * passes):.1f}")
 path = os.path.join(root, "profiles", f"{rnd}_rocprofv3_pmc_{tag}.csv")
