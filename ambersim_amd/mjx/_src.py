@@ -249,8 +249,13 @@ def forward(m: Model, d: Data) -> Data:
     s = (lambda t: t) if b else (lambda t: t[0])
     # the solver's result becomes the next warm start, as in the reference physics
     warm_out = qacc if m.nefc_max > 0 else warm
+    # every leaf of a batched Data carries the batch axis (as under jax.vmap), `time` included: a later step() returns [n] and the
+    # structure of the record must not change between calls (graph capture of the env step keeps persistent buffers per leaf)
+    time = d.time
+    if b and torch.is_tensor(time) and time.dim() == 0:
+        time = time.to(device=dev, dtype=torch.float32).expand(n).clone()
     return d.replace(qacc=s(qacc), qacc_smooth=s(qs), qfrc_bias=s(fb), qfrc_constraint=s(fc), xpos=s(xpos), xquat=s(xquat),
-                     qacc_warmstart=s(warm_out), qvel=s(qvel), ctrl=s(ctrl))
+                     qacc_warmstart=s(warm_out), qvel=s(qvel), ctrl=s(ctrl), time=time)
 
 
 def step(m: Model, d: Data, nsub: int = 1) -> Data:

@@ -34,6 +34,11 @@ class PendulumSwingupEnv(MjxEnv):
         mj_model = load_mj_model_from_file(self.config.model_path)
         super().__init__(mj_model, self.config.physics_steps_per_control_step, num_envs, device)
 
+    @property
+    def graph_capturable(self) -> bool:
+        """step() issues device work only (no draw from a host-side generator): it can be captured in a HIP graph."""
+        return self.config.stdev_obs == 0.0
+
     def compute_obs(self, data: mjx.Data, info: Dict[str, Any]) -> torch.Tensor:
         theta = data.qpos[..., 0]
         return torch.stack((torch.cos(theta), torch.sin(theta), data.qvel[..., 0]), dim=-1)
@@ -53,7 +58,7 @@ class PendulumSwingupEnv(MjxEnv):
         data = self.pipeline_init(u(c.qpos_lo, c.qpos_hi, self.sys.nq), u(c.qvel_lo, c.qvel_hi, self.sys.nv))
         obs = self.compute_obs(data, {})
         reward, done = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
-        return State(data, obs, reward, done, {"reward": reward}, {"rng": rng, "step": 0})
+        return State(data, obs, reward, done, {"reward": reward}, {"rng": rng, "step": torch.zeros((), device=dev)})
 
     def step(self, state: State, action: torch.Tensor) -> State:
         """physics + observation (+ noise) + reward; done is always 0 (reference :106-122)."""
@@ -63,6 +68,6 @@ class PendulumSwingupEnv(MjxEnv):
         if self.config.stdev_obs != 0.0:
             obs = obs + torch.randn(obs.shape, generator=rng, device=obs.device, dtype=obs.dtype) * self.config.stdev_obs
         reward = self.compute_reward(data, state.info)
-        state.info["step"] = state.info["step"] + 1
-        state.metrics["reward"] = reward
-        return state.replace(pipeline_state=data, obs=obs, reward=reward, done=torch.zeros_like(reward))
+        # functional update: the caller's State (and the dicts it holds) is left as it was - a captured graph re-reads its inputs
+        info = dict(state.info, step=state.info["step"] + 1)  # a device counter: no host arithmetic inside a step
+        return state.replace(pipeline_state=data, obs=obs, reward=reward, done=torch.zeros_like(reward), metrics=dict(state.metrics, reward=reward), info=info)

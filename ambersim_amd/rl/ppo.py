@@ -19,36 +19,45 @@ from ambersim_amd.rl.wrappers import EpisodeAutoReset
 
 
 class RunningStatistics:
-    """Running mean / std of observations (brax `running_statistics`), clipped like brax's normaliser."""
+    """Running mean / std of observations (brax `running_statistics`), clipped like brax's normaliser.  All tensors are
+    updated IN PLACE (a captured HIP graph holds their addresses): `mean_f` / `std_f` are the float32 copies `normalize` reads."""
 
     def __init__(self, size: int, device=None, max_abs_value: float = 5.0, min_std: float = 1e-6):
         self.count = torch.zeros((), device=device, dtype=torch.float64)
         self.mean = torch.zeros(size, device=device, dtype=torch.float64)
         self.m2 = torch.zeros(size, device=device, dtype=torch.float64)
+        self.mean_f = torch.zeros(size, device=device, dtype=torch.float32)
+        self.std_f = torch.full((size,), float(min_std), device=device, dtype=torch.float32)
         self.max_abs_value, self.min_std = max_abs_value, min_std
+
+    def _refresh(self):
+        self.mean_f.copy_(self.mean)
+        self.std_f.copy_(self.std)
 
     def update(self, batch: torch.Tensor):
         b = batch.reshape(-1, batch.shape[-1]).to(torch.float64)
         n = b.shape[0]
         tot = self.count + n
         delta = b.mean(0) - self.mean
-        self.m2 = self.m2 + ((b - b.mean(0)) ** 2).sum(0) + delta ** 2 * self.count * n / tot
-        self.mean = self.mean + delta * n / tot
-        self.count = tot
+        self.m2.add_(((b - b.mean(0)) ** 2).sum(0) + delta ** 2 * self.count * n / tot)
+        self.mean.add_(delta * n / tot)
+        self.count.copy_(tot)
+        self._refresh()
 
     @property
     def std(self):
         return torch.sqrt(self.m2 / torch.clamp(self.count, min=1.0)).clamp(min=self.min_std)
 
     def normalize(self, obs: torch.Tensor) -> torch.Tensor:
-        out = (obs - self.mean.to(obs.dtype)) / self.std.to(obs.dtype)
+        out = (obs - self.mean_f.to(obs.dtype)) / self.std_f.to(obs.dtype)
         return out.clamp(-self.max_abs_value, self.max_abs_value)
 
     def state_dict(self):
         return {"count": self.count, "mean": self.mean, "m2": self.m2}
 
     def load_state_dict(self, d):
-        self.count, self.mean, self.m2 = d["count"], d["mean"], d["m2"]
+        self.count.copy_(d["count"]); self.mean.copy_(d["mean"]); self.m2.copy_(d["m2"])
+        self._refresh()
 
 
 @dataclass
@@ -81,8 +90,139 @@ class PPOResult:
             self.normalizer.load_state_dict({k: v.to(dev) for k, v in d["normalizer"].items()})
 
 
+# --------------------------------------------------------------------------------------------- device-resident stepping
+# The reference's training step is one fused device program: brax jit-compiles the unroll (policy + env.step, scanned) and the
+# SGD epochs, and nothing returns to the host in between (reference examples/rl/pendulum/ex_swingup.py:25-43 -> brax ppo.train;
+# ambersim/rl/base.py:88-96 is a lax.scan).  The counterpart here: the same Python code is run ONCE under HIP-graph capture
+# (torch.cuda.CUDAGraph) and replayed - `unroll_length` x {policy MLP, env.step (amx_step_to through the C ABI), observation,
+# reward, episode bookkeeping, auto reset} is one graph launch, a minibatch update (forward, backward, Adam) another.  Eager
+# execution remains (use_graphs=False, CPU tests of the host logic, envs that draw observation noise from a torch.Generator).
+def _leaves(x, out=None):
+    """Tensor leaves of a State / Data / dict / list, in a fixed order."""
+    out = [] if out is None else out
+    if torch.is_tensor(x):
+        out.append(x)
+    elif isinstance(x, dict):
+        for k in sorted(x):
+            _leaves(x[k], out)
+    elif isinstance(x, (list, tuple)):
+        for v in x:
+            _leaves(v, out)
+    elif hasattr(x, "__slots__") and not isinstance(x, torch.Generator):
+        for k in x.__slots__:
+            _leaves(getattr(x, k), out)
+    elif hasattr(x, "pipeline_state"):  # State
+        for k in ("pipeline_state", "obs", "reward", "done", "metrics", "info"):
+            _leaves(getattr(x, k), out)
+    return out
+
+
+def _persist(state):
+    """A State whose tensor leaves are private contiguous buffers (the graphs read and rewrite them in place)."""
+    def clone(x):
+        if torch.is_tensor(x):
+            return x.clone().contiguous()
+        if isinstance(x, dict):
+            return {k: clone(v) for k, v in x.items()}
+        if isinstance(x, (list, tuple)):
+            return type(x)(clone(v) for v in x)
+        if hasattr(x, "__slots__") and not isinstance(x, torch.Generator):
+            return type(x)(**{k: clone(getattr(x, k)) for k in x.__slots__})
+        if hasattr(x, "pipeline_state"):
+            return type(x)(clone(x.pipeline_state), clone(x.obs), clone(x.reward), clone(x.done), clone(x.metrics), clone(x.info))
+        return x
+    return clone(state)
+
+
+def _write_back(dst, src):
+    """dst leaves <- src leaves (same structure), in place; leaves that are already the same buffer are skipped."""
+    a, b = _leaves(dst), _leaves(src)
+    assert len(a) == len(b), "the env changed the structure of its State inside a step"
+    for d, v in zip(a, b):
+        if d.data_ptr() != v.data_ptr() or d.shape != v.shape:
+            d.copy_(v.expand_as(d) if v.shape != d.shape else v)
+
+
+class _Replayable:
+    """`fn()` (no arguments, works on persistent buffers) run eagerly, or captured once as a HIP graph and replayed."""
+
+    def __init__(self, fn: Callable[[], None], use_graph: bool, device, warmup: int = 0):
+        self.fn, self.graph = fn, None
+        if use_graph:
+            side = torch.cuda.Stream(device=device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    fn()
+            torch.cuda.current_stream(device).wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                fn()
+
+    def __call__(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self.fn()
+
+
+def graphs_available(environment, device) -> bool:
+    """HIP graphs apply when the env lives on a GPU and its step draws nothing from a host-side torch.Generator."""
+    return torch.device(device).type == "cuda" and bool(getattr(environment, "graph_capturable", False))
+
+
+class Evaluator:
+    """`episode_length` steps of the deterministic (or sampled) policy in every env of `env`; the steps run in chunks of
+    `chunk` captured as one graph."""
+
+    def __init__(self, env, nets, norm, episode_length: int, deterministic: bool, use_graph: bool, chunk: int = 20):
+        self.env, self.n = env, episode_length
+        dev = env.sys.device
+        dist = nets.parametric_action_distribution
+        self.chunk = max(1, min(chunk, episode_length))
+        while episode_length % self.chunk:
+            self.chunk -= 1
+        self.state = None
+        self.total = None
+        self.noise = None if deterministic else torch.zeros((self.chunk, env.num_envs, env.action_size), device=dev)
+
+        def body():
+            s = self.state
+            tot = self.total
+            for t in range(self.chunk):
+                x = norm.normalize(s.obs) if norm is not None else s.obs
+                params = nets.policy_network(x)
+                if deterministic:
+                    act = dist.mode(params)
+                else:
+                    loc, scale = dist._split(params)
+                    act = dist.postprocess(loc + scale * self.noise[t])
+                s = env.step(s, act)
+                tot = tot + s.reward
+            _write_back(self.state, s)
+            self.total.copy_(tot)
+        self._body, self._use_graph, self._run = body, use_graph, None
+
+    def __call__(self, seed: int) -> float:
+        dev = self.env.sys.device
+        rng = torch.Generator(device=dev).manual_seed(seed)
+        with torch.no_grad():
+            s0 = self.env.reset(rng)
+            if self.state is None:
+                self.state = _persist(s0)
+                self.total = torch.zeros_like(s0.reward)
+                self._run = _Replayable(self._body, self._use_graph, dev, warmup=1 if self._use_graph else 0)
+            _write_back(self.state, s0)
+            self.total.zero_()
+            for _ in range(self.n // self.chunk):
+                if self.noise is not None:
+                    self.noise.normal_(generator=rng)
+                self._run()
+        return float(self.total.mean().item())
+
+
 def evaluate(env, policy, episode_length: int, seed: int) -> float:
-    """Mean undiscounted return of `policy` over one episode in every env of `env` (brax's `eval/episode_reward`)."""
+    """Mean undiscounted return of `policy` over one episode in every env of `env` (brax's `eval/episode_reward`).  Eager."""
     rng = torch.Generator(device=env.sys.device).manual_seed(seed)
     s = env.reset(rng)
     total = torch.zeros_like(s.reward)
@@ -92,17 +232,57 @@ def evaluate(env, policy, episode_length: int, seed: int) -> float:
     return float(total.mean().item())
 
 
+class Collector:
+    """One unroll: `unroll_length` x {policy, env.step} from every env, results in persistent [T, N, ...] buffers."""
+
+    def __init__(self, env, nets, norm, unroll_length: int, reward_scaling: float, state, use_graph: bool):
+        self.T = unroll_length
+        dev = env.sys.device
+        dist = nets.parametric_action_distribution
+        N, A, O = state.obs.shape[0], env.action_size, state.obs.shape[-1]
+        f = lambda *sh: torch.zeros(sh, device=dev)
+        self.state = _persist(state)
+        self.noise = f(self.T, N, A)
+        self.obs, self.raw, self.logp, self.rew = f(self.T, N, O), f(self.T, N, A), f(self.T, N), f(self.T, N)
+        self.done, self.trunc, self.nobs = f(self.T, N), f(self.T, N), f(self.T, N, O)
+
+        def body():
+            s = self.state
+            for t in range(self.T):
+                obs = s.obs
+                x = norm.normalize(obs) if norm is not None else obs
+                params = nets.policy_network(x)
+                loc, scale = dist._split(params)
+                raw = loc + scale * self.noise[t]
+                self.obs[t].copy_(obs)  # before env.step: the wrapper may hand the same buffer back
+                s = env.step(s, dist.postprocess(raw))
+                self.raw[t].copy_(raw); self.logp[t].copy_(dist.log_prob(params, raw))
+                self.rew[t].copy_(s.reward * reward_scaling); self.done[t].copy_(s.done); self.trunc[t].copy_(s.info["truncation"])
+                self.nobs[t].copy_(s.info["terminal_obs"])
+            _write_back(self.state, s)
+        self._run = _Replayable(body, use_graph, dev, warmup=0)  # no warm-up run: it would advance the envs (capture does not execute)
+
+    def __call__(self, gen: torch.Generator):
+        self.noise.normal_(generator=gen)
+        self._run()
+        return self
+
+
 def train(environment, num_timesteps: int, episode_length: int, num_envs: int = 1, num_evals: int = 1, action_repeat: int = 1,
           unroll_length: int = 10, batch_size: int = 32, num_minibatches: int = 16, num_updates_per_batch: int = 2, learning_rate: float = 1e-4,
           entropy_cost: float = 1e-4, discounting: float = 0.9, reward_scaling: float = 1.0, normalize_observations: bool = False,
           clipping_epsilon: float = 0.3, gae_lambda: float = 0.95, seed: int = 0, network_factory: Callable = make_ppo_networks,
-          progress_fn: Callable = lambda *a: None, eval_env=None, deterministic_eval: bool = True) -> PPOResult:
+          progress_fn: Callable = lambda *a: None, eval_env=None, deterministic_eval: bool = True, use_graphs: Optional[bool] = None) -> PPOResult:
     """Argument names and defaults follow brax's `ppo.train` as called by the reference example.  `environment` must be
-    built with `num_envs` parallel envs; `eval_env` (optional, same class) is used for the `num_evals` evaluations."""
+    built with `num_envs` parallel envs; `eval_env` (optional, same class) is used for the `num_evals` evaluations.
+    `use_graphs` (default: whenever the env allows it, see graphs_available): unrolls, evaluation chunks and minibatch updates
+    run as replayed HIP graphs - no host round trip inside an unroll, as in the reference's jitted training step."""
     env = EpisodeAutoReset(environment, episode_length, action_repeat)
     assert environment.num_envs == num_envs, "build the environment with num_envs parallel envs"
     assert (batch_size * num_minibatches) % num_envs == 0, "batch_size * num_minibatches must be a multiple of num_envs"
     dev = environment.sys.device
+    if use_graphs is None:
+        use_graphs = graphs_available(environment, dev)
     torch.manual_seed(seed)
     gen = torch.Generator(device=dev).manual_seed(seed)
     obs_size, act_size = environment.observation_size, environment.action_size
@@ -111,48 +291,70 @@ def train(environment, num_timesteps: int, episode_length: int, num_envs: int = 
     dist = nets.parametric_action_distribution
     norm = RunningStatistics(obs_size, dev) if normalize_observations else None
     nets.policy_network(torch.zeros((1, obs_size), device=dev)); nets.value_network(torch.zeros((1, obs_size), device=dev))  # materialise lazy layers
-    opt = torch.optim.Adam(list(nets.policy_network.parameters()) + list(nets.value_network.parameters()), lr=learning_rate)
+    graph_updates = use_graphs and not entropy_cost  # the entropy estimate draws from the generator
+    params_all = list(nets.policy_network.parameters()) + list(nets.value_network.parameters())
+    opt = torch.optim.Adam(params_all, lr=learning_rate, capturable=bool(graph_updates))
 
     env_steps_per_training_step = batch_size * unroll_length * num_minibatches * action_repeat
     num_evals_after_init = max(num_evals - 1, 1)
     training_steps_per_epoch = max(1, math.ceil(num_timesteps / (num_evals_after_init * env_steps_per_training_step)))
     unrolls_per_step = batch_size * num_minibatches // num_envs
     result = PPOResult(nets, norm, [])
+    e_env = eval_env if eval_env is not None else environment
+    evaluator = Evaluator(e_env, nets, norm, episode_length // action_repeat, deterministic_eval, use_graphs and graphs_available(e_env, dev))
 
     def run_eval(steps_done, t0):
-        e = eval_env if eval_env is not None else environment
-        r = evaluate(e, result.make_inference_fn(deterministic_eval), episode_length // action_repeat, seed + 1)
+        r = evaluator(seed + 1)
         m = {"eval/episode_reward": r, "walltime": time.time() - t0}
         result.metrics.append((steps_done, m))
         progress_fn(steps_done, m)
 
     t0 = time.time()
-    state = env.reset(gen)
+    with torch.no_grad():
+        collector = Collector(env, nets, norm, unroll_length, reward_scaling, env.reset(gen), use_graphs)
     if num_evals > 1:
         run_eval(0, t0)
+
+    # persistent batch buffers of one training step: [T, U*N, ...] -> flattened [n, ...]
+    T, U, N = unroll_length, unrolls_per_step, num_envs
+    n = T * U * N
+    mb = n // num_minibatches
+    f = lambda *sh: torch.zeros(sh, device=dev)
+    obs_t, raw_t, logp_t, rew_t = f(T, U * N, obs_size), f(T, U * N, act_size), f(T, U * N), f(T, U * N)
+    done_t, trunc_t, nobs_t = f(T, U * N), f(T, U * N), f(T, U * N, obs_size)
+    obs_f, raw_f, logp_f, adv_f, tgt_f = f(n, obs_size), f(n, act_size), f(n), f(n), f(n)
+    idx = torch.zeros(mb, dtype=torch.int64, device=dev)
+
+    def update_body():
+        """One clipped-surrogate minibatch update on the rows `idx` of the flattened batch."""
+        o = obs_f.index_select(0, idx)
+        params = nets.policy_network(o)
+        logp = dist.log_prob(params, raw_f.index_select(0, idx))
+        ratio = torch.exp(logp - logp_f.index_select(0, idx))
+        a = adv_f.index_select(0, idx)
+        policy_loss = -torch.minimum(ratio * a, ratio.clamp(1 - clipping_epsilon, 1 + clipping_epsilon) * a).mean()
+        v = nets.value_network(o).squeeze(-1)
+        value_loss = 0.5 * 0.5 * ((tgt_f.index_select(0, idx) - v) ** 2).mean()
+        loss = policy_loss + value_loss
+        if entropy_cost:
+            loss = loss - entropy_cost * dist.entropy(params, gen).mean()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+
+    update, eager_updates = None, 0  # the graph is captured after three eager (real) updates on a side stream, as torch's capture recipe asks
+    side = torch.cuda.Stream(device=dev) if graph_updates else None
+
     steps_done = 0
     for _ in range(num_evals_after_init):
         for _ in range(training_steps_per_epoch):
             # ---- collect unrolls_per_step x unroll_length transitions from every env
-            obs_b, raw_b, logp_b, rew_b, done_b, trunc_b, boot_b = [], [], [], [], [], [], []
             with torch.no_grad():
-                for _u in range(unrolls_per_step):
-                    o_l, a_l, lp_l, r_l, d_l, tr_l, nobs_l = [], [], [], [], [], [], []
-                    for _t in range(unroll_length):
-                        obs = state.obs
-                        x = norm.normalize(obs) if norm is not None else obs
-                        params = nets.policy_network(x)
-                        raw = dist.sample_raw(params, gen)
-                        state = env.step(state, dist.postprocess(raw))
-                        o_l.append(obs); a_l.append(raw); lp_l.append(dist.log_prob(params, raw))
-                        r_l.append(state.reward * reward_scaling); d_l.append(state.done); tr_l.append(state.info["truncation"])
-                        nobs_l.append(state.info["terminal_obs"])
-                    obs_b.append(torch.stack(o_l)); raw_b.append(torch.stack(a_l)); logp_b.append(torch.stack(lp_l))
-                    rew_b.append(torch.stack(r_l)); done_b.append(torch.stack(d_l)); trunc_b.append(torch.stack(tr_l))
-                    boot_b.append(torch.stack(nobs_l))
-                # [T, U*N, ...]
-                cat = lambda xs: torch.cat(xs, dim=1)
-                obs_t, raw_t, logp_t, rew_t, done_t, trunc_t, nobs_t = map(cat, (obs_b, raw_b, logp_b, rew_b, done_b, trunc_b, boot_b))
+                for u in range(U):
+                    c = collector(gen)
+                    sl = slice(u * N, (u + 1) * N)
+                    obs_t[:, sl].copy_(c.obs); raw_t[:, sl].copy_(c.raw); logp_t[:, sl].copy_(c.logp); rew_t[:, sl].copy_(c.rew)
+                    done_t[:, sl].copy_(c.done); trunc_t[:, sl].copy_(c.trunc); nobs_t[:, sl].copy_(c.nobs)
                 if norm is not None:
                     norm.update(obs_t)
                 nx = lambda o: norm.normalize(o) if norm is not None else o
@@ -168,28 +370,28 @@ def train(environment, num_timesteps: int, episode_length: int, num_envs: int = 
                     adv[t] = acc
                 targets = adv + values
                 flat = lambda z: z.reshape((-1,) + z.shape[2:])
-                obs_f, raw_f, logp_f, adv_f, tgt_f = map(flat, (nx(obs_t), raw_t, logp_t, adv, targets))
-                adv_f = (adv_f - adv_f.mean()) / (adv_f.std() + 1e-8)
+                obs_f.copy_(flat(nx(obs_t))); raw_f.copy_(flat(raw_t)); logp_f.copy_(flat(logp_t)); tgt_f.copy_(flat(targets))
+                a_ = flat(adv)
+                adv_f.copy_((a_ - a_.mean()) / (a_.std() + 1e-8))
             steps_done += env_steps_per_training_step
             # ---- updates: minibatches of batch_size * unroll_length transitions
-            n = obs_f.shape[0]
-            mb = n // num_minibatches
             for _e in range(num_updates_per_batch):
                 perm = torch.randperm(n, device=dev, generator=gen)
                 for k in range(num_minibatches):
-                    idx = perm[k * mb:(k + 1) * mb]
-                    params = nets.policy_network(obs_f[idx])
-                    logp = dist.log_prob(params, raw_f[idx])
-                    ratio = torch.exp(logp - logp_f[idx])
-                    a = adv_f[idx]
-                    policy_loss = -torch.minimum(ratio * a, ratio.clamp(1 - clipping_epsilon, 1 + clipping_epsilon) * a).mean()
-                    v = nets.value_network(obs_f[idx]).squeeze(-1)
-                    value_loss = 0.5 * 0.5 * ((tgt_f[idx] - v) ** 2).mean()
-                    loss = policy_loss + value_loss
-                    if entropy_cost:
-                        loss = loss - entropy_cost * dist.entropy(params, gen).mean()
-                    opt.zero_grad(set_to_none=True)
-                    loss.backward()
-                    opt.step()
+                    idx.copy_(perm[k * mb:(k + 1) * mb])
+                    if not graph_updates:
+                        update_body()
+                    elif update is not None:
+                        update()
+                    elif eager_updates < 3:
+                        side.wait_stream(torch.cuda.current_stream(dev))
+                        with torch.cuda.stream(side):
+                            update_body()
+                        torch.cuda.current_stream(dev).wait_stream(side)
+                        eager_updates += 1
+                    else:
+                        opt.zero_grad(set_to_none=True)
+                        update = _Replayable(update_body, True, dev, warmup=0)  # capture executes nothing: replay it for this minibatch
+                        update()
         run_eval(steps_done, t0)
     return result

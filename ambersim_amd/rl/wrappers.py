@@ -37,28 +37,35 @@ class EpisodeAutoReset:
         s.info["episode_return"] = torch.zeros(n, device=dev)
         s.info["last_episode_return"] = torch.zeros(n, device=dev)
         s.info["episodes"] = torch.zeros(n, device=dev)
+        s.info["terminal_obs"] = s.obs.clone()  # present from the start: the State keeps one structure (graph capture)
         return s
 
     def step(self, state: State, action: torch.Tensor) -> State:
-        info = state.info
+        """Functional: `state` and its dicts are not modified (the PPO loop replays this code as a HIP graph on persistent
+        buffers; an in-place edit of the input's info would alias the graph's inputs and outputs)."""
+        info = dict(state.info)
         total = torch.zeros_like(state.reward)
         s = state
         for _ in range(self.action_repeat):
             s = self.env.step(s, action)
             total = total + s.reward
-        steps = info["steps"] + self.action_repeat
+        info.update({k: v for k, v in s.info.items() if k not in info or k in ("step", "rng")})
+        steps = state.info["steps"] + self.action_repeat
         trunc = (steps >= self.episode_length).to(s.reward.dtype)
         done = torch.maximum(s.done, trunc)
-        ret = info["episode_return"] + total
-        info["last_episode_return"] = torch.where(done > 0, ret, info["last_episode_return"])
-        info["episodes"] = info["episodes"] + done
-        info["episode_return"] = torch.where(done > 0, torch.zeros_like(ret), ret)
+        fin = done > 0
+        ret = state.info["episode_return"] + total
+        info["last_episode_return"] = torch.where(fin, ret, state.info["last_episode_return"])
+        info["episodes"] = state.info["episodes"] + done
+        info["episode_return"] = torch.where(fin, torch.zeros_like(ret), ret)
         info["truncation"] = trunc * (1 - s.done)
-        info["steps"] = torch.where(done > 0, torch.zeros_like(steps), steps)
+        info["steps"] = torch.where(fin, torch.zeros_like(steps), steps)
         # auto reset: finished envs continue from their first state; the transition keeps this step's reward and done
-        first, cur = info["first_pipeline_state"], s.pipeline_state
-        fields = {f: _blend(done, getattr(first, f), getattr(cur, f)) for f in cur.__slots__}
+        first, cur = state.info["first_pipeline_state"], s.pipeline_state
+        # only the fields a step reads: the derived ones (qacc_smooth, qfrc_bias, xpos, ...) are not recomputed by mjx.step and are
+        # stale pass-throughs in `cur` either way
+        fields = {f: _blend(done, getattr(first, f), getattr(cur, f)) for f in ("qpos", "qvel", "ctrl", "qacc_warmstart", "time")}
         data = cur.replace(**{k: v for k, v in fields.items() if v is not None})
         info["terminal_obs"] = s.obs  # observation before the reset, for bootstrapping truncated episodes
-        obs = _blend(done, info["first_obs"], s.obs)
-        return s.replace(pipeline_state=data, obs=obs, reward=total, done=done)
+        obs = _blend(done, state.info["first_obs"], s.obs)
+        return s.replace(pipeline_state=data, obs=obs, reward=total, done=done, info=info)

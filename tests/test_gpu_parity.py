@@ -584,6 +584,42 @@ def test_episode_wrapper_and_ppo_improves_pendulum_reward(dev):
     assert rewards[-1] > rewards[0] + 50.0, rewards
 
 
+def test_unroll_as_hip_graph_matches_eager(dev):
+    """A1 as the reference runs it - no host round trip inside an unroll (reference ambersim/rl/base.py:88-96 is a lax.scan inside
+    brax's jitted training step): ten steps of {policy MLP, env.step = amx_step_to through the C ABI, observation, reward,
+    episode bookkeeping, auto reset} are captured as ONE HIP graph (torch.cuda.CUDAGraph) and replayed.  The replays must
+    reproduce eager execution bit for bit - trajectories and the carried state, across an episode boundary (auto reset)."""
+    from ambersim_amd.rl import ppo
+    from ambersim_amd.rl.helpers import make_ppo_networks
+    from ambersim_amd.rl.pendulum.swingup import PendulumSwingupEnv
+    from ambersim_amd.rl.wrappers import EpisodeAutoReset
+    env = PendulumSwingupEnv(num_envs=256, device=dev)
+    assert ppo.graphs_available(env, dev)
+    w = EpisodeAutoReset(env, episode_length=25)  # three unrolls of ten cross a reset
+    torch.manual_seed(0)
+    nets = make_ppo_networks(3, 1, policy_hidden_layer_sizes=(64,) * 3)
+    nets.policy_network.to(dev); nets.value_network.to(dev)
+    nets.policy_network(torch.zeros(1, 3, device=dev))
+    norm = ppo.RunningStatistics(3, dev)
+    norm.update(torch.randn(512, 3, device=dev))
+    with torch.no_grad():
+        s0 = w.reset(torch.Generator(device=dev).manual_seed(1))
+        eager = ppo.Collector(w, nets, norm, 10, 0.1, s0, use_graph=False)
+        graph = ppo.Collector(w, nets, norm, 10, 0.1, s0, use_graph=True)
+        assert graph._run.graph is not None and eager._run.graph is None
+        g1, g2 = torch.Generator(device=dev).manual_seed(2), torch.Generator(device=dev).manual_seed(2)
+        resets = 0
+        for rep in range(4):
+            a, b = eager(g1), graph(g2)
+            for name in ("obs", "raw", "logp", "rew", "done", "trunc", "nobs"):
+                assert torch.equal(getattr(a, name), getattr(b, name)), (rep, name)
+            for x, y in zip(ppo._leaves(a.state), ppo._leaves(b.state)):
+                assert torch.equal(x, y), rep
+            resets += int(a.done.sum().item())
+        assert resets == 256  # every env was reset once inside the captured unrolls
+        assert float(a.state.info["step"].item()) == 40.0  # the env's own counter lives on the device and advances in replays
+
+
 def test_random_models_vs_oracle(dev):
     """Fuzz parity: 40 seeded random trees (tests/fuzz_models.py: free/ball/hinge/slide joints, several roots, limits,
     springs, armature, motors and position servos, a polynomial joint equality, sphere/capsule contacts, Newton and CG with
