@@ -20,12 +20,12 @@ def shoot(m: mjx.Model, x0: torch.Tensor, us: torch.Tensor) -> torch.Tensor:
 
 @dataclass
 class ShootingParams(TrajectoryOptimizerParams):
-    x0: torch.Tensor = None        # (nq+nv,)
-    us_guess: torch.Tensor = None  # (N, nu)
+    x0: torch.Tensor = None        # (nq+nv,), or (B, nq+nv) for a batch of problems
+    us_guess: torch.Tensor = None  # (N, nu), or (B, N, nu)
 
     @property
     def N(self) -> int:
-        return self.us_guess.shape[0]
+        return self.us_guess.shape[-2]
 
 
 class ShootingAlgorithm(TrajectoryOptimizer):
@@ -35,7 +35,7 @@ class ShootingAlgorithm(TrajectoryOptimizer):
 
 @dataclass
 class VanillaPredictiveSamplerParams(ShootingParams):
-    key: Optional[torch.Generator] = None  # random generator for sampling (the reference passes a JAX PRNG key)
+    key: Optional[torch.Generator] = None  # random generator for sampling (the reference passes a JAX PRNG key); a batch may pass one per problem
 
 
 @dataclass
@@ -47,17 +47,36 @@ class VanillaPredictiveSampler(ShootingAlgorithm):
     stdev: float = 0.0
 
     def optimize(self, params: VanillaPredictiveSamplerParams) -> Tuple[torch.Tensor, torch.Tensor]:
+        """One problem - x0 [nx], us_guess [N, nu] -> (xs [N+1, nx], us [N, nu]) - or a BATCH of problems in one call: x0 [B, nx],
+        us_guess [B, N, nu] -> (xs [B, N+1, nx], us [B, N, nu]), the reference's `vmap(ps.optimize)(params)` (reference
+        tests/trajopt/test_predictive_sampler.py:78).  A batch is ONE fused rollout launch of B * nsamples environments (each
+        problem's samples start from its own x0: amx_rollout with per-environment initial states), one cost launch, and the
+        winners are picked on the device (argmin + gather): nothing returns to the host in between."""
         m, dev = self.model, self.model.device
         x0 = params.x0.to(device=dev, dtype=torch.float32)
         us_guess = params.us_guess.to(device=dev, dtype=torch.float32)
-        N = params.N
-        # the first sample is the guess itself (reference :140-143)
-        noise = torch.randn((self.nsamples - 1, N, m.nu), generator=params.key, device=dev, dtype=torch.float32) * self.stdev
-        noise = torch.cat((torch.zeros((1, N, m.nu), device=dev), noise), dim=0)
-        us_samples = us_guess.unsqueeze(0) + noise
+        batched = us_guess.dim() == 3
+        if not batched:
+            x0, us_guess = x0.unsqueeze(0), us_guess.unsqueeze(0)
+        if x0.dim() != 2 or x0.shape[0] != us_guess.shape[0] or us_guess.shape[2] != m.nu:
+            raise ValueError(f"optimize: x0 {tuple(params.x0.shape)} and us_guess {tuple(params.us_guess.shape)} do not describe one problem or one batch of problems")
+        B, N, S = us_guess.shape[0], us_guess.shape[1], self.nsamples
+        # the first sample of every problem is its guess (reference :140-143); `key` may be one generator for the whole batch or a
+        # sequence of B generators (the reference splits its key per problem)
+        if isinstance(params.key, (list, tuple)):
+            if len(params.key) != B:
+                raise ValueError(f"optimize: {len(params.key)} generators for a batch of {B} problems")
+            noise = torch.stack([torch.randn((S - 1, N, m.nu), generator=k, device=dev, dtype=torch.float32) for k in params.key])
+        else:
+            noise = torch.randn((B, S - 1, N, m.nu), generator=params.key, device=dev, dtype=torch.float32)
+        noise = torch.cat((torch.zeros((B, 1, N, m.nu), device=dev), noise * self.stdev), dim=1)
+        us_samples = us_guess.unsqueeze(1) + noise  # [B, S, N, nu]
         lim = m.actuator_ctrlrange
         us_samples = torch.minimum(torch.maximum(us_samples, lim[:, 0]), lim[:, 1])  # clip to ctrl limits (:146-148)
-        xs_samples = shoot(m, x0, us_samples)
-        costs, _ = self.cost_function.cost(xs_samples, us_samples, None)
-        best = int(torch.argmin(costs))
-        return xs_samples[best], us_samples[best]
+        us_flat = us_samples.reshape(B * S, N, m.nu)
+        x0_flat = x0.unsqueeze(1).expand(B, S, x0.shape[-1]).reshape(B * S, -1)
+        xs_flat = mjx.rollout(m, x0_flat, us_flat)  # [B*S, N+1, nx]: one launch
+        costs, _ = self.cost_function.cost(xs_flat, us_flat, None)  # [B*S]
+        best = torch.argmin(costs.reshape(B, S), dim=1) + S * torch.arange(B, device=dev)  # on the device: no host synchronisation
+        xs_star, us_star = xs_flat.index_select(0, best), us_flat.index_select(0, best)
+        return (xs_star, us_star) if batched else (xs_star[0], us_star[0])

@@ -402,8 +402,15 @@ def test_VPS_cost_decrease(vps_data, dev):
     rng = np.random.default_rng(0)  # the reference draws x0, us_guess ~ N(0,1) from a JAX key; same law, numpy stream
     x0 = torch.tensor(rng.standard_normal((10, model.nq + model.nv)), dtype=torch.float32, device=dev)
     us_guess = torch.tensor(rng.standard_normal((10, 10, model.nu)), dtype=torch.float32, device=dev)
-    stars = [ps.optimize(VanillaPredictiveSamplerParams(key=g, x0=x0[i], us_guess=us_guess[i])) for i in range(10)]
-    costs_star, _ = cost.cost(torch.stack([s[0] for s in stars]), torch.stack([s[1] for s in stars]), None)
+    # vmap(ps.optimize)(params) as ONE call: 10 problems x nsamples rollouts in one launch, winners picked on the device
+    xs_stars, us_stars = ps.optimize(VanillaPredictiveSamplerParams(key=g, x0=x0, us_guess=us_guess))
+    assert xs_stars.shape == (10, 11, model.nq + model.nv) and us_stars.shape == (10, 10, model.nu)
+    costs_star, _ = cost.cost(xs_stars, us_stars, None)
+    # the batch IS the per-problem optimisation: with one generator per problem (the reference splits its key per problem,
+    # test_predictive_sampler.py:73) problem 3 of the batch returns what a separate call with the same generator returns
+    xs3, us3 = ps.optimize(VanillaPredictiveSamplerParams(key=[torch.Generator(device=dev).manual_seed(100 + i) for i in range(10)], x0=x0, us_guess=us_guess))
+    xs3b, us3b = ps.optimize(VanillaPredictiveSamplerParams(key=torch.Generator(device=dev).manual_seed(103), x0=x0[3], us_guess=us_guess[3]))
+    assert torch.equal(xs3[3], xs3b) and torch.equal(us3[3], us3b)  # per-problem keys: the batch equals ten separate calls
     xs_guess = shoot(model, x0, us_guess)  # vmap(shoot, in_axes=(None, 0, 0))
     costs_guess, _ = cost.cost(xs_guess, us_guess, None)
     assert bool(torch.isfinite(costs_star).all()) and bool(torch.isfinite(costs_guess).all())
