@@ -120,9 +120,30 @@ def load_mj_model_from_file(
 
 def mj_to_mjx_model_and_data(mj_model: MjModel, device=None) -> Tuple[mjx.Model, mjx.Data]:
     """Host model -> (device Model, zero Data) (reference ambersim/utils/io_utils.py:222-241)."""
-    mjx_model = mjx.put_model(mj_model, device)
-    mjx_data = mjx.make_data(mjx_model)
-    return mjx_model, mjx_data
+    try:
+        mjx_model = mjx.put_model(mj_model, device)
+        mjx_data = mjx.make_data(mjx_model)
+        return mjx_model, mjx_data
+    except NotImplementedError as e:
+        # same behaviour as the reference (:228-241): print what usually lies behind an unsupported-feature error, re-raise it.
+        # The causes are this engine's own (its table of collision pairs and constraint rows, include/amx.h), not MJX's.
+        print(UNSUPPORTED_HINT)
+        raise e
+
+
+UNSUPPORTED_HINT = """
+        If you are seeing this, the model asks for something the MI355X engine (ambersim_amd) does not implement:
+
+        (1) a collision pair outside its table: plane / sphere / capsule primitives against each other, a plane, sphere or
+            convex hull (box, mesh) against a convex hull of at most 32 vertices, 32 faces and 64 edges; at most 16 contact
+            slots per environment.  Restrict contype / conaffinity, simplify meshes (maxhullvert) or disable contact
+            (DisableBit.CONTACT), as the reference's own Barrett-hand fixture does.
+
+        (2) an elliptic instead of a pyramidal friction cone, or condim other than 3.
+
+        (3) a model beyond the lane-role capacities (nv <= 32, 64 bodies / joints / pairs, 64 equality + limit rows), a non-Euler
+            integrator, the PGS solver, or an equality / actuator type the engine does not carry (see DESIGN.md, capacity limits).
+"""
 
 
 def load_mjx_model_and_data_from_file(filepath: Union[str, Path], force_float: bool = False, device=None) -> Tuple[mjx.Model, mjx.Data]:
