@@ -23,13 +23,14 @@
 // Record strides (floats) of the constant image.  All odd, so lane-per-record LDS reads are conflict free.
 // Record strides (floats) of the per-environment slab, also odd.
 enum { BODY_E = 29, JNT_E = 7, DOF_E = 17, ROW_E = 3, CON_E = 5, GEO_E = 13 };
-enum { BODY_S = 25, JNT_S = 13, DOF_S = 11, ACT_S = 13, GEOM_S = 13, PAIR_S = 29, LIM_S = 15, EQ_S = 21, HULL_S = 7 };
+enum { BODY_S = 25, JNT_S = 13, DOF_S = 13, ACT_S = 13, GEOM_S = 13, PAIR_S = 29, LIM_S = 15, EQ_S = 21, HULL_S = 7, FRI_S = 5 };
 // convex-convex scratch per environment (floats): world vertices of both hulls [2][32][3], two clip polygons [2][16][3]
 enum { CX_MAXV = 32, CX_MAXP = 16, CX_VA = 0, CX_VB = 96, CX_POLY = 192, CX_SCRATCH = 289 };
 // BodyRec: 0 parent 1 level 2 rootslot 3 jntadr 4 jntnum 5 childadr 6 childnum 7-9 pos 10-13 quat 14-16 ipos 17-20 iquat 21 mass 22-24 inertia
 // JntRec : 0 type 1 qadr 2 dadr 3 body 4-6 pos 7-9 axis 10 qpos0 11 stiffness 12 springref
 // DofRec : 0 body 1 jnt 2 kind(0 free-trans,1 free/ball-rot,2 hinge,3 slide) 3 axis 4 armature 5 damping 6 actadr 7 actnum 8 rootslot
-//          9 first dof of the joint 10 lane of the limit row on this dof (-1: none)
+//          9 first dof of the joint 10 lane of the limit row on this dof (-1: none) 11 lane of its friction-loss row (-1: none) 12 pad
+// FriRec : 0 dadr 1 D = 1 / max(invweight0 (1 - imp) / imp, MINVAL) with imp = impedance at pos 0 2 b 3 frictionloss 4 pad   (all folded on the host)
 // ActRec : 0 qadr 1 dadr 2 flags(1 ctrllimited,2 forcelimited,4 affine bias) 3 gear 4 gain 5-7 bias 8-9 ctrlrange 10-11 forcerange 12 pad
 // GeomRec: 0 body 1 type 2-4 pos 5-8 quat 9-11 size 12 pad
 // PairRec: 0 g1 1 g2 2 fn 3 conadr 4 ncon 5 vertadr 6 vertnum 7 root1 8 root2 9 dofadr 10 dofnum 11 mu 12 k 13 b 14 dmin 15 dmax
@@ -44,7 +45,7 @@ enum { CX_MAXV = 32, CX_MAXP = 16, CX_VA = 0, CX_VB = 96, CX_POLY = 192, CX_SCRA
 //   sizes .. options
 #define AMX_MODEL_INTS(X)                                                                                                  \
   X(nconst)                                                                                                                \
-  X(nq) X(nv) X(nu) X(nb) X(njnt) X(ngc) X(npair) X(ncon) X(neq) X(nlim) X(nefc) X(nlevel) X(nM) X(nroot)                    \
+  X(nq) X(nv) X(nu) X(nb) X(njnt) X(ngc) X(npair) X(ncon) X(neq) X(nfri) /* friction-loss rows, between the equality and the limit rows */ X(nlim) X(nefc) X(nlevel) X(nM) X(nroot)                    \
   X(ldc) /* contact-row stride: longest pair dof list, odd */                                                              \
   X(ldm) /* row stride of M and H: >= nv, a multiple of 4 */                                                                \
   X(mrot) /* 1: row i of M stores chunk c at position (c + i) mod ldm/4 (fused path with an even chunk count) */          \
@@ -56,7 +57,7 @@ enum { CX_MAXV = 32, CX_MAXP = 16, CX_VA = 0, CX_VB = 96, CX_POLY = 192, CX_SCRA
   X(G)   /* lanes per environment: 16, 32 or 64 */                                                                         \
   X(wpb) /* wavefronts per workgroup (1..AMX_WAVES_PER_BLOCK), chosen to maximise resident waves per CU */                 \
   /* bases inside the constant image (float offsets) */                                                                    \
-  X(c_body) X(c_jnt) X(c_dof) X(c_act) X(c_geom) X(c_pair) X(c_lim) X(c_eq)                                                \
+  X(c_body) X(c_jnt) X(c_dof) X(c_act) X(c_geom) X(c_pair) X(c_lim) X(c_eq) X(c_fri)                                                \
   X(c_qpos0) /* [nq] */ X(c_child) X(c_M) /* packed offset of M[i][j] | offset of M[j][i]<<11 | i<<22 | j<<27 */ X(c_dofact) X(c_pairdof) /* packed dof|sign<<8 */            \
   X(c_jac) /* packed contact|slot<<6|dof<<11|chain sign<<16|pair<<18 */                                                    \
   X(c_hent) /* [nhent] terms: packed dof_i|dof_j<<5|first contact row<<10|slot_i<<18|slot_j<<23 (dof_j <= dof_i) */         \

@@ -55,7 +55,7 @@
 #define MINVAL 1e-15f
 
 enum { JFREE = 0, JBALL = 1, JSLIDE = 2, JHINGE = 3 };
-enum { DIS_CONSTRAINT = 1, DIS_EQUALITY = 2, DIS_LIMIT = 8, DIS_CONTACT = 16, DIS_PASSIVE = 32,
+enum { DIS_CONSTRAINT = 1, DIS_EQUALITY = 2, DIS_FRICTIONLOSS = 4, DIS_LIMIT = 8, DIS_CONTACT = 16, DIS_PASSIVE = 32,
        DIS_GRAVITY = 64, DIS_CLAMPCTRL = 128, DIS_WARMSTART = 256, DIS_ACTUATION = 1024,
        DIS_REFSAFE = 2048, DIS_EULERDAMP = 16384 };
 
@@ -1439,7 +1439,7 @@ struct Env {
   int ebB, ebD;
   // static role constants of this lane
   int b_parent, b_level, b_root, b_jntadr, b_jntnum, b_childadr, b_childnum, b_subend;  // body `lane` (b_subend: one past its last descendant)
-  int d_body, d_jnt, d_kind, d_axis, d_root, d_jadr, d_limrow;                // dof `lane` (d_jadr: first dof of its joint; d_limrow: lane of its limit row)
+  int d_body, d_jnt, d_kind, d_axis, d_root, d_jadr, d_limrow, d_frirow;      // dof `lane` (d_jadr: first dof of its joint; d_limrow / d_frirow: lane of its limit / friction-loss row)
   int m_rot, m_diag;  // row `lane` of M: chunk rotation of the row (0 unless MV::mrot), float offset of its diagonal entry inside M
   // Constraint rows: a lane owns TWO row slots, so that a group of G lanes carries up to 2 G rows -
   //   slot A: equality / limit row `gl` (gl < nA = neq + nlim): one or two Jacobian entries, kept in registers;
@@ -1447,6 +1447,9 @@ struct Env {
   // (One slot per lane made the 56 rows of the biped - 24 limits, 32 contact rows - need a 64-lane group for a 30-dof model.)
   // Row r of the reference's row table is A row r, or B row r - nA.
   float aD, aAref, aJaref, aJv;  // slot A solver state
+  // friction-loss rows (slot A, between the equality and the limit rows; models with nfri > 0 only): the force of such a row is
+  // bounded by +-aFl, so its cost is quadratic while |Jaref| < aFl / aD and linear beyond (aFl = 0 on every other row)
+  float aFl;
   float cD, cAref, cJaref, cJv;  // slot B solver state
   // contact row `gl`: J*v reads v from the pair's gathered copy (stage_chain) - vch_base: where that copy starts;
   // staging item `gl` (slot t of pair p, gl = p*ldc + t): vch_dof = its dof, -1 past the list's end
@@ -1456,7 +1459,7 @@ struct Env {
   bool aact, cact;  // the slot's row is active at the current iterate (set by constraint_force_and_grad)
   PROF_DECL
 
-  DEV int nA() const { return m.nefc() == 0 ? 0 : m.neq() + m.nlim(); }  // nefc == 0: constraints disabled
+  DEV int nA() const { return m.nefc() == 0 ? 0 : m.neq() + m.nfri() + m.nlim(); }  // nefc == 0: constraints disabled
   DEV int nB() const { return m.nefc() == 0 ? 0 : 4 * m.ncon(); }
 
   DEV Env(const MV<S> &m_, int eb_, int gl_, int gb4_) : m(m_), eb(eb_), gl(gl_), gb4(gb4_) {
@@ -1467,17 +1470,18 @@ struct Env {
     b_parent = CI(br); b_level = lane < m.nb() ? CI(br + 1) : -1; b_root = CI(br + 2); b_jntadr = CI(br + 3); b_jntnum = CI(br + 4);
     b_childadr = CI(br + 5); b_childnum = CI(br + 6) & 255; b_subend = CI(br + 6) >> 8;
     const int dr = m.c_dof() + (lane < m.nv() ? lane : 0) * DOF_S;
-    d_body = CI(dr); d_jnt = CI(dr + 1); d_kind = CI(dr + 2); d_axis = CI(dr + 3); d_root = CI(dr + 8); d_jadr = CI(dr + 9); d_limrow = CI(dr + 10);
+    d_body = CI(dr); d_jnt = CI(dr + 1); d_kind = CI(dr + 2); d_axis = CI(dr + 3); d_root = CI(dr + 8); d_jadr = CI(dr + 9); d_limrow = CI(dr + 10); d_frirow = CI(dr + 11);
     {
       const int nch = m.ldm() >> 2, i = lane < m.nv() ? lane : 0;
       m_rot = m.mrot() ? AMX_ROW_ROT(i, nch) : 0;
       m_diag = moff(i, i);
     }
-    aD = aAref = aJaref = aJv = cD = cAref = cJaref = cJv = rJ1 = rJ2 = 0.0f;
+    aD = aAref = aJaref = aJv = cD = cAref = cJaref = cJv = rJ1 = rJ2 = aFl = 0.0f;
     aact = cact = false;
     rd1 = 0; rd2 = -1;
     if (lane < m.neq()) { const int er = m.c_eq() + lane * EQ_S; rd1 = CI(er + 1); rd2 = CI(er + 3); }
-    else if (lane < m.neq() + m.nlim()) rd1 = CI(m.c_lim() + (lane - m.neq()) * LIM_S + 1);
+    else if (lane < m.neq() + m.nfri()) rd1 = CI(m.c_fri() + (lane - m.neq()) * FRI_S);
+    else if (lane < m.neq() + m.nfri() + m.nlim()) rd1 = CI(m.c_lim() + (lane - m.neq() - m.nfri()) * LIM_S + 1);
     vch_base = eb + m.e_vch();
     if (lane < 4 * m.ncon()) vch_base += CI(m.c_conpair() + (lane >> 2)) * m.ldc();
     {
@@ -2192,7 +2196,7 @@ struct Env {
     const int Jo = eb + m.e_J(), ldc = m.ldc();
     const int qp = eb + m.e_qpos(), qv = eb + m.e_qvel();
     const bool con_on = !(m.disableflags() & DIS_CONSTRAINT);
-    const int row0 = m.neq() + m.nlim();
+    const int row0 = m.neq() + m.nfri() + m.nlim();
     if (con_on && !(m.disableflags() & DIS_CONTACT)) {
       // contact Jacobian entries: one lane per (contact, dof of the pair's ancestor chains); rows are stored
       // chain-compressed: Jc[contact row][slot], slot = position of the dof in the pair's dof list
@@ -2226,8 +2230,8 @@ struct Env {
       stage_chain(qv, 1);  // for the rows' J * qvel below
     }
     WSYNC();
-    // slot A: equality / limit row gl
-    float dd = 0, ar = 0;
+    // slot A: equality / friction-loss / limit row gl
+    float dd = 0, ar = 0, fl_ = 0;
     if (con_on && gl < nA()) {
       const int r = gl;
       float pos = 0, invw = 0, jv = 0;
@@ -2254,8 +2258,17 @@ struct Env {
           }
           rec = er + 9;
         }
+      } else if (r < m.neq() + m.nfri()) {
+        // friction loss (MuJoCo mj_instantiateFriction): J = e_dof, pos = 0, so D and b are constants of the row
+        if (!(m.disableflags() & DIS_FRICTIONLOSS)) {
+          const int fr_ = m.c_fri() + (r - m.neq()) * FRI_S;
+          rJ1 = 1.0f;
+          dd = CF(fr_ + 1);
+          ar = -CF(fr_ + 2) * lds[qv + rd1];
+          fl_ = CF(fr_ + 3);
+        }
       } else if (!(m.disableflags() & DIS_LIMIT)) {
-        const int lr = m.c_lim() + (r - m.neq()) * LIM_S;
+        const int lr = m.c_lim() + (r - m.neq() - m.nfri()) * LIM_S;
         const float q = lds[qp + CI(lr)];
         const float dmin = q - CF(lr + 2), dmax = CF(lr + 3) - q;
         pos = fminf(dmin, dmax) - CF(lr + 4);
@@ -2274,6 +2287,7 @@ struct Env {
     }
     aD = dd;
     aAref = ar;
+    aFl = fl_;
     // slot B: contact pyramid row gl
     dd = 0; ar = 0;
     if (con_on && gl < nB() && !(m.disableflags() & DIS_CONTACT)) {
@@ -2384,7 +2398,13 @@ struct Env {
   }
   DEV float constraint_cost(int vf, float *gauss_out) const {
     const bool actA = (gl < nA()) & ((aJaref < 0) | (gl < m.neq())), actB = (gl < nB()) & (cJaref < 0);
-    float c = (actA ? 0.5f * aD * aJaref * aJaref : 0.0f) + (actB ? 0.5f * cD * cJaref * cJaref : 0.0f);
+    float ca_ = actA ? 0.5f * aD * aJaref * aJaref : 0.0f;
+    if (m.nfri() > 0) {  // a property of the model.  Friction-loss rows: quadratic inside |Jaref| < rf = aFl / aD, linear outside
+      const float rf = fdiv(aFl, fmaxf(aD, MINVAL)), z = aJaref;
+      const float lin = aFl * (fabsf(z) - 0.5f * rf), quad = 0.5f * aD * z * z;
+      ca_ = aFl > 0.0f ? (fabsf(z) >= rf ? lin : quad) : ca_;
+    }
+    float c = ca_ + (actB ? 0.5f * cD * cJaref * cJaref : 0.0f);
     const int li = gl < m.nv() ? gl : 0;  // unconditional loads, then a select (a lazily evaluated ?: is a branch with its own wait)
     const float gv = (dof(D_MA, li) - dof(D_FSMOOTH, li)) * (dof(vf, li) - dof(D_ASMOOTH, li));
     float g = gl < m.nv() ? gv : 0.0f;
@@ -2400,22 +2420,39 @@ struct Env {
   // GRADCOL), so a call that is followed by newton_direction() only publishes the row records and the limit-row force
   static constexpr bool grad_in_solve() { return S::is_static && G == 32 && S::fusedH && S::solver == 2 && S::nv <= 31 && sym_elim_ok<S, G>() && !AMX_NO_GRADCOL; }
   float pend_flim;  // limit-row force on this lane's dof, handed from a deferring constraint_force_and_grad to newton_direction
+  // x of the single-entry rows on this lane's dof, summed: its limit row and (models with friction loss) its friction-loss row, each
+  // fetched from the row's lane through the crossbar; 0 on lanes without a dof or without such rows
+  DEV float dof_rows_fetch(float x) const {
+    float r = __int_as_float(__builtin_amdgcn_ds_bpermute(gb4 + 4 * (d_limrow < 0 ? 0 : d_limrow), __float_as_int(x)));
+    r = (gl < m.nv() && d_limrow >= 0) ? r : 0.0f;
+    if (m.nfri() > 0) {
+      const float r2 = __int_as_float(__builtin_amdgcn_ds_bpermute(gb4 + 4 * (d_frirow < 0 ? 0 : d_frirow), __float_as_int(x)));
+      r += (gl < m.nv() && d_frirow >= 0) ? r2 : 0.0f;
+    }
+    return r;
+  }
   // alive: false for a group whose solve has converged while its wave mate iterates on - its force and gradient are left as
   // they are (recomputing them is idempotent in value but not in bits: the matrix-core sum and the gather round differently,
   // and which of the two ran last must not depend on the wave mate)
   DEV void constraint_force_and_grad(bool defer = false, bool alive = true) {
-    const int Jo = eb + m.e_J(), ldc = m.ldc(), row0 = m.neq() + m.nlim();
+    const int Jo = eb + m.e_J(), ldc = m.ldc(), row0 = m.neq() + m.nfri() + m.nlim();
     aact = (gl < nA()) & ((aJaref < 0) | (gl < m.neq())) & (aD > 0);
     cact = (gl < nB()) & (cJaref < 0) & (cD > 0);
-    const float f = aact ? -aD * aJaref : 0.0f, fc = cact ? -cD * cJaref : 0.0f;
+    float f = aact ? -aD * aJaref : 0.0f;
+    const float fc = cact ? -cD * cJaref : 0.0f;
+    if (m.nfri() > 0) {  // friction-loss rows: the force saturates at +-aFl; only the quadratic zone enters the Hessian
+      const bool fri = aFl > 0.0f;
+      const float fq = -aD * aJaref, fs = fminf(fmaxf(fq, -aFl), aFl);
+      f = fri ? fs : f;
+      aact = fri ? (fabsf(fq) < aFl) : aact;
+    }
     if (gl < nA()) { row(0, gl) = aact ? aD : 0.0f; row(1, gl) = f; }
     if (gl < nB()) { row(0, row0 + gl) = cact ? cD : 0.0f; row(1, row0 + gl) = fc; }
     WSYNC();
     if (grad_in_solve() && defer) {
       float fl = 0.0f;
       if (nA() > 0) {
-        fl = __int_as_float(__builtin_amdgcn_ds_bpermute(gb4 + 4 * (d_limrow < 0 ? 0 : d_limrow), __float_as_int(rJ1 * f)));
-        fl = (gl < m.nv() && d_limrow >= 0) ? fl : 0.0f;
+        fl = dof_rows_fetch(rJ1 * f);
       }
       pend_flim = fl;
       return;
@@ -2446,8 +2483,7 @@ struct Env {
       // limit rows have one entry each and a dof at most one limit row: without equality rows the dof lane fetches its row's
       // force through the crossbar instead of the rows scattering with LDS atomics
       if (m.neq() == 0 && nA() > 0) {
-        const float fl = __int_as_float(__builtin_amdgcn_ds_bpermute(gb4 + 4 * (d_limrow < 0 ? 0 : d_limrow), __float_as_int(rJ1 * f)));
-        acc += (isd && d_limrow >= 0) ? fl : 0.0f;
+        acc += dof_rows_fetch(rJ1 * f);
       }
       if (isd && alive) dof(D_FCON, gl) = acc;
     }
@@ -2469,15 +2505,14 @@ struct Env {
   // wave: the direction was not computed and the caller must not iterate again
   DEV bool newton_direction(bool alive = true, bool early_out = false, bool imp_done = false, bool *group_done = nullptr) {
     const int nv = m.nv(), Mo = eb + m.e_M(), Ho = eb + m.e_H(), Jo = eb + m.e_J(), ldc = m.ldc(), ldm = m.ldm();
-    const int row0 = m.neq() + m.nlim();
+    const int row0 = m.neq() + m.nfri() + m.nlim();
     if constexpr (G >= 32) {
       if (m.fusedH()) {
         const unsigned long long act = __ballot(cact);
         const unsigned long long rows = G == 32 ? ((act | (act >> 32)) & 0xFFFFFFFFull) : act;  // contact row active in any environment of the wave
         // diagonal term of the limit row on this lane's dof: D of that row if it is active (J = +-1), through the crossbar
         const float dsrc = aact ? aD : 0.0f;
-        float dlim = __int_as_float(__builtin_amdgcn_ds_bpermute(gb4 + 4 * (d_limrow < 0 ? 0 : d_limrow), __float_as_int(dsrc)));
-        dlim = (gl < nv && d_limrow >= 0 && nA() > 0) ? dlim : 0.0f;
+        const float dlim = nA() > 0 ? dof_rows_fetch(dsrc) : 0.0f;  // J = +-1 on these rows: J' D J is D on the diagonal
         PROF(19);
         bool stop = false;
 #ifdef AMX_PROFILE
@@ -2553,11 +2588,24 @@ struct Env {
   // evaluated at the same alphas, so the accepted step is the one the reference's search takes.
   struct LSTerms { float q1, q2; };
   DEV LSTerms ls_terms(float alpha, bool validA, bool validB, bool iseq, float *q0 = nullptr) const {
-    const bool actA = validA & ((aJaref + alpha * aJv < 0) | iseq), actB = validB & (cJaref + alpha * cJv < 0);
+    const float xA = aJaref + alpha * aJv;
+    const bool actA = validA & ((xA < 0) | iseq), actB = validB & (cJaref + alpha * cJv < 0);
+    float a1 = actA ? aJv * aJaref * aD : 0.0f, a2 = actA ? 0.5f * aJv * aJv * aD : 0.0f, a0 = actA ? 0.5f * aJaref * aJaref * aD : 0.0f;
+    if (m.nfri() > 0) {  // friction-loss rows: the zone at alpha picks the coefficients (quadratic inside |x| < rf, linear outside)
+      const bool fri = aFl > 0.0f;
+      const float rf = fdiv(aFl, fmaxf(aD, MINVAL));
+      const bool lin = fabsf(xA) >= rf;
+      const float sg = xA < 0 ? -1.0f : 1.0f;  // linear branch: cost = aFl (-rf/2 + sg x)
+      const float l1 = sg * aFl * aJv, l0 = aFl * (sg * aJaref - 0.5f * rf);
+      const float q1q = aJv * aJaref * aD, q2q = 0.5f * aJv * aJv * aD, q0q = 0.5f * aJaref * aJaref * aD;
+      a1 = fri ? (lin ? l1 : q1q) : a1;
+      a2 = fri ? (lin ? 0.0f : q2q) : a2;
+      a0 = fri ? (lin ? l0 : q0q) : a0;
+    }
     LSTerms r;
-    r.q1 = (actA ? aJv * aJaref * aD : 0.0f) + (actB ? cJv * cJaref * cD : 0.0f);
-    r.q2 = (actA ? 0.5f * aJv * aJv * aD : 0.0f) + (actB ? 0.5f * cJv * cJv * cD : 0.0f);
-    if (q0) *q0 = (actA ? 0.5f * aJaref * aJaref * aD : 0.0f) + (actB ? 0.5f * cJaref * cJaref * cD : 0.0f);
+    r.q1 = a1 + (actB ? cJv * cJaref * cD : 0.0f);
+    r.q2 = a2 + (actB ? 0.5f * cJv * cJv * cD : 0.0f);
+    if (q0) *q0 = a0 + (actB ? 0.5f * cJaref * cJaref * cD : 0.0f);
     return r;
   }
   struct LSD { float alpha, d0, d1; };

@@ -228,6 +228,7 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
     im.seti(o + 6, dofact_adr[i]); im.seti(o + 7, dofact_num[i]); im.seti(o + 8, root_slot[d->dof_bodyid[i]]);
     im.seti(o + 9, d->jnt_dofadr[j]);  // first dof of the dof's joint: its record holds the joint's anchor and axis
     im.seti(o + 10, -1);               // lane of the limit row on this dof (filled below), -1: none
+    im.seti(o + 11, -1);               // lane of the friction-loss row on this dof (filled below), -1: none
   }
   // collision geoms (only those that appear in a pair)
   std::vector<int> gmap(d->ngeom > 0 ? d->ngeom : 1, -1), gc_src;
@@ -365,10 +366,30 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
     write_kbi(im, o + 5, d->jnt_solref + 2 * j, d->jnt_solimp + 5 * j, d->timestep, refsafe);
     im.setf(o + 14, d->dof_invweight0[d->jnt_dofadr[j]]);
   }
+  // friction-loss rows: one per dof with frictionloss > 0, after the equality rows and before the limit rows.  pos = 0 always,
+  // so the impedance is the constant d(0) = dmin and D, b are folded here
+  std::vector<int> fri_i;
+  for (int i = 0; i < nv; i++) if (d->dof_frictionloss[i] > 0) fri_i.push_back(i);
+  m.nfri = (int)fri_i.size();
+  m.c_fri = im.reserve(m.nfri * FRI_S);
+  for (int f = 0; f < m.nfri; f++) {
+    const int i = fri_i[f], o = m.c_fri + f * FRI_S;
+    // the position-independent part of solreffriction / solimpfriction (write_kbi's arithmetic, kept in double)
+    const double *sr = d->dof_solref + 2 * i, *si = d->dof_solimp + 5 * i;
+    auto clip = [](double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); };
+    const double imp = clip(si[0], 0.0001, 0.9999), dmax = clip(si[1], 0.0001, 0.9999);  // impedance at pos = 0 is dmin
+    double timeconst = sr[0];
+    if (refsafe) timeconst = std::max(timeconst, 2 * d->timestep);
+    double b = 2.0 / (dmax * timeconst);
+    if (sr[1] <= 0) b = -sr[1] / dmax;
+    const double R = std::max(d->dof_invweight0[i] * (1 - imp) / imp, 1e-15);
+    im.seti(o, i); im.setf(o + 1, 1.0 / R); im.setf(o + 2, b); im.setf(o + 3, d->dof_frictionloss[i]);
+  }
   {
     int neq_active = 0;
     for (int e = 0; e < d->neq; e++) if (d->eq_active[e]) neq_active++;
-    for (int l = 0; l < m.nlim; l++) im.seti(m.c_dof + d->jnt_dofadr[lim_j[l]] * DOF_S + 10, neq_active + l);
+    for (int f = 0; f < m.nfri; f++) im.seti(m.c_dof + fri_i[f] * DOF_S + 11, neq_active + f);
+    for (int l = 0; l < m.nlim; l++) im.seti(m.c_dof + d->jnt_dofadr[lim_j[l]] * DOF_S + 10, neq_active + m.nfri + l);
   }
   std::vector<int> eq_e;
   for (int e = 0; e < d->neq; e++) if (d->eq_active[e]) eq_e.push_back(e);
@@ -386,12 +407,12 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
     im.setf(o + 19, d->qpos0[d->jnt_qposadr[j1]]); im.setf(o + 20, j2 >= 0 ? d->qpos0[d->jnt_qposadr[j2]] : 0.0);
   }
   const bool con_off = d->disableflags & 1;
-  m.nefc = con_off ? 0 : m.neq + m.nlim + 4 * m.ncon;
-  if (m.neq + m.nlim > AMX_WAVE) return fail(AMX_ECAPACITY, "%d equality + limit rows exceed the lane-role capacity %d", m.neq + m.nlim, AMX_WAVE);
+  m.nefc = con_off ? 0 : m.neq + m.nfri + m.nlim + 4 * m.ncon;
+  if (m.neq + m.nfri + m.nlim > AMX_WAVE) return fail(AMX_ECAPACITY, "%d equality + friction + limit rows exceed the lane-role capacity %d", m.neq + m.nfri + m.nlim, AMX_WAVE);
   // lanes per environment: the smallest group that holds every lane-role index set.  A lane carries two constraint rows:
   // one equality / limit row and one contact row (amx_kernels.hip, Env), so the rows ask for max(neq + nlim, 4 ncon) lanes.
   {
-    const int need = std::max({nb, nj, nv, np, m.ngc, con_off ? 0 : m.neq + m.nlim, con_off ? 0 : 4 * m.ncon, 1});
+    const int need = std::max({nb, nj, nv, np, m.ngc, con_off ? 0 : m.neq + m.nfri + m.nlim, con_off ? 0 : 4 * m.ncon, 1});
     m.G = need <= 16 ? 16 : (need <= 32 ? 32 : 64);
     if (const char *force = getenv("AMX_FORCE_G")) { int g = atoi(force); if ((g == 16 || g == 32 || g == 64) && g >= m.G) m.G = g; }
   }

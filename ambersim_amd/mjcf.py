@@ -550,7 +550,8 @@ class _Compiler:
             return dict(name=e.get("name", ""), type=JNT_FREE, pos=np.zeros(3), axis=np.array([0, 0, 1.0]),
                         limited=False, range=np.zeros(2), damping=0.0, armature=0.0, stiffness=0.0,
                         ref=0.0, springref=0.0, margin=0.0, frictionloss=0.0,
-                        solref=np.array([0.02, 1.0]), solimp=self._solimp(None))
+                        solref=np.array([0.02, 1.0]), solimp=self._solimp(None),
+                        solref_fri=np.array([0.02, 1.0]), solimp_fri=self._solimp(None))
         at = self.defaults.attrs("joint", e.get("class", childclass), e.attrib)
         jt = {"free": JNT_FREE, "ball": JNT_BALL, "slide": JNT_SLIDE, "hinge": JNT_HINGE}[at.get("type", "hinge")]
         rng = _floats(at.get("range", "0 0"), 2)
@@ -569,16 +570,18 @@ class _Compiler:
         springref = float(at.get("springref", 0))
         if jt == JNT_HINGE:
             ref, springref = self._angle(ref), self._angle(springref)
-        if float(at.get("frictionloss", 0)) != 0:
-            raise NotImplementedError("joint frictionloss (unsupported by the reference physics, mjx feature parity)")
+        frictionloss = float(at.get("frictionloss", 0))
+        if frictionloss < 0:
+            raise ValueError("joint frictionloss must be non-negative")
         if jt == JNT_BALL and limited:
             raise NotImplementedError("ball joint limits")
         return dict(
             name=at.get("name", ""), type=jt, pos=_floats(at.get("pos", "0 0 0"), 3), axis=axis,
             limited=limited, range=rng, damping=float(at.get("damping", 0)), armature=float(at.get("armature", 0)),
             stiffness=float(at.get("stiffness", 0)), ref=ref, springref=springref,
-            margin=float(at.get("margin", 0)), frictionloss=0.0,
+            margin=float(at.get("margin", 0)), frictionloss=frictionloss,
             solref=_floats(at.get("solreflimit", "0.02 1"), 2), solimp=self._solimp(at.get("solimplimit")),
+            solref_fri=_floats(at.get("solreffriction", "0.02 1"), 2), solimp_fri=self._solimp(at.get("solimpfriction")),
         )
 
     # -- main
@@ -672,7 +675,11 @@ class _Compiler:
         m.jnt_solimp = F([j["solimp"] for j in jnt], (-1, 5))
         m.dof_bodyid, m.dof_jntid, m.dof_parentid = I32(dof_bodyid), I32(dof_jntid), I32(dof_parentid)
         m.dof_armature, m.dof_damping = F(dof_armature, (-1,)), F(dof_damping, (-1,))
-        m.dof_frictionloss = np.zeros(m.nv)
+        # dry friction: every dof of a joint carries the joint's frictionloss and its solreffriction / solimpfriction (MuJoCo's
+        # dof_frictionloss, dof_solref, dof_solimp)
+        m.dof_frictionloss = F([jnt[j]["frictionloss"] for j in dof_jntid], (-1,))
+        m.dof_solref = F([jnt[j]["solref_fri"] for j in dof_jntid], (-1, 2))
+        m.dof_solimp = F([jnt[j]["solimp_fri"] for j in dof_jntid], (-1, 5))
         m.qpos0, m.qpos_spring = F(qpos0, (-1,)), F(qpos_spring, (-1,))
 
         # root / weld ids

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AMX_VERSION 2 /* 2: convex hull tables for convex-convex pairs */
+#define AMX_VERSION 3 /* 2: convex hull tables for convex-convex pairs; 3: joint friction loss (appended fields) */
 
 enum {
   AMX_OK = 0,
@@ -84,6 +84,10 @@ typedef struct amx_model_desc {
   /* joint equalities [neq] */
   const int *eq_obj1id, *eq_obj2id, *eq_active;
   const double *eq_data /*[neq,5] polycoef*/, *eq_solref /*[neq,2]*/, *eq_solimp /*[neq,5]*/;
+  /* dry joint friction [nv] (version 3): a dof with dof_frictionloss > 0 carries one friction-loss constraint row (force
+   * clamped to +-frictionloss: quadratic inside, linear outside), regularised by dof_solref / dof_solimp
+   * (MJCF solreffriction / solimpfriction).  Reaches the reference through URDF <dynamics friction=...>. */
+  const double *dof_frictionloss /*[nv]*/, *dof_solref /*[nv,2]*/, *dof_solimp /*[nv,5]*/;
 } amx_model_desc;
 
 typedef struct amx_model amx_model; /* opaque: device-resident constant block + launch plan */

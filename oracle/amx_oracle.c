@@ -59,7 +59,7 @@ static inline REAL r_clip(REAL x, REAL lo, REAL hi) { return x < lo ? lo : (x > 
 #define MINIMP ((REAL)0.0001)
 #define MAXIMP ((REAL)0.9999)
 enum { JFREE = 0, JBALL = 1, JSLIDE = 2, JHINGE = 3 };
-enum { DIS_CONSTRAINT = 1, DIS_EQUALITY = 2, DIS_LIMIT = 8, DIS_CONTACT = 16, DIS_PASSIVE = 32,
+enum { DIS_CONSTRAINT = 1, DIS_EQUALITY = 2, DIS_FRICTIONLOSS = 4, DIS_LIMIT = 8, DIS_CONTACT = 16, DIS_PASSIVE = 32,
        DIS_GRAVITY = 64, DIS_CLAMPCTRL = 128, DIS_WARMSTART = 256, DIS_ACTUATION = 1024,
        DIS_REFSAFE = 2048, DIS_EULERDAMP = 16384 };
 
@@ -74,7 +74,7 @@ typedef struct amxo_model {
   REAL *jnt_pos, *jnt_axis, *jnt_range, *jnt_margin, *jnt_stiffness, *jnt_solref, *jnt_solimp;
   REAL *qpos0, *qpos_spring;
   int *dof_bodyid, *dof_jntid, *dof_parentid;
-  REAL *dof_armature, *dof_damping, *dof_invweight0;
+  REAL *dof_armature, *dof_damping, *dof_invweight0, *dof_frictionloss, *dof_solref, *dof_solimp;
   int *geom_type, *geom_bodyid;
   REAL *geom_pos, *geom_quat, *geom_size;
   int *pair_geom1, *pair_geom2, *pair_fn, *pair_vertadr, *pair_vertnum, *pair_conadr;
@@ -130,6 +130,7 @@ amxo_model *amxo_model_create(const amx_model_desc *d) {
   m->dof_bodyid = dup_i(d->dof_bodyid, nv); m->dof_jntid = dup_i(d->dof_jntid, nv);
   m->dof_parentid = dup_i(d->dof_parentid, nv);
   m->dof_armature = dup_r(d->dof_armature, nv); m->dof_damping = dup_r(d->dof_damping, nv);
+  m->dof_frictionloss = dup_r(d->dof_frictionloss, nv); m->dof_solref = dup_r(d->dof_solref, nv * 2); m->dof_solimp = dup_r(d->dof_solimp, nv * 5);
   m->dof_invweight0 = dup_r(d->dof_invweight0, nv);
   m->geom_type = dup_i(d->geom_type, ng); m->geom_bodyid = dup_i(d->geom_bodyid, ng);
   m->geom_pos = dup_r(d->geom_pos, ng * 3); m->geom_quat = dup_r(d->geom_quat, ng * 4);
@@ -166,7 +167,9 @@ amxo_model *amxo_model_create(const amx_model_desc *d) {
   for (size_t p = 0; p < np; p++) { m->pair_conadr[p] = m->ncon; m->ncon += PAIR_NCON[m->pair_fn[p]]; }
   int nlim = 0;
   for (size_t j = 0; j < nj; j++) nlim += (m->jnt_limited[j] && (m->jnt_type[j] == JSLIDE || m->jnt_type[j] == JHINGE));
-  m->nefc_max = m->neq + nlim + 4 * m->ncon;
+  int nfri = 0;
+  for (size_t i = 0; i < nv; i++) nfri += m->dof_frictionloss[i] > 0;
+  m->nefc_max = m->neq + nfri + nlim + 4 * m->ncon;
   return m;
 }
 
@@ -181,7 +184,7 @@ void amxo_model_destroy(amxo_model *m) {
     (void **)&m->jnt_type, (void **)&m->jnt_qposadr, (void **)&m->jnt_dofadr, (void **)&m->jnt_bodyid, (void **)&m->jnt_limited,
     (void **)&m->jnt_pos, (void **)&m->jnt_axis, (void **)&m->jnt_range, (void **)&m->jnt_margin, (void **)&m->jnt_stiffness,
     (void **)&m->jnt_solref, (void **)&m->jnt_solimp, (void **)&m->qpos0, (void **)&m->qpos_spring, (void **)&m->dof_bodyid,
-    (void **)&m->dof_jntid, (void **)&m->dof_parentid, (void **)&m->dof_armature, (void **)&m->dof_damping,
+    (void **)&m->dof_jntid, (void **)&m->dof_parentid, (void **)&m->dof_armature, (void **)&m->dof_damping, (void **)&m->dof_frictionloss, (void **)&m->dof_solref, (void **)&m->dof_solimp,
     (void **)&m->dof_invweight0, (void **)&m->geom_type, (void **)&m->geom_bodyid, (void **)&m->geom_pos, (void **)&m->geom_quat,
     (void **)&m->geom_size, (void **)&m->pair_geom1, (void **)&m->pair_geom2, (void **)&m->pair_fn, (void **)&m->pair_vertadr,
     (void **)&m->pair_vertnum, (void **)&m->pair_conadr, (void **)&m->pair_friction, (void **)&m->pair_solref,
@@ -203,8 +206,8 @@ typedef struct amxo_data {
   REAL *qfrc_passive, *qfrc_bias, *qfrc_actuator, *qfrc_smooth, *qacc_smooth, *qacc, *qfrc_constraint;
   REAL *actuator_moment_gear; /* per actuator: gear on its dof */
   REAL *con_dist, *con_pos, *con_frame; int *con_pair;
-  int nefc, ne;
-  REAL *efc_J, *efc_D, *efc_aref, *efc_pos, *efc_force;
+  int nefc, ne, nf; /* rows: [0, ne) equality, [ne, ne + nf) friction loss, then limits, then contacts */
+  REAL *efc_J, *efc_D, *efc_aref, *efc_pos, *efc_force, *efc_floss; /* efc_floss: the friction rows' force bound, 0 elsewhere */
   int solver_niter;
   /* scratch */
   REAL *w_a, *w_b, *w_c, *w_d, *w_e, *w_f, *w_g, *w_H, *w_L, *w_jv, *w_jaref, *w_mass, *w_quad;
@@ -226,7 +229,7 @@ amxo_data *amxo_data_create(const amxo_model *m) {
   ALLOC(qacc_smooth, nv); ALLOC(qacc, nv); ALLOC(qfrc_constraint, nv); ALLOC(actuator_moment_gear, m->nu);
   ALLOC(con_dist, nc); ALLOC(con_pos, nc * 3); ALLOC(con_frame, nc * 9);
   d->con_pair = (int *)calloc((size_t)(nc > 0 ? nc : 1), sizeof(int));
-  ALLOC(efc_J, ne * nv); ALLOC(efc_D, ne); ALLOC(efc_aref, ne); ALLOC(efc_pos, ne); ALLOC(efc_force, ne);
+  ALLOC(efc_J, ne * nv); ALLOC(efc_D, ne); ALLOC(efc_aref, ne); ALLOC(efc_pos, ne); ALLOC(efc_force, ne); ALLOC(efc_floss, ne);
   ALLOC(w_a, nv); ALLOC(w_b, nv); ALLOC(w_c, nv); ALLOC(w_d, nv); ALLOC(w_e, nv); ALLOC(w_f, nv); ALLOC(w_g, nv);
   ALLOC(w_H, nv * nv + 3 * nv); ALLOC(w_L, nv * nv);
   ALLOC(w_jv, ne); ALLOC(w_jaref, ne); ALLOC(w_mass, nb * 4); ALLOC(w_quad, ne * 3);
@@ -241,7 +244,7 @@ void amxo_data_destroy(amxo_data *d) {
     &d->xanchor, &d->xaxis, &d->geom_xpos, &d->geom_xmat, &d->subtree_com, &d->cinert, &d->cdof, &d->crb, &d->qM, &d->qL,
     &d->cvel, &d->cdof_dot, &d->cacc, &d->cfrc, &d->qfrc_passive, &d->qfrc_bias, &d->qfrc_actuator, &d->qfrc_smooth,
     &d->qacc_smooth, &d->qacc, &d->qfrc_constraint, &d->actuator_moment_gear, &d->con_dist, &d->con_pos, &d->con_frame,
-    &d->efc_J, &d->efc_D, &d->efc_aref, &d->efc_pos, &d->efc_force, &d->w_a, &d->w_b, &d->w_c, &d->w_d, &d->w_e, &d->w_f, &d->w_g, &d->w_H, &d->w_L,
+    &d->efc_J, &d->efc_D, &d->efc_aref, &d->efc_pos, &d->efc_force, &d->efc_floss, &d->w_a, &d->w_b, &d->w_c, &d->w_d, &d->w_e, &d->w_f, &d->w_g, &d->w_H, &d->w_L,
     &d->w_jv, &d->w_jaref, &d->w_mass, &d->w_quad, &d->w_support};
   for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); i++) free(*ptrs[i]);
   free(d->con_pair);
@@ -896,6 +899,7 @@ static void finish_row(const amxo_model *m, amxo_data *d, int row, REAL pos, REA
   d->efc_D[row] = 1 / r;
   d->efc_aref[row] = -b * jv - k * imp * pos;
   d->efc_pos[row] = pos;
+  d->efc_floss[row] = 0;
 }
 /* translational Jacobian of a world point fixed to body b, into jac[3*nv] (row-major 3 x nv) [mjx:support.jac] */
 static void jac_point(const amxo_model *m, const amxo_data *d, REAL *jac, const REAL *point, int b, REAL sign) {
@@ -938,6 +942,21 @@ static void make_constraint(const amxo_model *m, amxo_data *d) {
     }
   }
   d->ne = row;
+  /* friction loss [mjx:constraint._instantiate_friction; MuJoCo engine_core_constraint.c mj_instantiateFriction]: one row per
+   * dof with frictionloss > 0: J = e_i, pos = 0 (aref = -b * qvel_i), D from the dof's invweight0 and solreffriction /
+   * solimpfriction; the force is bounded by +-frictionloss (update_constraint below) */
+  if (!(m->disableflags & DIS_FRICTIONLOSS)) {
+    for (int i = 0; i < nv; i++) {
+      if (!(m->dof_frictionloss[i] > 0)) continue;
+      REAL *J = d->efc_J + row * nv;
+      memset(J, 0, sizeof(REAL) * nv);
+      J[i] = 1;
+      finish_row(m, d, row, 0, m->dof_invweight0[i], m->dof_solref + 2 * i, m->dof_solimp + 5 * i);
+      d->efc_floss[row] = m->dof_frictionloss[i];
+      row++;
+    }
+  }
+  d->nf = row - d->ne;
   if (!(m->disableflags & DIS_LIMIT)) {
     for (int j = 0; j < m->njnt; j++) {
       if (!m->jnt_limited[j] || (m->jnt_type[j] != JSLIDE && m->jnt_type[j] != JHINGE)) continue;
@@ -1083,8 +1102,17 @@ static void update_constraint(const amxo_model *m, amxo_data *d, sctx *c) {
   memset(d->qfrc_constraint, 0, sizeof(REAL) * nv);
   for (int r = 0; r < ne; r++) {
     int active = (c->Jaref[r] < 0) || r < d->ne;
-    d->efc_force[r] = active ? -d->efc_D[r] * c->Jaref[r] : 0;
-    if (active) cost += (REAL)0.5 * d->efc_D[r] * c->Jaref[r] * c->Jaref[r];
+    if (d->efc_floss[r] > 0) {
+      /* friction row: quadratic while |D Jaref| < floss, linear beyond (the force saturates at +-floss)
+       * [MuJoCo mj_constraintUpdate: LINEARNEG / LINEARPOS / QUADRATIC] */
+      REAL f = d->efc_floss[r], rf = f / d->efc_D[r], z = c->Jaref[r];
+      if (z <= -rf) { d->efc_force[r] = f; cost += f * (-(REAL)0.5 * rf - z); }
+      else if (z >= rf) { d->efc_force[r] = -f; cost += f * (-(REAL)0.5 * rf + z); }
+      else { d->efc_force[r] = -d->efc_D[r] * z; cost += (REAL)0.5 * d->efc_D[r] * z * z; }
+    } else {
+      d->efc_force[r] = active ? -d->efc_D[r] * c->Jaref[r] : 0;
+      if (active) cost += (REAL)0.5 * d->efc_D[r] * c->Jaref[r] * c->Jaref[r];
+    }
     if (d->efc_force[r] != 0)
       for (int i = 0; i < nv; i++) d->qfrc_constraint[i] += d->efc_J[r * nv + i] * d->efc_force[r];
   }
@@ -1102,6 +1130,7 @@ static void update_gradient(const amxo_model *m, amxo_data *d, sctx *c) {
   memcpy(H, d->qM, sizeof(REAL) * nv * nv);
   for (int r = 0; r < ne; r++) {
     int active = (c->Jaref[r] < 0) || r < d->ne;
+    if (d->efc_floss[r] > 0) { REAL rf = d->efc_floss[r] / d->efc_D[r]; active = c->Jaref[r] > -rf && c->Jaref[r] < rf; } /* quadratic zone only */
     if (!active) continue;
     const REAL *J = d->efc_J + r * nv;
     for (int i = 0; i < nv; i++) {
@@ -1117,6 +1146,13 @@ static lspoint ls_point(const amxo_data *d, const sctx *c, const REAL *jv, const
   REAL q0 = qg[0], q1 = qg[1], q2 = qg[2];
   for (int r = 0; r < d->nefc; r++) {
     REAL x = c->Jaref[r] + alpha * jv[r];
+    if (d->efc_floss[r] > 0) { /* friction row: the zone at alpha decides the quadratic's coefficients [mjx:solver._while_loop ls point] */
+      REAL f = d->efc_floss[r], rf = f / d->efc_D[r];
+      if (x <= -rf) { q0 += f * (-(REAL)0.5 * rf - c->Jaref[r]); q1 += -f * jv[r]; continue; }
+      if (x >= rf) { q0 += f * (-(REAL)0.5 * rf + c->Jaref[r]); q1 += f * jv[r]; continue; }
+      q0 += (REAL)0.5 * c->Jaref[r] * c->Jaref[r] * d->efc_D[r]; q1 += jv[r] * c->Jaref[r] * d->efc_D[r]; q2 += (REAL)0.5 * jv[r] * jv[r] * d->efc_D[r];
+      continue;
+    }
     if (x < 0 || r < d->ne) {
       q0 += (REAL)0.5 * c->Jaref[r] * c->Jaref[r] * d->efc_D[r];
       q1 += jv[r] * c->Jaref[r] * d->efc_D[r];

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.lib()
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.amx_version() == 2
+    assert lib.amx_version() == 3
 
 
 def test_desc_layout_matches_c(tmp_path):
@@ -157,7 +157,7 @@ def test_per_model_specialised_build():
     path = _spec.build_specialised_library(mj)
     assert path.exists() and path == _spec.build_specialised_library(mj)  # cached
     L = _lib.load(path)
-    assert L.amx_version() == 2
+    assert L.amx_version() == 3
     mj2 = jit_test_model_equality()
     p2 = _spec.plan(mj2)
     assert p2["neq"] == "1" and p2["G"] == "32" and p2["fusedH"] == "0"

@@ -128,6 +128,79 @@ def test_limit_row_closed_form_gpu():
         assert f["nefc"] == 1
 
 
+FRICTION_HINGE = """<mujoco><option timestep="0.002" gravity="0 0 0" iterations="30" ls_iterations="30"/><worldbody>
+  <body><joint name="h" type="hinge" axis="0 0 1" frictionloss="1.0"/><inertial pos="0 0 0" mass="1" diaginertia="0.05 0.05 0.05"/></body>
+</worldbody><actuator><motor joint="h" gear="1"/></actuator></mujoco>"""
+
+# Dry joint friction (SURVEY.md A9.6 "friction loss" rows; reaches the reference through URDF <dynamics friction=...>).  One hinge,
+# inertia I = 0.05, no gravity, frictionloss f = 1, motor torque tau, default solreffriction (0.02, 1) / solimpfriction (0.9, ...).
+# The friction row has J = 1, pos = 0, so its impedance is d(0) = 0.9, R = (1 - imp)/imp * invweight0 = (1/9)(1/I), D = 9 I = 0.45,
+# aref = -b v with b = 2/(dmax tc) = 105.26316, and its force is clamped to +-f: with z = a - aref,
+#   stick (|D z| < f):  minimise 1/2 I a^2 - tau a + 1/2 D z^2  ->  a = (tau + D aref) / (I + D)
+#   slip:               force = -f sign(z)                      ->  a = (tau - f sign(z)) / I
+#   v = 0,   tau = 0.5: a = 0.5 / 0.5 = 1            (D a = 0.45 < 1: stick)
+#   v = 0,   tau = 3:   a = (3 - 1) / 0.05 = 40      (0.9 tau >= f: slip);  tau = -3: a = -40
+#   v = 0.2, tau = 0:   a = -0.9 * 105.26316 * 0.2 = -18.947368   (z = 2.105 < f / D = 2.222: stick)
+#   v = 0.5, tau = 0:   a = -f / I = -20                          (z = -20 + 52.63 = 32.6 >= 2.222: slip)
+FRICTION_CASES = [(0.0, 0.5, 1.0), (0.0, 3.0, 40.0), (0.0, -3.0, -40.0), (0.2, 0.0, -18.947368421), (0.5, 0.0, -20.0)]
+
+
+def test_friction_loss_closed_form_oracle():
+    """The CPU restatement's friction-loss row: regulariser, reference acceleration, both zones of the bounded force."""
+    from oracle.oracle import Oracle
+    mj = MjModel.from_xml_string(FRICTION_HINGE)
+    assert mj.dof_frictionloss.tolist() == [1.0] and abs(mj.dof_invweight0[0] - 20.0) < 1e-12
+    for dt in (np.float64, np.float32):
+        o = Oracle(mj, dt)
+        for v, tau, want in FRICTION_CASES:
+            o.set_state(np.array([0.0]), np.array([v]), np.array([tau])); o.forward()
+            assert abs(o.get("qacc")[0] - want) < (1e-9 if dt is np.float64 else 2e-5) * abs(want), (v, tau, o.get("qacc")[0], want)
+            assert int(o.get("nefc")[0]) == 1
+    # the flag <option><flag frictionloss="disable"/> removes the row
+    off = MjModel.from_xml_string(FRICTION_HINGE.replace('iterations="30"', 'iterations="30"><flag frictionloss="disable"/></option><option'))
+    o = Oracle(off, np.float64)
+    o.set_state(np.array([0.0]), np.array([0.0]), np.array([0.5])); o.forward()
+    assert abs(o.get("qacc")[0] - 10.0) < 1e-9 and int(o.get("nefc")[0]) == 0
+
+
+@pytest.mark.gpu
+def test_friction_loss_closed_form_gpu():
+    """The same numbers from the HIP path (amx_forward, never through the oracle), then a step-level check against the oracle on a
+    two-link arm with friction on both joints, limits and gravity (generic kernels and a per-model build)."""
+    import torch
+    from test_gpu_kat import Gpu
+    from oracle.oracle import Oracle
+    dev = torch.device("cuda", 0)
+    mj = MjModel.from_xml_string(FRICTION_HINGE)
+    g = Gpu(mj, dev)
+    for v, tau, want in FRICTION_CASES:
+        f = g.forward(np.array([0.0]), np.array([v]), np.array([tau]))
+        assert abs(f["qacc"][0] - want) < 2e-5 * abs(want), (v, tau, f["qacc"][0], want)
+        assert f["nefc"] == 1
+    arm = MjModel.from_xml_string(FRICTION_ARM)
+    assert arm.dof_frictionloss.tolist() == [0.3, 0.1]
+    rng = np.random.default_rng(5)
+    x0 = np.concatenate([rng.uniform(-1.0, 1.0, (16, 2)), rng.uniform(-3, 3, (16, 2))], axis=1)
+    x0[:4, 2:] = 0.0  # some start at rest: the rows hold them (stick)
+    us = rng.uniform(-1, 1, (16, 20, 2))
+    ref = Oracle(arm, np.float64).rollout(x0, us)
+    for spec in (False, True):
+        from ambersim_amd import mjx
+        model = mjx.put_model(arm, dev, specialise=spec)
+        xs = mjx.rollout(model, torch.tensor(x0, dtype=torch.float32), torch.tensor(us, dtype=torch.float32)).cpu().numpy()
+        err1 = np.abs(xs[:, 1] - ref[:, 1]).max() / max(1.0, np.abs(ref[:, 1]).max())
+        err20 = np.abs(xs[:, 20] - ref[:, 20]).max() / max(1.0, np.abs(ref[:, 20]).max())
+        assert err1 < 1e-5 and err20 < 1e-4, (spec, err1, err20)
+
+
+FRICTION_ARM = """<mujoco><compiler angle="radian"/><option timestep="0.002" iterations="10" ls_iterations="10"/><worldbody>
+  <body pos="0 0 1"><joint name="a" type="hinge" axis="0 1 0" frictionloss="0.3" damping="0.05" range="-2 2"/>
+    <geom type="capsule" fromto="0 0 0 0 0 -0.4" size="0.03" mass="1" contype="0" conaffinity="0"/>
+    <body pos="0 0 -0.4"><joint name="b" type="hinge" axis="0 1 0" frictionloss="0.1" armature="0.01" range="-1.5 1.5"/>
+      <geom type="capsule" fromto="0 0 0 0 0 -0.3" size="0.025" mass="0.5" contype="0" conaffinity="0"/></body></body>
+</worldbody><actuator><motor joint="a" gear="2" ctrlrange="-1 1"/><motor joint="b" gear="1" ctrlrange="-1 1"/></actuator></mujoco>"""
+
+
 BALL_ON_PLANE = """<mujoco><option timestep="0.002" iterations="30" ls_iterations="30"/><worldbody>
   <geom type="plane" size="2 2 0.1" friction="1 0.005 0.0001"/>
   <body pos="0 0 0.1"><freejoint/><geom type="sphere" size="0.1" mass="0.7" friction="1 0.005 0.0001"/></body>

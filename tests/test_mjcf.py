@@ -94,7 +94,6 @@ def test_compiler_features():
 @pytest.mark.parametrize("snippet,exc", [
     ('<option cone="elliptic"/>', NotImplementedError),
     ('<option integrator="RK4"/>', None),  # compiles on the host; rejected when put on the device
-    ('<worldbody><body><joint type="hinge" frictionloss="0.1"/><geom size="0.1"/></body></worldbody>', NotImplementedError),
     ('<equality><weld body1="a" body2="b"/></equality>', NotImplementedError),
 ])
 def test_unsupported_features_raise(snippet, exc):
@@ -105,3 +104,15 @@ def test_unsupported_features_raise(snippet, exc):
     else:
         with pytest.raises(exc):
             MjModel.from_xml_string(xml)
+
+
+def test_joint_frictionloss_compiles_to_dof_fields():
+    """Dry joint friction (MJCF frictionloss / URDF <dynamics friction>) is carried since r03: every dof of the
+    joint gets the joint's frictionloss and its solreffriction / solimpfriction; a negative value is refused."""
+    from ambersim_amd.mjcf import MjModel
+    m = MjModel.from_xml_string("""<mujoco><worldbody><body><joint type="hinge" frictionloss="0.1" solreffriction="0.03 1"/><geom size="0.1"/>
+        <body pos="0 0 1"><joint type="ball" frictionloss="0.2"/><geom size="0.1"/></body></body></worldbody></mujoco>""")
+    assert m.dof_frictionloss.tolist() == [0.1, 0.2, 0.2, 0.2]
+    assert m.dof_solref.tolist() == [[0.03, 1.0]] + [[0.02, 1.0]] * 3 and m.dof_solimp.shape == (4, 5)
+    with pytest.raises(ValueError):
+        MjModel.from_xml_string('<mujoco><worldbody><body><joint type="hinge" frictionloss="-1"/><geom size="0.1"/></body></worldbody></mujoco>')
