@@ -25,7 +25,8 @@ _INT_FIELDS_6 = ["actuator_trnid", "actuator_biastype", "actuator_ctrllimited", 
 _DBL_FIELDS_6 = ["actuator_gear", "actuator_gainprm", "actuator_biasprm", "actuator_ctrlrange", "actuator_forcerange"]
 _INT_FIELDS_7 = ["eq_obj1id", "eq_obj2id", "eq_active"]
 _DBL_FIELDS_7 = ["eq_data", "eq_solref", "eq_solimp"]
-_DBL_FIELDS_8 = ["dof_frictionloss", "dof_solref", "dof_solimp"]  # version 3, appended
+_INT_FIELDS_8 = ["eq_type"]  # version 3, appended (eq_data is [neq, 11] since then)
+_DBL_FIELDS_8 = ["dof_frictionloss", "dof_solref", "dof_solimp"]
 
 
 def _ptr_fields():
@@ -33,7 +34,7 @@ def _ptr_fields():
     for ints, dbls in [(_INT_FIELDS_1, _DBL_FIELDS_1), (_INT_FIELDS_2, _DBL_FIELDS_2), (_INT_FIELDS_3, _DBL_FIELDS_3),
                        (_INT_FIELDS_4, _DBL_FIELDS_4), (_INT_FIELDS_5, _DBL_FIELDS_5), (_INT_FIELDS_5B, _DBL_FIELDS_5B), (_INT_FIELDS_5C, []),
                        (_INT_FIELDS_6, _DBL_FIELDS_6),
-                       (_INT_FIELDS_7, _DBL_FIELDS_7), ([], _DBL_FIELDS_8)]:
+                       (_INT_FIELDS_7, _DBL_FIELDS_7), (_INT_FIELDS_8, _DBL_FIELDS_8)]:
         out += [(n, _I) for n in ints] + [(n, _D) for n in dbls]
     return out
 

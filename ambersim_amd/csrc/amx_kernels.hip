@@ -1457,6 +1457,7 @@ struct Env {
   float rJ1, rJ2;      // equality / limit row `gl`: Jacobian entries on dofs rd1, rd2
   int rd1, rd2;
   bool aact, cact;  // the slot's row is active at the current iterate (set by constraint_force_and_grad)
+  bool cEq;         // the lane's slot B row belongs to a connect / weld equality (a pseudo-pair, [npc, npair)): active on both sides
   PROF_DECL
 
   DEV int nA() const { return m.nefc() == 0 ? 0 : m.neq() + m.nfri() + m.nlim(); }  // nefc == 0: constraints disabled
@@ -1483,7 +1484,12 @@ struct Env {
     else if (lane < m.neq() + m.nfri()) rd1 = CI(m.c_fri() + (lane - m.neq()) * FRI_S);
     else if (lane < m.neq() + m.nfri() + m.nlim()) rd1 = CI(m.c_lim() + (lane - m.neq() - m.nfri()) * LIM_S + 1);
     vch_base = eb + m.e_vch();
-    if (lane < 4 * m.ncon()) vch_base += CI(m.c_conpair() + (lane >> 2)) * m.ldc();
+    cEq = false;
+    if (lane < 4 * m.ncon()) {
+      const int pr_ = CI(m.c_conpair() + (lane >> 2));
+      vch_base += pr_ * m.ldc();
+      cEq = m.npair() > m.npc() && pr_ >= m.npc();
+    }
     {
       const int nvch = m.npair() * m.ldc();
       vch_dof = CI(m.c_vchdof() + (lane < nvch ? lane : 0));
@@ -2041,15 +2047,39 @@ struct Env {
     // plane - convex pairs with at most 32 hull vertices: one lane per hull vertex (plane_convex_parallel), on groups of 32
     // lanes (one pair per pass) and 64 lanes (two).  The planner found the run of such pairs (pcx_first, npcx).
     const int cx_first = G >= 32 ? m.pcx_first() : 0, cx_num = G >= 32 ? m.npcx() : 0;
-    if (G >= 32 && cx_num > 0)  // uniform: a property of the model
+    const bool contacts_on = !(m.disableflags() & DIS_CONTACT);
+    if (G >= 32 && cx_num > 0 && contacts_on)  // uniform: a property of the model
     {
       if constexpr (S::is_static) plane_convex_parallel_body<G, (S::pcx_unit == 16 && G >= 32) ? 16 : 32>(cx_first, cx_num, m.c_pair(), m.c_vert(), eb + m.e_geom(), eb + m.e_con(), eb + m.e_frame(), gl, gb4);
       else if (m.pcx_unit() == 16) plane_convex_parallel<G, G >= 32 ? 16 : 32>(cx_first, cx_num, m.c_pair(), m.c_vert(), eb + m.e_geom(), eb + m.e_con(), eb + m.e_frame(), gl, gb4);
       else plane_convex_parallel<G, 32>(cx_first, cx_num, m.c_pair(), m.c_vert(), eb + m.e_geom(), eb + m.e_con(), eb + m.e_frame(), gl, gb4);
     }
-    if (m.ncx() > 0)  // uniform: a property of the model
+    if (m.ncx() > 0 && contacts_on)  // uniform: a property of the model
       convex_convex_pairs<G>(m.cx_first(), m.ncx(), m.c_pair(), eb + m.e_geom(), eb + m.e_con(), eb + m.e_frame(), eb + m.e_cx(), gl, gb4);
-    if (gl < np && !(gl >= cx_first && gl < cx_first + cx_num) && !(gl >= m.cx_first() && gl < m.cx_first() + m.ncx())) {
+    if (m.npair() > m.npc() && !(m.disableflags() & DIS_EQUALITY) && gl >= m.npc() && gl < np) {
+      // Row groups of the connect / weld equalities (oracle: make_constraint, connect and weld): the residual of
+      // the group and what its Jacobian entries need, while the body poses are still at hand.  Function 8: a point fixed in
+      // body1 against a point fixed in body2; function 9 (second group of a weld): the relative orientation against relpose.
+      // All rows of one equality share the impedance of the norm of its whole residual: con(0) = that norm, con(1..3) = the
+      // group's three residual components; the frame slot carries the two world points (8) or the two quaternions (9).
+      const int pr = gl, rec = m.c_pair() + pr * PAIR_S;
+      const int b1 = CI(rec), b2 = CI(rec + 1), fn = CI(rec + 2), c0 = CI(rec + 3), weld = CI(rec + 5);
+      const float ts = CF(rec + 11);
+      const f4 q1 = ld_xquat(b1), q2 = ld_xquat(b2), rq = {CF(rec + 29), CF(rec + 30), CF(rec + 31), CF(rec + 32)};
+      const f3 p1 = ld_xpos(b1) + qrot(q1, mk3(CF(rec + 23), CF(rec + 24), CF(rec + 25)));
+      const f3 p2 = ld_xpos(b2) + qrot(q2, mk3(CF(rec + 26), CF(rec + 27), CF(rec + 28)));
+      const f3 cpos = p1 - p2;
+      const f4 q1r = qmul(q1, rq), q2c = {q2.w, -q2.x, -q2.y, -q2.z};
+      const f4 qe = qmul(q2c, q1r);
+      const f3 crot = mk3(qe.x * ts, qe.y * ts, qe.z * ts);
+      const float nrm = sqrtf(dot(cpos, cpos) + (weld ? dot(crot, crot) : 0.0f));
+      const f3 res = fn == 8 ? cpos : crot;
+      con(0, c0) = nrm; con(1, c0) = res.x; con(2, c0) = res.y; con(3, c0) = res.z;
+      const int fo = eb + m.e_frame() + pr * 9;
+      if (fn == 8) { lds[fo] = p1.x; lds[fo + 1] = p1.y; lds[fo + 2] = p1.z; lds[fo + 3] = p2.x; lds[fo + 4] = p2.y; lds[fo + 5] = p2.z; }
+      else { lds[fo] = q1r.w; lds[fo + 1] = q1r.x; lds[fo + 2] = q1r.y; lds[fo + 3] = q1r.z; lds[fo + 4] = q2c.w; lds[fo + 5] = q2c.x; lds[fo + 6] = q2c.y; lds[fo + 7] = q2c.z; }
+    }
+    if (gl < m.npc() && !(m.disableflags() & DIS_CONTACT) && !(gl >= cx_first && gl < cx_first + cx_num) && !(gl >= m.cx_first() && gl < m.cx_first() + m.ncx())) {
       const int pr = gl, rec = m.c_pair() + pr * PAIR_S;
       const int g1 = CI(rec), g2 = CI(rec + 1), fn = CI(rec + 2), c0 = CI(rec + 3);
       const f3 pos1 = mk3(geo(0, g1), geo(1, g1), geo(2, g1)), pos2 = mk3(geo(0, g2), geo(1, g2), geo(2, g2));
@@ -2197,7 +2227,8 @@ struct Env {
     const int qp = eb + m.e_qpos(), qv = eb + m.e_qvel();
     const bool con_on = !(m.disableflags() & DIS_CONSTRAINT);
     const int row0 = m.neq() + m.nfri() + m.nlim();
-    if (con_on && !(m.disableflags() & DIS_CONTACT)) {
+    const bool eq_groups = m.npair() > m.npc();  // a property of the model: connect / weld equalities present
+    if (con_on && (!(m.disableflags() & DIS_CONTACT) || eq_groups)) {
       // contact Jacobian entries: one lane per (contact, dof of the pair's ancestor chains); rows are stored
       // chain-compressed: Jc[contact row][slot], slot = position of the dof in the pair's dof list
       struct JEnt { int at; float r0, r1, r2, r3; };
@@ -2212,6 +2243,24 @@ struct Env {
           const f3 fn_ = mk3(lds[fo], lds[fo + 1], lds[fo + 2]), ft1 = mk3(lds[fo + 3], lds[fo + 4], lds[fo + 5]),
                    ft2 = mk3(lds[fo + 6], lds[fo + 7], lds[fo + 8]);
           const f3 w = mk3(dof(0, i), dof(1, i), dof(2, i)), l = mk3(dof(3, i), dof(4, i), dof(5, i));
+          if (eq_groups && pr >= m.npc()) {
+            // a connect / weld row group (oracle: make_constraint): body1's Jacobian minus body2's
+            const bool s1 = sg & 1, s2 = sg & 2;  // the dof moves body2 / body1
+            const int at = Jo + (4 * c) * ldc + slot;
+            if (CI(rec + 2) == 8) {  // points: fo holds p1 (fixed in body1), p2 (fixed in body2)
+              const f3 p1 = fn_, p2 = ft1;
+              const f3 a1 = l + cross(w, p1 - ld_com(root1)), a2 = l + cross(w, p2 - ld_com(root2));
+              const f3 jp8 = mk3((s2 ? a1.x : 0.0f) - (s1 ? a2.x : 0.0f), (s2 ? a1.y : 0.0f) - (s1 ? a2.y : 0.0f), (s2 ? a1.z : 0.0f) - (s1 ? a2.z : 0.0f));
+              return JEnt{at, jp8.x, jp8.y, jp8.z, 0.0f};
+            }
+            // orientation: 0.5 * vec(conj(q2) * (0, jacr1 - jacr2) * q1 * relpose) * torquescale; fo holds q1 * relpose and conj(q2)
+            const float sgn = (s2 ? 1.0f : 0.0f) - (s1 ? 1.0f : 0.0f);
+            const f4 q1r = {lds[fo], lds[fo + 1], lds[fo + 2], lds[fo + 3]}, q2c = {lds[fo + 4], lds[fo + 5], lds[fo + 6], lds[fo + 7]};
+            const f4 jw = {0.0f, sgn * w.x, sgn * w.y, sgn * w.z};
+            const f4 v = qmul(qmul(q2c, jw), q1r);
+            const float h = 0.5f * mu;  // field 11 of an equality group is its torquescale
+            return JEnt{at, h * v.x, h * v.y, h * v.z, 0.0f};
+          }
           f3 jp;
           if (m.jac_one_sided()) {  // a property of the model: contacts with the ground only - one arm, no selects
             jp = l + cross(w, pt - ld_com(root2));
@@ -2288,8 +2337,21 @@ struct Env {
     aD = dd;
     aAref = ar;
     aFl = fl_;
-    // slot B: contact pyramid row gl
+    // slot B: contact pyramid row gl, or row gl of a connect / weld group
     dd = 0; ar = 0;
+    if (eq_groups && cEq) {
+      // three rows per group (the fourth idles), always active, impedance at the norm of the equality's whole residual
+      const int cr = gl, c = cr >> 2, k = cr & 3;
+      const int prec = m.c_pair() + CI(m.c_conpair() + c) * PAIR_S, rec = prec + 12;
+      const float nrm = con(0, c), pos = con(1 + (k < 3 ? k : 0), c), invw = CF(prec + 22);
+      const float jv = chain_dot(Jo + cr * ldc);
+      if (con_on && k < 3 && !(m.disableflags() & DIS_EQUALITY)) {
+        const float imp = row_impedance(rec, nrm);
+        const float rr = fmaxf(fdiv(invw * (1 - imp), imp), MINVAL);
+        dd = fdiv(1.0f, rr);
+        ar = -CF(rec + 1) * jv - CF(rec) * imp * pos;
+      }
+    } else
     if (con_on && gl < nB() && !(m.disableflags() & DIS_CONTACT)) {
       const int cr = gl, c = cr >> 2, k = cr & 3;
       const int pr = CI(m.c_conpair() + c), prec = m.c_pair() + pr * PAIR_S;
@@ -2397,7 +2459,8 @@ struct Env {
     WSYNC();
   }
   DEV float constraint_cost(int vf, float *gauss_out) const {
-    const bool actA = (gl < nA()) & ((aJaref < 0) | (gl < m.neq())), actB = (gl < nB()) & (cJaref < 0);
+    const bool eqB = m.npair() > m.npc() && cEq;  // rows of connect / weld groups are active on both sides
+    const bool actA = (gl < nA()) & ((aJaref < 0) | (gl < m.neq())), actB = (gl < nB()) & ((cJaref < 0) | eqB);
     float ca_ = actA ? 0.5f * aD * aJaref * aJaref : 0.0f;
     if (m.nfri() > 0) {  // a property of the model.  Friction-loss rows: quadratic inside |Jaref| < rf = aFl / aD, linear outside
       const float rf = fdiv(aFl, fmaxf(aD, MINVAL)), z = aJaref;
@@ -2437,7 +2500,7 @@ struct Env {
   DEV void constraint_force_and_grad(bool defer = false, bool alive = true) {
     const int Jo = eb + m.e_J(), ldc = m.ldc(), row0 = m.neq() + m.nfri() + m.nlim();
     aact = (gl < nA()) & ((aJaref < 0) | (gl < m.neq())) & (aD > 0);
-    cact = (gl < nB()) & (cJaref < 0) & (cD > 0);
+    cact = (gl < nB()) & ((cJaref < 0) | (m.npair() > m.npc() && cEq)) & (cD > 0);
     float f = aact ? -aD * aJaref : 0.0f;
     const float fc = cact ? -cD * cJaref : 0.0f;
     if (m.nfri() > 0) {  // friction-loss rows: the force saturates at +-aFl; only the quadratic zone enters the Hessian
@@ -2589,7 +2652,7 @@ struct Env {
   struct LSTerms { float q1, q2; };
   DEV LSTerms ls_terms(float alpha, bool validA, bool validB, bool iseq, float *q0 = nullptr) const {
     const float xA = aJaref + alpha * aJv;
-    const bool actA = validA & ((xA < 0) | iseq), actB = validB & (cJaref + alpha * cJv < 0);
+    const bool actA = validA & ((xA < 0) | iseq), actB = validB & ((cJaref + alpha * cJv < 0) | (m.npair() > m.npc() && cEq));
     float a1 = actA ? aJv * aJaref * aD : 0.0f, a2 = actA ? 0.5f * aJv * aJv * aD : 0.0f, a0 = actA ? 0.5f * aJaref * aJaref * aD : 0.0f;
     if (m.nfri() > 0) {  // friction-loss rows: the zone at alpha picks the coefficients (quadratic inside |x| < rf, linear outside)
       const bool fri = aFl > 0.0f;
@@ -2821,7 +2884,7 @@ struct Env {
     PROF(1);
     com_pos();
     PROF(2);
-    if (m.ncon() > 0 && !(m.disableflags() & (DIS_CONTACT | DIS_CONSTRAINT))) collision();
+    if (m.ncon() > 0 && !(m.disableflags() & DIS_CONSTRAINT) && (!(m.disableflags() & DIS_CONTACT) || m.npair() > m.npc())) collision();  // contacts, and the connect / weld residuals
     PROF(4);
     crb_and_M();
     PROF(3);

@@ -35,7 +35,7 @@ struct Image {
   int geti(int off) const { int x; memcpy(&x, &v[off], 4); return x; }
   void setf(int off, double x) { v[off] = (float)x; }
 };
-const int PAIR_NCON[8] = {1, 2, 4, 1, 1, 1, 4, 1};
+const int PAIR_NCON[10] = {1, 2, 4, 1, 1, 1, 4, 1, 1, 1};  // 8, 9: one row group each (connect / weld-translation, weld-rotation)
 
 // {k, b, dmin, dmax, width, mid, power, ca, cb}: the position-independent part of MuJoCo's solref/solimp
 // mapping (reference physics: constraint._kbi), evaluated once on the host in double precision.
@@ -86,7 +86,11 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
   if (d->solver != 1 && d->solver != 2) return fail(AMX_EUNSUPPORTED, "solver must be CG (1) or Newton (2), got %d", d->solver);
   if (d->nv < 1) return fail(AMX_EUNSUPPORTED, "model has no degrees of freedom");
   if (d->nv > AMX_MAX_NV) return fail(AMX_ECAPACITY, "nv=%d exceeds the register-row factorisation capacity %d", d->nv, AMX_MAX_NV);
-  const int nb = d->nbody, nv = d->nv, nq = d->nq, nu = d->nu, nj = d->njnt, np = d->npair;
+  // connect / weld equalities ride in the contact rows' machinery as pseudo-pairs behind the collision pairs: one row group per
+  // connect (3 rows + 1 idle), two per weld (translation, rotation)
+  int neqgroups = 0;
+  for (int e = 0; e < d->neq; e++) if (d->eq_active[e] && d->eq_type[e] >= 0 && d->eq_type[e] <= 1) neqgroups += d->eq_type[e] == 1 ? 2 : 1;
+  const int nb = d->nbody, nv = d->nv, nq = d->nq, nu = d->nu, nj = d->njnt, npc = d->npair, np = d->npair + neqgroups;
   if (nb > AMX_WAVE || nj > AMX_WAVE || np > AMX_WAVE)
     return fail(AMX_ECAPACITY, "lane-role capacity: nbody=%d njnt=%d npair=%d must each be <= %d", nb, nj, np, AMX_WAVE);
 
@@ -119,19 +123,20 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
       if (i < d->jnt_dofadr[j] || i >= d->jnt_dofadr[j] + DW[d->jnt_type[j]]) return fail(AMX_EINVAL, "dof %d does not belong to its joint %d", i, j);
     }
     for (int g = 0; g < d->ngeom; g++) AMX_CHK(geom_bodyid, g, 0, nb);
-    for (int p = 0; p < np; p++) {
+    for (int p = 0; p < npc; p++) {
       AMX_CHK(pair_geom1, p, 0, d->ngeom);
       AMX_CHK(pair_geom2, p, 0, d->ngeom);
     }
     for (int e = 0; e < d->neq; e++) {
-      AMX_CHK(eq_obj1id, e, 0, nj);
-      AMX_CHK(eq_obj2id, e, -1, nj);
+      AMX_CHK(eq_type, e, 0, 3);
+      if (d->eq_type[e] == 2) { AMX_CHK(eq_obj1id, e, 0, nj); AMX_CHK(eq_obj2id, e, -1, nj); }
+      else { AMX_CHK(eq_obj1id, e, 0, nb); AMX_CHK(eq_obj2id, e, 0, nb); }
     }
 #undef AMX_CHK
   }
 
   memset(&m, 0, sizeof(m));
-  m.nq = nq; m.nv = nv; m.nu = nu; m.nb = nb; m.njnt = nj; m.npair = np;
+  m.nq = nq; m.nv = nv; m.nu = nu; m.nb = nb; m.njnt = nj; m.npair = np; m.npc = npc;
   m.iterations = d->iterations; m.ls_iterations = d->ls_iterations; m.solver = d->solver; m.disableflags = d->disableflags;
   m.dt = (float)d->timestep; m.gx = (float)d->gravity[0]; m.gy = (float)d->gravity[1]; m.gz = (float)d->gravity[2];
   m.tolerance = (float)d->tolerance; m.ls_tolerance = (float)d->ls_tolerance; m.impratio = (float)d->impratio;
@@ -233,7 +238,7 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
   // collision geoms (only those that appear in a pair)
   std::vector<int> gmap(d->ngeom > 0 ? d->ngeom : 1, -1), gc_src;
   auto use_geom = [&](int g) { if (gmap[g] < 0) { gmap[g] = (int)gc_src.size(); gc_src.push_back(g); } return gmap[g]; };
-  for (int p = 0; p < np; p++) { use_geom(d->pair_geom1[p]); use_geom(d->pair_geom2[p]); }
+  for (int p = 0; p < npc; p++) { use_geom(d->pair_geom1[p]); use_geom(d->pair_geom2[p]); }
   m.ngc = (int)gc_src.size();
   if (m.ngc > AMX_WAVE) return fail(AMX_ECAPACITY, "%d collision geoms exceed the lane-role capacity %d", m.ngc, AMX_WAVE);
   m.c_geom = im.reserve(m.ngc * GEOM_S);
@@ -282,15 +287,39 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
   std::vector<std::vector<int>> dofmem(nv), hmembers(nv * (nv + 1) / 2);
   int maxchain = 1;
   int ncon = 0;
+  // the equality row groups behind the collision pairs: (equality, 8 = points / 9 = orientation)
+  std::vector<std::pair<int, int>> eqgroup;
+  for (int e = 0; e < d->neq; e++)
+    if (d->eq_active[e] && d->eq_type[e] <= 1) { eqgroup.push_back({e, 8}); if (d->eq_type[e] == 1) eqgroup.push_back({e, 9}); }
   for (int p = 0; p < np; p++) {
-    int g1 = d->pair_geom1[p], g2 = d->pair_geom2[p], fn = d->pair_fn[p], o = m.c_pair + p * PAIR_S;
+    const int o = m.c_pair + p * PAIR_S;
+    int fn, b1, b2, g1 = 0, g2 = 0;
+    if (p >= npc) {
+      // connect / weld: bodies instead of geoms, body-fixed points and the relative orientation instead of shapes
+      const int e = eqgroup[p - npc].first;
+      fn = eqgroup[p - npc].second;
+      b1 = d->eq_obj1id[e]; b2 = d->eq_obj2id[e];
+      const double *dat = d->eq_data + 11 * e;
+      const bool weld = d->eq_type[e] == 1;
+      im.seti(o, b1); im.seti(o + 1, b2); im.seti(o + 2, fn); im.seti(o + 3, ncon); im.seti(o + 4, 1);
+      im.seti(o + 5, weld ? 1 : 0);
+      im.seti(o + 7, root_slot[b1]); im.seti(o + 8, root_slot[b2]);
+      im.setf(o + 11, weld ? dat[10] : 1.0);
+      write_kbi(im, o + 12, d->eq_solref + 2 * e, d->eq_solimp + 5 * e, d->timestep, refsafe);
+      im.setf(o + 21, 0.0);
+      im.setf(o + 22, d->body_invweight0[2 * b1 + (fn == 9)] + d->body_invweight0[2 * b2 + (fn == 9)]);
+      // the point fixed in body1 and the one fixed in body2 (eq_data layout: include/amx.h)
+      for (int k = 0; k < 3; k++) { im.setf(o + 23 + k, weld ? dat[3 + k] : dat[k]); im.setf(o + 26 + k, weld ? dat[k] : dat[3 + k]); }
+      for (int k = 0; k < 4; k++) im.setf(o + 29 + k, weld ? dat[6 + k] : (k == 0 ? 1.0 : 0.0));
+    } else {
+    g1 = d->pair_geom1[p]; g2 = d->pair_geom2[p]; fn = d->pair_fn[p];
     if (fn < 0 || fn > 7) return fail(AMX_EUNSUPPORTED, "pair %d: unknown collision function %d", p, fn);
     if (fn == 7 && (d->pair_hull2[p] < 0 || d->pair_hull2[p] >= d->nhull)) return fail(AMX_EINVAL, "pair %d: sphere-convex pair without a hull", p);
     if (fn == 6 && (d->pair_hull1[p] < 0 || d->pair_hull1[p] >= d->nhull || d->pair_hull2[p] < 0 || d->pair_hull2[p] >= d->nhull))
       return fail(AMX_EINVAL, "pair %d: convex-convex pair without hulls", p);
     if (fn == 2 && (d->pair_vertnum[p] < 1 || d->pair_vertadr[p] < 0 || d->pair_vertadr[p] + d->pair_vertnum[p] > d->nconvexvert))
       return fail(AMX_EINVAL, "pair %d: bad convex vertex range", p);
-    int b1 = d->geom_bodyid[g1], b2 = d->geom_bodyid[g2];
+    b1 = d->geom_bodyid[g1]; b2 = d->geom_bodyid[g2];
     im.seti(o, gmap[g1]); im.seti(o + 1, gmap[g2]); im.seti(o + 2, fn); im.seti(o + 3, ncon); im.seti(o + 4, PAIR_NCON[fn]);
     im.seti(o + 5, fn == 2 ? d->pair_vertadr[p] : 0); im.seti(o + 6, fn == 2 ? d->pair_vertnum[p] : 0);
     im.seti(o + 7, root_slot[b1]); im.seti(o + 8, root_slot[b2]);
@@ -300,6 +329,7 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
     write_kbi(im, o + 12, d->pair_solref + 2 * p, d->pair_solimp + 5 * p, d->timestep, refsafe);
     im.setf(o + 21, d->pair_margin[p]);
     im.setf(o + 22, d->body_invweight0[2 * b1] + d->body_invweight0[2 * b2]);
+    }
     // union of the ancestor dof chains of both bodies
     std::vector<int> sign(nv, 0);
     for (int side = 0; side < 2; side++) {
@@ -333,10 +363,10 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
   m.ncon = ncon; m.njac = (int)jac_items.size(); m.nhent = (int)hent.size();
   m.jac_one_sided = 1;
   for (int it : jac_items) if (((it >> 16) & 3) != 1) m.jac_one_sided = 0;
-  if (ncon > 16) return fail(AMX_ECAPACITY, "%d contact slots exceed 16 (4 pyramid rows each, one row per lane of a 64-lane group)", ncon);
+  if (ncon > 16) return fail(AMX_ECAPACITY, "%d contact slots (connect / weld row groups included) exceed 16 (4 rows each, one row per lane of a 64-lane group)", ncon);
   {
     int first = -1, last = -1, cnt = 0;
-    for (int p = 0; p < np; p++) if (d->pair_fn[p] == 6) { if (first < 0) first = p; last = p; cnt++; }
+    for (int p = 0; p < npc; p++) if (d->pair_fn[p] == 6) { if (first < 0) first = p; last = p; cnt++; }
     if (cnt > 0 && last - first + 1 != cnt) return fail(AMX_EINVAL, "convex-convex pairs must be contiguous in the pair list (pairs are sorted by function)");
     if (cnt > 0) { m.cx_first = first; m.ncx = cnt; }
   }
@@ -344,7 +374,7 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
   // pair indices (pairs come grouped by function, so they do unless a larger hull sits among them)
   {
     int first = -1, last = -1, cnt = 0;
-    for (int p = 0; p < np; p++)
+    for (int p = 0; p < npc; p++)
       if (d->pair_fn[p] == 2 && d->pair_vertnum[p] <= 32) { if (first < 0) first = p; last = p; cnt++; }
     if (cnt > 0 && last - first + 1 == cnt) { m.pcx_first = first; m.npcx = cnt; }
     m.pcx_unit = 32;
@@ -387,12 +417,12 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
   }
   {
     int neq_active = 0;
-    for (int e = 0; e < d->neq; e++) if (d->eq_active[e]) neq_active++;
+    for (int e = 0; e < d->neq; e++) if (d->eq_active[e] && d->eq_type[e] == 2) neq_active++;  // slot A carries the joint equalities only
     for (int f = 0; f < m.nfri; f++) im.seti(m.c_dof + fri_i[f] * DOF_S + 11, neq_active + f);
     for (int l = 0; l < m.nlim; l++) im.seti(m.c_dof + d->jnt_dofadr[lim_j[l]] * DOF_S + 10, neq_active + m.nfri + l);
   }
   std::vector<int> eq_e;
-  for (int e = 0; e < d->neq; e++) if (d->eq_active[e]) eq_e.push_back(e);
+  for (int e = 0; e < d->neq; e++) if (d->eq_active[e] && d->eq_type[e] == 2) eq_e.push_back(e);  // connect / weld: pseudo-pairs above
   m.neq = (int)eq_e.size();
   m.c_eq = im.reserve(m.neq * EQ_S);
   for (int r = 0; r < m.neq; r++) {
@@ -401,7 +431,7 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
       return fail(AMX_EUNSUPPORTED, "equality %d must couple hinge/slide joints", e);
     im.seti(o, d->jnt_qposadr[j1]); im.seti(o + 1, d->jnt_dofadr[j1]);
     im.seti(o + 2, j2 >= 0 ? d->jnt_qposadr[j2] : -1); im.seti(o + 3, j2 >= 0 ? d->jnt_dofadr[j2] : -1);
-    for (int k = 0; k < 5; k++) im.setf(o + 4 + k, d->eq_data[5 * e + k]);
+    for (int k = 0; k < 5; k++) im.setf(o + 4 + k, d->eq_data[11 * e + k]);
     write_kbi(im, o + 9, d->eq_solref + 2 * e, d->eq_solimp + 5 * e, d->timestep, refsafe);
     im.setf(o + 18, d->dof_invweight0[d->jnt_dofadr[j1]] + (j2 >= 0 ? d->dof_invweight0[d->jnt_dofadr[j2]] : 0.0));
     im.setf(o + 19, d->qpos0[d->jnt_qposadr[j1]]); im.setf(o + 20, j2 >= 0 ? d->qpos0[d->jnt_qposadr[j2]] : 0.0);

@@ -839,30 +839,65 @@ class _Compiler:
         m.actuator_forcerange = np.array([a["forcerange"] for a in acts], dtype=float).reshape(-1, 2)
 
     def _compile_equality(self, m: MjModel):
+        """<equality>: joint (polycoef), connect and weld.  eq_data has MuJoCo's 11 columns; what they hold here:
+          joint   [0:5] polycoef
+          connect [0:3] anchor in body1's frame, [3:6] the same point in body2's frame at qpos0
+          weld    [0:3] the weld point in body2's frame (`anchor`), [3:6] the same point in body1's frame, [6:10] relpose quaternion
+                  (orientation of body2 in body1's frame), [10] torquescale
+        obj ids are joint ids for joint equalities and body ids for connect / weld (body2 omitted = the world)."""
+        xpos0, xquat0 = _kinematics_qpos0(m)
         eqs = []
         for sec in _merge_sections(self.root, "equality"):
             for e in sec:
-                if e.tag != "joint":
-                    raise NotImplementedError(f"equality <{e.tag}>")
                 at = self.defaults.attrs("equality", e.get("class"), e.attrib)
-                j1 = m.names_joint.index(at["joint1"])
-                j2 = m.names_joint.index(at["joint2"]) if "joint2" in at else -1
-                for j in (j1, j2):
-                    if j >= 0 and m.jnt_type[j] not in (JNT_HINGE, JNT_SLIDE):
-                        raise ValueError("joint equality needs scalar joints")
-                pc = np.array([0.0, 1.0, 0, 0, 0])
-                if "polycoef" in at:
-                    u = _floats(at["polycoef"])
-                    pc[: u.size] = u
-                eqs.append(dict(name=at.get("name", ""), j1=j1, j2=j2, data=pc, active=at.get("active", "true") == "true",
-                                solref=_floats(at.get("solref", "0.02 1"), 2), solimp=self._solimp(at.get("solimp"))))
+                common = dict(name=at.get("name", ""), active=at.get("active", "true") == "true",
+                              solref=_floats(at.get("solref", "0.02 1"), 2), solimp=self._solimp(at.get("solimp")))
+                data = np.zeros(11)
+                if e.tag == "joint":
+                    j1 = m.names_joint.index(at["joint1"])
+                    j2 = m.names_joint.index(at["joint2"]) if "joint2" in at else -1
+                    for j in (j1, j2):
+                        if j >= 0 and m.jnt_type[j] not in (JNT_HINGE, JNT_SLIDE):
+                            raise ValueError("joint equality needs scalar joints")
+                    data[:5] = [0.0, 1.0, 0, 0, 0]
+                    if "polycoef" in at:
+                        u = _floats(at["polycoef"])
+                        data[: u.size] = u
+                    eqs.append(dict(type=EQ_JOINT, o1=j1, o2=j2, data=data, **common))
+                elif e.tag in ("connect", "weld"):
+                    if "site1" in at or "site2" in at:
+                        raise NotImplementedError(f"equality <{e.tag}> between sites (give body1 / body2)")
+                    b1 = m.names_body.index(at["body1"])
+                    b2 = m.names_body.index(at["body2"]) if "body2" in at else 0
+                    inv = lambda b, p: _rot(_quat_conj(xquat0[b]), p - xpos0[b])  # world point -> body frame at qpos0
+                    if e.tag == "connect":
+                        a1 = _floats(at["anchor"], 3)
+                        data[0:3] = a1
+                        data[3:6] = inv(b2, xpos0[b1] + _rot(xquat0[b1], a1))
+                        eqs.append(dict(type=EQ_CONNECT, o1=b1, o2=b2, data=data, **common))
+                    else:
+                        a2 = _floats(at.get("anchor", "0 0 0"), 3)
+                        rel = _floats(at.get("relpose", "0 1 0 0 0 0 0"), 7)
+                        if np.all(rel[3:] == 0):  # MuJoCo: an all-zero quaternion means "the relative pose at qpos0"
+                            rq = _quat_mul(_quat_conj(xquat0[b1]), xquat0[b2])
+                            rp = inv(b1, xpos0[b2])
+                        else:
+                            rq = rel[3:] / np.linalg.norm(rel[3:])
+                            rp = rel[:3]
+                        data[0:3] = a2
+                        data[3:6] = rp + _rot(rq, a2)  # the weld point in body1's frame when the relative pose is relpose
+                        data[6:10] = rq
+                        data[10] = float(at.get("torquescale", 1.0))
+                        eqs.append(dict(type=EQ_WELD, o1=b1, o2=b2, data=data, **common))
+                else:
+                    raise NotImplementedError(f"equality <{e.tag}>")
         m.neq = len(eqs)
         m.names_eq = [q["name"] for q in eqs]
-        m.eq_type = np.full(m.neq, EQ_JOINT, dtype=np.int32)
-        m.eq_obj1id = np.array([q["j1"] for q in eqs], dtype=np.int32).reshape(-1)
-        m.eq_obj2id = np.array([q["j2"] for q in eqs], dtype=np.int32).reshape(-1)
+        m.eq_type = np.array([q["type"] for q in eqs], dtype=np.int32).reshape(-1)
+        m.eq_obj1id = np.array([q["o1"] for q in eqs], dtype=np.int32).reshape(-1)
+        m.eq_obj2id = np.array([q["o2"] for q in eqs], dtype=np.int32).reshape(-1)
         m.eq_active = np.array([int(q["active"]) for q in eqs], dtype=np.int32).reshape(-1)
-        m.eq_data = np.array([q["data"] for q in eqs], dtype=float).reshape(-1, 5)
+        m.eq_data = np.array([q["data"] for q in eqs], dtype=float).reshape(-1, 11)
         m.eq_solref = np.array([q["solref"] for q in eqs], dtype=float).reshape(-1, 2)
         m.eq_solimp = np.array([q["solimp"] for q in eqs], dtype=float).reshape(-1, 5)
 

@@ -81,12 +81,19 @@ typedef struct amx_model_desc {
   const int *actuator_trnid, *actuator_biastype /*0 none 1 affine*/, *actuator_ctrllimited, *actuator_forcelimited;
   const double *actuator_gear, *actuator_gainprm /*[nu,3]*/, *actuator_biasprm /*[nu,3]*/,
       *actuator_ctrlrange /*[nu,2]*/, *actuator_forcerange /*[nu,2]*/;
-  /* joint equalities [neq] */
+  /* equalities [neq]: joint (polycoef), connect, weld - see eq_type below */
   const int *eq_obj1id, *eq_obj2id, *eq_active;
-  const double *eq_data /*[neq,5] polycoef*/, *eq_solref /*[neq,2]*/, *eq_solimp /*[neq,5]*/;
+  const double *eq_data /*[neq,11]*/, *eq_solref /*[neq,2]*/, *eq_solimp /*[neq,5]*/;
   /* dry joint friction [nv] (version 3): a dof with dof_frictionloss > 0 carries one friction-loss constraint row (force
    * clamped to +-frictionloss: quadratic inside, linear outside), regularised by dof_solref / dof_solimp
    * (MJCF solreffriction / solimpfriction).  Reaches the reference through URDF <dynamics friction=...>. */
+  /* equality types (version 3): eq_type[e] = 0 connect, 1 weld, 2 joint (MuJoCo's mjtEq).  obj ids are joint ids for joint
+   * equalities and body ids for connect / weld (0 = the world).  eq_data columns:
+   *   joint   [0:5] polycoef
+   *   connect [0:3] anchor in body1's frame, [3:6] the same point in body2's frame at qpos0
+   *   weld    [0:3] the weld point in body2's frame, [3:6] the same point in body1's frame at the relative pose, [6:10] relpose
+   *           quaternion (orientation of body2 in body1's frame), [10] torquescale */
+  const int *eq_type /*[neq]*/;
   const double *dof_frictionloss /*[nv]*/, *dof_solref /*[nv,2]*/, *dof_solimp /*[nv,5]*/;
 } amx_model_desc;
 

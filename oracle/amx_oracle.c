@@ -81,7 +81,7 @@ typedef struct amxo_model {
   REAL *pair_friction, *pair_solref, *pair_solimp, *pair_margin, *convex_vert;
   int *actuator_trnid, *actuator_biastype, *actuator_ctrllimited, *actuator_forcelimited;
   REAL *actuator_gear, *actuator_gainprm, *actuator_biasprm, *actuator_ctrlrange, *actuator_forcerange;
-  int *eq_obj1id, *eq_obj2id, *eq_active;
+  int *eq_obj1id, *eq_obj2id, *eq_active, *eq_type;
   REAL *eq_data, *eq_solref, *eq_solimp;
   /* convex hulls of the convex-convex pairs */
   int *pair_hull1, *pair_hull2, *hull_vertadr, *hull_vertnum, *hull_faceadr, *hull_facenum, *hull_edgeadr, *hull_edgenum;
@@ -150,7 +150,8 @@ amxo_model *amxo_model_create(const amx_model_desc *d) {
   m->actuator_forcerange = dup_r(d->actuator_forcerange, nu * 2);
   m->eq_obj1id = dup_i(d->eq_obj1id, ne); m->eq_obj2id = dup_i(d->eq_obj2id, ne);
   m->eq_active = dup_i(d->eq_active, ne);
-  m->eq_data = dup_r(d->eq_data, ne * 5); m->eq_solref = dup_r(d->eq_solref, ne * 2);
+  m->eq_type = dup_i(d->eq_type, ne);
+  m->eq_data = dup_r(d->eq_data, ne * 11); m->eq_solref = dup_r(d->eq_solref, ne * 2);
   m->eq_solimp = dup_r(d->eq_solimp, ne * 5);
   {
     size_t nh = d->nhull, nf = d->nhullface;
@@ -167,9 +168,10 @@ amxo_model *amxo_model_create(const amx_model_desc *d) {
   for (size_t p = 0; p < np; p++) { m->pair_conadr[p] = m->ncon; m->ncon += PAIR_NCON[m->pair_fn[p]]; }
   int nlim = 0;
   for (size_t j = 0; j < nj; j++) nlim += (m->jnt_limited[j] && (m->jnt_type[j] == JSLIDE || m->jnt_type[j] == JHINGE));
-  int nfri = 0;
+  int nfri = 0, neqrows = 0;
   for (size_t i = 0; i < nv; i++) nfri += m->dof_frictionloss[i] > 0;
-  m->nefc_max = m->neq + nfri + nlim + 4 * m->ncon;
+  for (int e = 0; e < m->neq; e++) neqrows += m->eq_type[e] == 0 ? 3 : (m->eq_type[e] == 1 ? 6 : 1);
+  m->nefc_max = neqrows + nfri + nlim + 4 * m->ncon;
   return m;
 }
 
@@ -192,7 +194,7 @@ void amxo_model_destroy(amxo_model *m) {
     (void **)&m->actuator_biastype, (void **)&m->actuator_ctrllimited, (void **)&m->actuator_forcelimited,
     (void **)&m->actuator_gear, (void **)&m->actuator_gainprm, (void **)&m->actuator_biasprm, (void **)&m->actuator_ctrlrange,
     (void **)&m->actuator_forcerange, (void **)&m->eq_obj1id, (void **)&m->eq_obj2id, (void **)&m->eq_active,
-    (void **)&m->eq_data, (void **)&m->eq_solref, (void **)&m->eq_solimp};
+    (void **)&m->eq_data, (void **)&m->eq_solref, (void **)&m->eq_solimp, (void **)&m->eq_type};
   for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); i++) free(*ptrs[i]);
   free(m);
 }
@@ -901,6 +903,24 @@ static void finish_row(const amxo_model *m, amxo_data *d, int row, REAL pos, REA
   d->efc_pos[row] = pos;
   d->efc_floss[row] = 0;
 }
+/* a row whose impedance is evaluated at `pos_imp` (the norm of a multi-row residual) instead of its own position */
+static void finish_row_imp(const amxo_model *m, amxo_data *d, int row, REAL pos, REAL pos_imp, REAL invweight, const REAL *solref, const REAL *solimp) {
+  REAL k, b, imp, jv = 0;
+  kbi(m, solref, solimp, pos_imp, &k, &b, &imp);
+  for (int i = 0; i < m->nv; i++) jv += d->efc_J[row * m->nv + i] * d->qvel[i];
+  REAL r = r_max(invweight * (1 - imp) / imp, MINVAL);
+  d->efc_D[row] = 1 / r;
+  d->efc_aref[row] = -b * jv - k * imp * pos;
+  d->efc_pos[row] = pos;
+  d->efc_floss[row] = 0;
+}
+/* rotational Jacobian of body b (angular parts of the motion axes along its chain) into jac[3*nv] [mjx:support.jac] */
+static void jac_rot(const amxo_model *m, const amxo_data *d, REAL *jac, int b, REAL sign) {
+  while (b > 0 && m->body_dofnum[b] == 0) b = m->body_parentid[b];
+  if (b == 0) return;
+  for (int i = m->body_dofadr[b] + m->body_dofnum[b] - 1; i >= 0; i = m->dof_parentid[i])
+    for (int k = 0; k < 3; k++) jac[k * m->nv + i] += sign * d->cdof[6 * i + k];
+}
 /* translational Jacobian of a world point fixed to body b, into jac[3*nv] (row-major 3 x nv) [mjx:support.jac] */
 static void jac_point(const amxo_model *m, const amxo_data *d, REAL *jac, const REAL *point, int b, REAL sign) {
   if (b == 0) return;
@@ -919,10 +939,56 @@ static void make_constraint(const amxo_model *m, amxo_data *d) {
   d->ne = 0;
   if (m->disableflags & DIS_CONSTRAINT) { d->nefc = 0; return; }
   if (!(m->disableflags & DIS_EQUALITY)) {
+    /* connect and weld [mjx:constraint._instantiate_equality_connect / _weld; MuJoCo mj_instantiateEquality]: the difference of two
+     * body-fixed points (and, for a weld, of the orientations) held at zero.  All rows of one equality share the impedance of the
+     * norm of its residual; translational rows are regularised by the bodies' translational invweight0, rotational ones by the
+     * rotational. */
+    for (int e = 0; e < m->neq; e++) {
+      if (!m->eq_active[e] || m->eq_type[e] > 1) continue;
+      const int weld = m->eq_type[e] == 1, b1 = m->eq_obj1id[e], b2 = m->eq_obj2id[e], nr = weld ? 6 : 3;
+      const REAL *dat = m->eq_data + 11 * e;
+      /* connect: anchor in body1 = dat[0:3], in body2 = dat[3:6]; weld: weld point in body2 = dat[0:3], in body1 = dat[3:6] */
+      const REAL *a1 = weld ? dat + 3 : dat, *a2 = weld ? dat : dat + 3;
+      REAL p1[3], p2[3], pos[6], t[3];
+      mat_mul_vec3(t, d->xmat + 9 * b1, a1); for (int k = 0; k < 3; k++) p1[k] = d->xpos[3 * b1 + k] + t[k];
+      mat_mul_vec3(t, d->xmat + 9 * b2, a2); for (int k = 0; k < 3; k++) p2[k] = d->xpos[3 * b2 + k] + t[k];
+      for (int k = 0; k < 3; k++) pos[k] = p1[k] - p2[k];
+      REAL *J0 = d->efc_J + row * nv;
+      memset(J0, 0, sizeof(REAL) * nr * nv);
+      jac_point(m, d, J0, p1, b1, (REAL)1);
+      jac_point(m, d, J0, p2, b2, (REAL)-1);
+      if (weld) {
+        /* orientation residual: vector part of conj(q2) * q1 * relpose, times torquescale; its Jacobian is
+         * 0.5 * vec(conj(q2) * (0, jacr1 - jacr2) * q1 * relpose), times torquescale */
+        const REAL ts = dat[10];
+        REAL q1r[4], q2c[4], qe[4];
+        quat_mul(q1r, d->xquat + 4 * b1, dat + 6);
+        q2c[0] = d->xquat[4 * b2]; q2c[1] = -d->xquat[4 * b2 + 1]; q2c[2] = -d->xquat[4 * b2 + 2]; q2c[3] = -d->xquat[4 * b2 + 3];
+        quat_mul(qe, q2c, q1r);
+        for (int k = 0; k < 3; k++) pos[3 + k] = qe[1 + k] * ts;
+        REAL *Jr = J0 + 3 * nv;
+        jac_rot(m, d, Jr, b1, (REAL)1);
+        jac_rot(m, d, Jr, b2, (REAL)-1);
+        for (int i = 0; i < nv; i++) {
+          REAL w[4] = {0, Jr[i], Jr[nv + i], Jr[2 * nv + i]}, u[4], v[4];
+          if (w[1] == 0 && w[2] == 0 && w[3] == 0) continue;
+          quat_mul(u, q2c, w); quat_mul(v, u, q1r);
+          for (int k = 0; k < 3; k++) Jr[k * nv + i] = (REAL)0.5 * v[1 + k] * ts;
+        }
+      }
+      REAL nrm = 0;
+      for (int k = 0; k < nr; k++) nrm += pos[k] * pos[k];
+      nrm = r_sqrt(nrm);
+      for (int k = 0; k < nr; k++) {
+        const REAL invw = m->body_invweight0[2 * b1 + (k >= 3)] + m->body_invweight0[2 * b2 + (k >= 3)];
+        finish_row_imp(m, d, row, pos[k], nrm, invw, m->eq_solref + 2 * e, m->eq_solimp + 5 * e);
+        row++;
+      }
+    }
     for (int e = 0; e < m->neq; e++) { /* joint polycoef equality */
-      if (!m->eq_active[e]) continue;
+      if (!m->eq_active[e] || m->eq_type[e] != 2) continue;
       int j1 = m->eq_obj1id[e], j2 = m->eq_obj2id[e];
-      const REAL *c = m->eq_data + 5 * e;
+      const REAL *c = m->eq_data + 11 * e;
       REAL *J = d->efc_J + row * nv;
       memset(J, 0, sizeof(REAL) * nv);
       REAL pos1 = d->qpos[m->jnt_qposadr[j1]] - m->qpos0[m->jnt_qposadr[j1]], pos, invw = m->dof_invweight0[m->jnt_dofadr[j1]];

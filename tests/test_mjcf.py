@@ -94,7 +94,6 @@ def test_compiler_features():
 @pytest.mark.parametrize("snippet,exc", [
     ('<option cone="elliptic"/>', NotImplementedError),
     ('<option integrator="RK4"/>', None),  # compiles on the host; rejected when put on the device
-    ('<equality><weld body1="a" body2="b"/></equality>', NotImplementedError),
 ])
 def test_unsupported_features_raise(snippet, exc):
     """Unsupported physics raises NotImplementedError, the type mjx.device_put raises (reference io_utils.py:228-241)."""
