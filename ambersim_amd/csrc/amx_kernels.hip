@@ -188,8 +188,59 @@ DEV void make_frame(f3 n, float *fr) {  // rows a, b, a x b
   fr[0] = a.x; fr[1] = a.y; fr[2] = a.z; fr[3] = b.x; fr[4] = b.y; fr[5] = b.z; fr[6] = c.x; fr[7] = c.y; fr[8] = c.z;
 }
 
+// ---- packed fp32 (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32: two operations per instruction at the scalar instructions'
+// issue cost).  Operands are aligned register pairs; values that arrive in pairs anyway (ds_read2_b32, ds_read_b64/b128) cost
+// nothing to pack.  The auto-vectoriser is off for these kernels (it packs everything it can and pays more in v_mov than it
+// saves: 7.6 k -> 8.2 k vector instructions, measured), so the packed forms are written out where the data layout suits them.
+typedef float f2v __attribute__((ext_vector_type(2)));
+#ifndef AMX_PK_DOT
+#define AMX_PK_DOT 1  // 0: scalar multiply-adds in the dot products (A/B switch)
+#endif
+#ifndef AMX_PK_SV
+#define AMX_PK_SV 1  // 0: scalar spatial-vector sums (A/B switch)
+#endif
+DEV f2v pk_fma(f2v a, f2v b, f2v c) { return __builtin_elementwise_fma(a, b, c); }
+
 // ---- spatial algebra on [rot(3); lin(3)] vectors and 10-float com-frame inertias
 struct sv { float v[6]; };
+DEV void sv_acc(sv &a, const sv &b) {  // a += b
+#if AMX_PK_SV
+#pragma unroll
+  for (int e = 0; e < 6; e += 2) { const f2v r = f2v{a.v[e], a.v[e + 1]} + f2v{b.v[e], b.v[e + 1]}; a.v[e] = r.x; a.v[e + 1] = r.y; }
+#else
+#pragma unroll
+  for (int e = 0; e < 6; ++e) a.v[e] += b.v[e];
+#endif
+}
+DEV float sv_dot(const sv &a, const sv &b) {
+#if AMX_PK_SV
+  f2v p = f2v{a.v[0], a.v[1]} * f2v{b.v[0], b.v[1]};
+  p = pk_fma(f2v{a.v[2], a.v[3]}, f2v{b.v[2], b.v[3]}, p);
+  p = pk_fma(f2v{a.v[4], a.v[5]}, f2v{b.v[4], b.v[5]}, p);
+  return p.x + p.y;
+#else
+  return (a.v[0] * b.v[0] + a.v[1] * b.v[1]) + (a.v[2] * b.v[2] + a.v[3] * b.v[3]) + (a.v[4] * b.v[4] + a.v[5] * b.v[5]);
+#endif
+}
+template <int N> DEV void pk_acc(float (&r)[N], const float (&x)[N]) {  // r += x, N even
+#if AMX_PK_SV
+#pragma unroll
+  for (int e = 0; e + 1 < N; e += 2) { const f2v t = f2v{r[e], r[e + 1]} + f2v{x[e], x[e + 1]}; r[e] = t.x; r[e + 1] = t.y; }
+  if (N & 1) r[N - 1] += x[N - 1];
+#else
+#pragma unroll
+  for (int e = 0; e < N; ++e) r[e] += x[e];
+#endif
+}
+DEV void sv_axpy(sv &a, const sv &c, float q) {  // a += c * q
+#if AMX_PK_SV
+#pragma unroll
+  for (int e = 0; e < 6; e += 2) { const f2v r = pk_fma(f2v{c.v[e], c.v[e + 1]}, f2v{q, q}, f2v{a.v[e], a.v[e + 1]}); a.v[e] = r.x; a.v[e + 1] = r.y; }
+#else
+#pragma unroll
+  for (int e = 0; e < 6; ++e) a.v[e] += c.v[e] * q;
+#endif
+}
 DEV sv inert_mul(const float *i, const sv &v) {
   sv r;
   r.v[0] = i[0] * v.v[0] + i[3] * v.v[1] + i[4] * v.v[2] - i[8] * v.v[4] + i[7] * v.v[5];
@@ -726,6 +777,9 @@ template <class S, int G, int K> struct SymRest {  // dense order: every column 
 #ifndef AMX_PIVOT_VCMP
 #define AMX_PIVOT_VCMP 0  // 1: the pivot-lane test as v_cmp per pivot (r02), A/B switch
 #endif
+#ifndef AMX_PIVOT_CLAMP
+#define AMX_PIVOT_CLAMP 0  // 1: every pivot clamped to MINVAL before its reciprocal (r02/r03a: one v_max_f32_dpp per pivot), A/B switch
+#endif
 #ifndef AMX_PIVOT_ASM_MAX
 #define AMX_PIVOT_ASM_MAX 1  // 0: the pivot broadcast as builtins (the compiler does not fold the DPP move into v_max here: +1 VALU per pivot, measured)
 #endif
@@ -749,7 +803,14 @@ template <class S, int G, int J, bool TREE, bool BCOL> DEV void sym_pivot(float 
   const float c = a[J];
   const RowPair p = row_pair<G>(c);
   float piv;
-#if AMX_PIVOT_ASM_MAX
+#if !AMX_PIVOT_CLAMP
+  // 1 / (lane J of p) in one instruction (v_rcp_f32 takes the DPP modifier itself); the leading s_nop 1 is the 2 wait states
+  // after the swap / the last writer.  The pivots of a positive definite matrix need no clamp (the reference's Cholesky has
+  // none either); the solution's final division clamps the stored diagonal once per elimination instead of once per pivot.
+  float rinv;
+  asm("s_nop 1\n\tv_rcp_f32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(rinv) : "v"(J < 16 ? p.r0 : p.r1), "n"(J & 15));
+  piv = c;  // on the pivot lane, the only one whose `diag` takes it
+#elif AMX_PIVOT_ASM_MAX
   // max(lane J of p, MINVAL) in one instruction; the leading s_nop 1 is the 2 wait states after the swap / the last writer
   asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(piv) : "v"(J < 16 ? p.r0 : p.r1), "v"(MINVAL), "n"(J & 15));
 #else
@@ -758,7 +819,11 @@ template <class S, int G, int J, bool TREE, bool BCOL> DEV void sym_pivot(float 
   // nf and reads a register written by the same swap, so their two wait states hold by construction as before.
   piv = fmaxf(bcast_row<J>(p), MINVAL);
 #endif
+#if !AMX_PIVOT_CLAMP
+  float nf = -c * rinv;
+#else
   float nf = -c * __builtin_amdgcn_rcpf(piv);
+#endif
 #if AMX_PIVOT_VCMP
   nf = gl == J ? 0.0f : nf;  // the pivot row itself is left alone
   diag = gl == J ? piv : diag;  // ... and its diagonal is final: kept for the last division (same test, no pass over the row at the end)
@@ -869,7 +934,7 @@ AMX_STATIC_SOLVE_ATTR void spd_solve_static(int A_off, int rhs_off, int x_off, i
     float d = 1.0f;
     if (BCOL && bt_off >= 0) sym_eliminate<S, G, TREE, true>(a, gle, d);
     else sym_eliminate<S, G, TREE, false>(a, gle, d);
-    if (gl < N) lds[x_off + gl * DOF_E] = fdiv(a[N], d);
+    if (gl < N) lds[x_off + gl * DOF_E] = fdiv(a[N], AMX_PIVOT_CLAMP ? d : fmaxf(d, MINVAL));
     WSYNC();
     return;
   }
@@ -911,8 +976,8 @@ AMX_STATIC_SOLVE_ATTR void spd_solve_static(int A_off, int rhs_off, int x_off, i
 // again the elimination (two thirds of this routine) is skipped and the routine returns true; the caller stops iterating.
 template <class S, int N, int G, bool TREE, bool GRADCOL = false>
 AMX_STATIC_SOLVE_ATTR bool newton_solve_fused(int M_off, int ld_, int n_, unsigned long long crows_, int row_base, int J_base, int ldc_, int slot_base_,
-                                                int rhs_off, int x_off, float dlim, int gl, int gb4, int rot, int bt_off, float flim = 0.0f, int ma_off = 0,
-                                                int fs_off = 0, int fcon_off = 0, bool store_ok = true, bool early_out = false, bool imp_done = false,
+                                                int rhs_off, int x_off, float dlim, int gl, int gb4, int rot, int bt_off, float flim = 0.0f, float ma_v = 0.0f,
+                                                float fs_v = 0.0f, int fcon_off = 0, bool store_ok = true, bool early_out = false, bool imp_done = false,
                                                 float scale = 1.0f, float tol = 0.0f, ProfCtx *pc = nullptr, bool *group_done = nullptr) {
   if constexpr (sym_elim_ok<S, G>() && G == 32) {
     // crossbar-free elimination (see sym_pivot): b reaches lane N as a row through the staging vector at bt_off
@@ -934,7 +999,7 @@ AMX_STATIC_SOLVE_ATTR bool newton_solve_fused(int M_off, int ld_, int n_, unsign
     float b;
     if constexpr (GRADCOL) {
       static_assert(NS <= 31, "column 31 must be spare");
-      const float ma = lds[ma_off + li * DOF_E], fs = lds[fs_off + li * DOF_E];
+      const float ma = ma_v, fs = fs_v;  // M*qacc and qfrc_smooth of the lane's dof, from the caller's registers
       PROF_CTX(pc, 24);
       jtdj_rows_mfma<G, true>(crows_u, row_base, J_base, S::ldc, S::c_slot, gl, lo, hi);
       PROF_CTX(pc, 25);
@@ -982,7 +1047,7 @@ AMX_STATIC_SOLVE_ATTR bool newton_solve_fused(int M_off, int ld_, int n_, unsign
     PROF_CTX(pc, 26);
     sym_eliminate<S, G, TREE, true>(a, gle, d);
     PROF_CTX(pc, 27);
-    if (owner) lds[x_off + gl * DOF_E] = fdiv(a[NS], d);
+    if (owner) lds[x_off + gl * DOF_E] = fdiv(a[NS], AMX_PIVOT_CLAMP ? d : fmaxf(d, MINVAL));
     WSYNC();
     return false;
   }
@@ -1456,6 +1521,9 @@ struct Env {
   int vch_base, vch_dof;
   float rJ1, rJ2;      // equality / limit row `gl`: Jacobian entries on dofs rd1, rd2
   int rd1, rd2;
+  // this lane's dof: M*qacc of the current iterate, qfrc_smooth and qacc_smooth, mirrored in registers (0 on lanes without a dof).  The
+  // LDS fields stay current - other routines and the outputs read them - but the solver's own per-dof arithmetic no longer waits for them.
+  float r_ma, r_fs, r_as;
   bool aact, cact;  // the slot's row is active at the current iterate (set by constraint_force_and_grad)
   bool cEq;         // the lane's slot B row belongs to a connect / weld equality (a pseudo-pair, [npc, npair)): active on both sides
   PROF_DECL
@@ -1478,6 +1546,7 @@ struct Env {
       m_diag = moff(i, i);
     }
     aD = aAref = aJaref = aJv = cD = cAref = cJaref = cJv = rJ1 = rJ2 = aFl = 0.0f;
+    r_ma = r_fs = r_as = 0.0f;
     aact = cact = false;
     rd1 = 0; rd2 = -1;
     if (lane < m.neq()) { const int er = m.c_eq() + lane * EQ_S; rd1 = CI(er + 1); rd2 = CI(er + 3); }
@@ -1759,8 +1828,10 @@ struct Env {
 #pragma unroll 4
       for (int k = 0; k < m.sub_iter(); ++k) {
         const int d_ = b + k, src = (inner && d_ < b_subend) ? d_ : ((isb && k == 0) ? b : 0);  // a root reads just itself
+        float x[10];
 #pragma unroll
-        for (int q = 0; q < 10; ++q) r[q] += body(F_CINERT + q, src);
+        for (int q = 0; q < 10; ++q) x[q] = body(F_CINERT + q, src);
+        pk_acc<10>(r, x);
       }
       // a root's composite = itself + the composites of its children = a group sum over the lanes of the root and of the
       // bodies right below it (registers and DPP only; the child-list loop it replaces waited on LDS for every child)
@@ -1823,7 +1894,7 @@ struct Env {
         const int i = (pk >> 22) & 31, j = pk >> 27;
         const sv f = ld_dsv(D_FCRB, i), c = ld_dsv(D_CDOF, j);
         const float arm = CF(m.c_dof() + i * DOF_S + 4);
-        float v = (c.v[0] * f.v[0] + c.v[1] * f.v[1]) + (c.v[2] * f.v[2] + c.v[3] * f.v[3]) + (c.v[4] * f.v[4] + c.v[5] * f.v[5]);
+        float v = sv_dot(c, f);
         v += i == j ? arm : 0.0f;  // a select: as `if`, the armature load sank into a branch of its own with its own wait
         return MEnt{Mo + (int)(pk & 2047u), Mo + (int)((pk >> 11) & 2047u), v};  // j is an ancestor of i: both triangles are stored
       },
@@ -1851,6 +1922,8 @@ struct Env {
     // with P_k alone; the motion cross product is bilinear).  vJ, w, loc need no other body and stay in registers; the
     // level scan is then twelve loads, one cross product and twelve stores.
     sv vJ = {{0, 0, 0, 0, 0, 0}}, w = {{0, 0, 0, 0, 0, 0}}, loc = {{0, 0, 0, 0, 0, 0}};
+    sv cv_own = {{0, 0, 0, 0, 0, 0}}, ca_own = {{0, 0, 0, 0, 0, 0}};
+    bool own_in_regs = false;
     if (b > 0 && b < m.nb()) {
       for (int k = 0; k < b_jntnum; ++k) {
         const int jr = m.c_jnt() + (b_jntadr + k) * JNT_S, t_ = CI(jr), da = CI(jr + 2);
@@ -1860,7 +1933,7 @@ struct Env {
             const sv c = ld_dsv(D_CDOF, da + i);
             const float q = lds[qv + da + i];
 #pragma unroll
-            for (int e = 0; e < 6; ++e) vJ.v[e] += c.v[e] * q;
+            for (int e = 0; e < 1; ++e) sv_axpy(vJ, c, q);
           }
           const sv c3 = ld_dsv(D_CDOF, da + 3), c4 = ld_dsv(D_CDOF, da + 4), c5 = ld_dsv(D_CDOF, da + 5);
           const sv cd3 = motion_cross(vJ, c3), cd4 = motion_cross(vJ, c4), cd5 = motion_cross(vJ, c5);
@@ -1880,10 +1953,10 @@ struct Env {
             const sv cd = motion_cross(vJ, c);
             const float q = lds[qv + da + i];
 #pragma unroll
-            for (int e = 0; e < 6; ++e) { loc.v[e] += cd.v[e] * q; add.v[e] += c.v[e] * q; }
+            for (int e = 0; e < 1; ++e) { sv_axpy(loc, cd, q); sv_axpy(add, c, q); }
           }
 #pragma unroll
-          for (int e = 0; e < 6; ++e) { vJ.v[e] += add.v[e]; w.v[e] += add.v[e]; }
+          for (int e = 0; e < 1; ++e) { sv_acc(vJ, add); sv_acc(w, add); }
         }
       }
     }
@@ -1905,14 +1978,16 @@ struct Env {
         const sv va = ld_bsv(F_CVEL, a), la = ld_bsv(F_CACC, a);
         const sv x = motion_cross(cv, va);
 #pragma unroll
-        for (int e = 0; e < 6; ++e) { ca.v[e] = ca.v[e] + x.v[e] + la.v[e]; cv.v[e] = cv.v[e] + va.v[e]; }
+        for (int e = 0; e < 1; ++e) { sv_acc(ca, x); sv_acc(ca, la); sv_acc(cv, va); }
       }
       const sv x = motion_cross(cv, w);
 #pragma unroll
-      for (int e = 0; e < 6; ++e) { ca.v[e] = ca.v[e] + x.v[e] + loc.v[e]; cv.v[e] = cv.v[e] + vJ.v[e]; }
-      WSYNC();
-      if (isb) { st_bsv(F_CVEL, b, cv); st_bsv(F_CACC, b, ca); }
-      WSYNC();
+      for (int e = 0; e < 1; ++e) { sv_acc(ca, x); sv_acc(ca, loc); sv_acc(cv, vJ); }
+      // the body's own velocity and acceleration are complete in this lane and nobody else reads them (the level scan below hands
+      // them from parent to child through LDS; here every body recomputed its ancestors'): the local force is formed straight from
+      // the registers - twelve stores, twelve loads and a round trip less
+      // (the local force goes to F_CFRC, which overlays the body's own inertia and not the joint sums other lanes still read)
+      cv_own = cv; ca_own = ca; own_in_regs = true;
     } else
     for (int L = 1; L < m.nlevel(); ++L) {
       if (b_level == L) {
@@ -1928,14 +2003,14 @@ struct Env {
     }
     PROF(23);
     if (b > 0 && b < m.nb()) {  // local force of every body in parallel: I cacc + cvel x* (I cvel)
-      const sv cv = ld_bsv(F_CVEL, b), ca = ld_bsv(F_CACC, b);
+      const sv cv = own_in_regs ? cv_own : ld_bsv(F_CVEL, b), ca = own_in_regs ? ca_own : ld_bsv(F_CACC, b);
       float I[10];
 #pragma unroll
       for (int k = 0; k < 10; ++k) I[k] = body(F_CINERT + k, b);
       sv f = inert_mul(I, ca);
       const sv g = motion_cross_force(cv, inert_mul(I, cv));
 #pragma unroll
-      for (int e = 0; e < 6; ++e) f.v[e] += g.v[e];
+      for (int e = 0; e < 1; ++e) sv_acc(f, g);
       st_bsv(F_CFRC, b, f);
     }
     WSYNC();
@@ -1949,7 +2024,7 @@ struct Env {
         const int d_ = b + k;
         const sv g = ld_bsv(F_CFRC, (inner && d_ < b_subend) ? d_ : ((isb && k == 0) ? b : 0));
 #pragma unroll
-        for (int e = 0; e < 6; ++e) f.v[e] += g.v[e];
+        for (int e = 0; e < 1; ++e) sv_acc(f, g);
       }
       for (int rt = 0; rt < m.nroot(); ++rt) {  // roots: group sum over themselves and the bodies right below them
         const bool part = isb && b_root == rt && b_level <= 2;
@@ -1978,7 +2053,7 @@ struct Env {
         for (int c = 0; c < b_childnum; ++c) {
           const sv g = ld_bsv(F_CFRC, CI(m.c_child() + b_childadr + c));
 #pragma unroll
-          for (int e = 0; e < 6; ++e) f.v[e] += g.v[e];
+          for (int e = 0; e < 1; ++e) sv_acc(f, g);
         }
         st_bsv(F_CFRC, b, f);
       }
@@ -2010,9 +2085,7 @@ struct Env {
     if (gl < m.nv()) {
       const int i = gl, dr = m.c_dof() + i * DOF_S;
       const sv c = ld_dsv(D_CDOF, i), f = ld_bsv(F_CFRC, d_body);
-      float bias = 0;
-#pragma unroll
-      for (int e = 0; e < 6; ++e) bias += c.v[e] * f.v[e];
+      const float bias = sv_dot(c, f);
       float pas = 0;
       if (!(m.disableflags() & DIS_PASSIVE)) {
         const int jr = m.c_jnt() + d_jnt * JNT_S;
@@ -2031,6 +2104,7 @@ struct Env {
       }
       dof(D_FBIAS, i) = bias;
       dof(D_FSMOOTH, i) = pas - bias + act;
+      r_fs = pas - bias + act;
     }
     WSYNC();
   }
@@ -2386,6 +2460,20 @@ struct Env {
     float acc0 = 0, acc1 = 0;
     const int nch = ldm >> 2;
     if constexpr (S::is_static) {  // static chunk count: one straight block, every load in flight
+#if AMX_PK_DOT
+      // packed fp32 (v_pk_fma_f32: two multiply-adds per instruction): a 16-byte load lands in two aligned register pairs, which
+      // is the operand form the packed instructions take - two per chunk instead of four scalar ones
+      f2v acc = {0.0f, 0.0f};
+#pragma unroll
+      for (int c = 0; c < S::ldm / 4; ++c) {
+        int pc = c + m_rot;
+        pc -= pc >= S::ldm / 4 ? S::ldm / 4 : 0;
+        const float4 a = mr[pc], v = vv[c];
+        acc = pk_fma(f2v{a.x, a.y}, f2v{v.x, v.y}, acc);
+        acc = pk_fma(f2v{a.z, a.w}, f2v{v.z, v.w}, acc);
+      }
+      return acc.x + acc.y;
+#else
 #pragma unroll
       for (int c = 0; c < S::ldm / 4; ++c) {
         int pc = c + m_rot;
@@ -2395,6 +2483,7 @@ struct Env {
         acc1 = __builtin_fmaf(a.z, v.z, __builtin_fmaf(a.w, v.w, acc1));
       }
       return acc0 + acc1;
+#endif
     }
 #pragma unroll 5
     for (int c = 0; c < nch; ++c) {
@@ -2435,6 +2524,16 @@ struct Env {
   // slots is loaded (slots past the list hold stale - finite - floats of the slab and meet a staged zero), so all the loads are in
   // flight together and each term is one fused multiply-add.  Two partial sums.
   DEV float chain_dot(int Jr) const {
+#if AMX_PK_DOT
+    if constexpr (S::is_static) {  // pairs of terms as packed multiply-adds (the loads are ds_read2_b32 pairs already)
+      f2v acc = {0.0f, 0.0f};
+#pragma unroll
+      for (int t = 0; t + 1 < S::ldc; t += 2) acc = pk_fma(f2v{lds[Jr + t], lds[Jr + t + 1]}, f2v{lds[vch_base + t], lds[vch_base + t + 1]}, acc);
+      float r = acc.x + acc.y;
+      if (S::ldc & 1) r = __builtin_fmaf(lds[Jr + S::ldc - 1], lds[vch_base + S::ldc - 1], r);
+      return r;
+    }
+#endif
     float a0 = 0, a1 = 0;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
@@ -2454,6 +2553,7 @@ struct Env {
   DEV void init_context(int vf) {
     const float ma = mul_M_row(vf);
     if (gl < m.nv()) dof(D_MA, gl) = ma;
+    r_ma = gl < m.nv() ? ma : 0.0f;
     aJaref = row_dot_A(vf) - aAref;
     cJaref = row_dot_B(vf) - cAref;
     WSYNC();
@@ -2469,7 +2569,7 @@ struct Env {
     }
     float c = ca_ + (actB ? 0.5f * cD * cJaref * cJaref : 0.0f);
     const int li = gl < m.nv() ? gl : 0;  // unconditional loads, then a select (a lazily evaluated ?: is a branch with its own wait)
-    const float gv = (dof(D_MA, li) - dof(D_FSMOOTH, li)) * (dof(vf, li) - dof(D_ASMOOTH, li));
+    const float gv = (r_ma - r_fs) * (dof(vf, li) - r_as);
     float g = gl < m.nv() ? gv : 0.0f;
     const float r = gsum_pack2<G>(c, g);  // both sums in one packed reduction
     c = quad_value<0>(r);
@@ -2549,6 +2649,11 @@ struct Env {
         acc += dof_rows_fetch(rJ1 * f);
       }
       if (isd && alive) dof(D_FCON, gl) = acc;
+      if (m.neq() == 0) {  // no scattered rows: the gradient is complete in this lane's registers
+        if (isd && alive) dof(D_GRAD, gl) = r_ma - r_fs - acc;
+        WSYNC();
+        return;
+      }
     }
     WSYNC();
     // equality / limit rows scatter their one or two entries
@@ -2557,7 +2662,7 @@ struct Env {
       if (rd2 >= 0) atomicAdd(&dof(D_FCON, rd2), rJ2 * f);
     }
     WSYNC();
-    if (gl < m.nv() && alive) dof(D_GRAD, gl) = dof(D_MA, gl) - dof(D_FSMOOTH, gl) - dof(D_FCON, gl);
+    if (gl < m.nv() && alive) dof(D_GRAD, gl) = r_ma - r_fs - dof(D_FCON, gl);
     WSYNC();
   }
   // Mgrad = (M + J' D_active J)^-1 grad, H a full symmetric matrix in LDS.
@@ -2585,7 +2690,7 @@ struct Env {
 #endif
         if constexpr (grad_in_solve())
           stop = newton_solve_fused<S, S::nv, G, S::tree_H, true>(Mo, ldm, nv, rows, eb + m.e_row() + row0 * ROW_E, Jo, ldc, m.c_slot(), dofoff(D_GRAD), dofoff(D_MGRAD), dlim, gl, gb4, m_rot,
-                                                                 eb + m.e_H(), pend_flim, dofoff(D_MA), dofoff(D_FSMOOTH), dofoff(D_FCON), alive, early_out, imp_done, m.scale(),
+                                                                 eb + m.e_H(), pend_flim, r_ma, r_fs, dofoff(D_FCON), alive, early_out, imp_done, m.scale(),
                                                                  m.tolerance(), pc, group_done);
         else if constexpr (S::is_static)
           newton_solve_fused<S, S::nv, G, S::tree_H>(Mo, ldm, nv, rows, eb + m.e_row() + row0 * ROW_E, Jo, ldc, m.c_slot(), dofoff(D_GRAD), dofoff(D_MGRAD), dlim, gl, gb4, m_rot, eb + m.e_H());
@@ -2685,7 +2790,7 @@ struct Env {
     float sn = 0, g1 = 0, g2 = 0;
     {  // unconditional loads, selects at the end
       const int li = gl < nv ? gl : 0;
-      const float si = dof(D_SEARCH, li), ma_ = dof(D_MA, li), fs_ = dof(D_FSMOOTH, li);
+      const float si = dof(D_SEARCH, li), ma_ = r_ma, fs_ = r_fs;
       const float sn_ = si * si, g1_ = si * ma_ - si * fs_, g2_ = 0.5f * si * mv;
       sn = gl < nv ? sn_ : 0.0f; g1 = gl < nv ? g1_ : 0.0f; g2 = gl < nv ? g2_ : 0.0f;
     }
@@ -2770,7 +2875,7 @@ struct Env {
     const bool improved = alive & ((lo_cost < p0_cost) | (hi_cost < p0_cost));
     const float alpha = lo_cost < hi_cost ? lo.alpha : hi.alpha;
     if (improved) {
-      if (gl < nv) { dof(D_QACC, gl) += alpha * dof(D_SEARCH, gl); dof(D_MA, gl) += alpha * mv; }
+      if (gl < nv) { r_ma += alpha * mv; dof(D_QACC, gl) += alpha * dof(D_SEARCH, gl); dof(D_MA, gl) = r_ma; }
       aJaref += alpha * aJv;
       cJaref += alpha * cJv;
     }
@@ -2786,7 +2891,7 @@ struct Env {
       float gw, gs;
       init_context(D_WARM);
       const float cw = constraint_cost(D_WARM, &gw);
-      { const float t_ = dof(D_MA, gl < nv ? gl : 0); ma_warm = gl < nv ? t_ : 0.0f; }
+      ma_warm = r_ma;
       ja_warm = aJaref;
       jc_warm = cJaref;
       WSYNC();
@@ -2800,6 +2905,7 @@ struct Env {
       { const float w_ = dof(D_WARM, gl), s_ = dof(D_ASMOOTH, gl); dof(D_QACC, gl) = use_warm ? w_ : s_; }
       if (use_warm) dof(D_MA, gl) = ma_warm;  // context of the chosen start: M*qacc and J*qacc - aref
     }
+    r_ma = use_warm ? ma_warm : r_ma;
     if (use_warm) { aJaref = ja_warm; cJaref = jc_warm; }
     WSYNC();
     if (m.disableflags() & DIS_WARMSTART) {
@@ -2902,6 +3008,7 @@ struct Env {
       else spd_solve<G>(m.nchol(), eb + m.e_M(), m.ldm(), nv, dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), gl, gb4, m_rot);
     }
     else chol_solve<G>(m.nchol(), eb + m.e_M(), m.ldm(), nv, eb + m.e_Lb(), dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), true, gl, gb4);
+    { const float t_ = dof(D_ASMOOTH, gl < nv ? gl : 0); r_as = gl < nv ? t_ : 0.0f; }
     PROF(8);
     if (m.nefc() == 0) {
       if (gl < nv) { dof(D_QACC, gl) = dof(D_ASMOOTH, gl); dof(D_FCON, gl) = 0; }
