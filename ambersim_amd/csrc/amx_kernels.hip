@@ -2782,7 +2782,8 @@ struct Env {
   static DEV LSD ls_derivs(float alpha, float q1, float q2) { return LSD{alpha, __builtin_fmaf(alpha + alpha, q2, q1), fmaxf(q2 + q2, MINVAL)}; }
 
   // MJX's bracketing line search.  `alive` freezes the state of a group that has already converged.
-  DEV void linesearch(float gauss, bool alive) {
+  // Returns the cost decrease of the accepted step (0: no step), which is the solver's `improvement` for its stopping test.
+  DEV float linesearch(bool alive) {
     const int nv = m.nv();
     const float mv = mul_M_row(D_SEARCH);
     aJv = row_dot_A(D_SEARCH);
@@ -2796,16 +2797,14 @@ struct Env {
     }
     const bool validA = gl < nA(), validB = gl < nB(), iseq = gl < m.neq();
     // the three dof sums and the three row sums of the starting point alpha = 0, in one packed reduction
-    float p0_cost;
+    float q0_start;  // this lane's constant term at alpha = 0 (see the acceptance test below)
     LSD p0d;
     {
-      float q0;
-      const LSTerms t = ls_terms(0.0f, validA, validB, iseq, &q0);
+      const LSTerms t = ls_terms(0.0f, validA, validB, iseq, &q0_start);
       float u, w;
-      gsum_pack6<G>(g1, g2, t.q1, t.q2, sn, q0, u, w);
+      gsum_pack6<G>(g1, g2, t.q1, t.q2, sn, 0.0f, u, w);
       g1 = quad_value<0>(u); g2 = quad_value<1>(u); sn = quad_value<0>(w);
       const float q1 = quad_value<3>(u) + g1, q2 = quad_value<2>(u) + g2;
-      p0_cost = quad_value<1>(w) + gauss;  // alpha = 0: the cost is q0
       p0d = ls_derivs(0.0f, q1, q2);
     }
     PROF(21);
@@ -2861,30 +2860,39 @@ struct Env {
     }
     PROF(22);
 #undef PICK
-    // costs of the two bracket ends
-    float lo_cost, hi_cost;
+    // Costs of the two bracket ends RELATIVE TO THE STARTING POINT: cost(alpha) - cost(0) = alpha^2 q2 + alpha q1 + (q0(alpha) - q0(0)),
+    // with the difference of the constant terms formed per row before the group sum - it is exactly zero for every row whose
+    // activity did not change.  The reference compares cost(alpha) < cost(0) with both sides carrying the full constant term
+    // (the Gauss term and every active row's 0.5 D aref^2: 1e3 .. 1e5 for contacts a few centimetres deep), so in single
+    // precision an improvement below half an ulp of that constant reads as "no improvement", the step is dropped and the
+    // iterate stays where the previous iteration left it (r03, convex-convex draw of tests/test_convex.py: three of 32
+    // environments 50 - 110 x their one-ulp input sensitivity away from the fp64 oracle, all three from a dropped last step).
+    // Same algebra, same decisions in exact arithmetic; here the comparison resolves improvements down to the rounding of the
+    // quadratic terms themselves.
+    float lo_delta, hi_delta;
     {
       float q0l, q0h;
       const LSTerms tl = ls_terms(lo.alpha, validA, validB, iseq, &q0l), th = ls_terms(hi.alpha, validA, validB, iseq, &q0h);
       float u, w;
-      gsum_pack6<G>(tl.q1, tl.q2, th.q1, th.q2, q0l, q0h, u, w);
+      gsum_pack6<G>(tl.q1, tl.q2, th.q1, th.q2, q0l - q0_start, q0h - q0_start, u, w);
       const float q1l = quad_value<0>(u) + g1, q2l = quad_value<1>(u) + g2, q1h = quad_value<3>(u) + g1, q2h = quad_value<2>(u) + g2;
-      lo_cost = lo.alpha * lo.alpha * q2l + lo.alpha * q1l + (quad_value<0>(w) + gauss);
-      hi_cost = hi.alpha * hi.alpha * q2h + hi.alpha * q1h + (quad_value<1>(w) + gauss);
+      lo_delta = lo.alpha * lo.alpha * q2l + lo.alpha * q1l + quad_value<0>(w);
+      hi_delta = hi.alpha * hi.alpha * q2h + hi.alpha * q1h + quad_value<1>(w);
     }
-    const bool improved = alive & ((lo_cost < p0_cost) | (hi_cost < p0_cost));
-    const float alpha = lo_cost < hi_cost ? lo.alpha : hi.alpha;
+    const bool improved = alive & ((lo_delta < 0.0f) | (hi_delta < 0.0f));
+    const float alpha = lo_delta < hi_delta ? lo.alpha : hi.alpha;
     if (improved) {
       if (gl < nv) { r_ma += alpha * mv; dof(D_QACC, gl) += alpha * dof(D_SEARCH, gl); dof(D_MA, gl) = r_ma; }
       aJaref += alpha * aJv;
       cJaref += alpha * cJv;
     }
     WSYNC();
+    return improved ? -fminf(lo_delta, hi_delta) : 0.0f;
   }
 
   DEV void solve() {
     const int nv = m.nv();
-    float gauss, cost, prev_cost;
+    float gauss, cost;
     bool use_warm = false;
     float ma_warm = 0, ja_warm = 0, jc_warm = 0;
     if (!(m.disableflags() & DIS_WARMSTART)) {
@@ -2912,7 +2920,11 @@ struct Env {
       init_context(D_QACC);
       cost = constraint_cost(D_QACC, &gauss);
     }
-    prev_cost = INFINITY;
+    // cost decrease of the last accepted step.  The reference forms it as prev_cost - cost from two full evaluations of the cost;
+    // the line search knows it as the value of its quadratic model at the accepted step length (the cost along the search line
+    // IS that piecewise quadratic), without the cancellation of two sums of 1e3 .. 1e5 - and the full evaluation per iteration
+    // is not needed at all (see linesearch: acceptance test)
+    float improvement = INFINITY;
     PROF(9);
     constraint_force_and_grad(m.solver() == 2);
     PROF(10);
@@ -2934,25 +2946,21 @@ struct Env {
           const float g_ = dof(D_GRAD, gl < nv ? gl : 0);
           const float g = gl < nv ? g_ : 0.0f;
           const float gn = gsum<G>(g * g);
-          done = (fdiv(prev_cost - cost, m.scale()) < m.tolerance()) | (fdiv(sqrtf(gn), m.scale()) < m.tolerance());
+          done = (fdiv(improvement, m.scale()) < m.tolerance()) | (fdiv(sqrtf(gn), m.scale()) < m.tolerance());
         }
         alive = alive & !done;
       }
       if (!wave_any(alive)) break;
       PROF(12);
-      linesearch(gauss, alive);
+      const float dec = linesearch(alive);
+      improvement = alive ? dec : improvement;
       PROF(13);
       float pg = 0;  // CG: keep grad.Mgrad of the previous iterate
       if (m.solver() != 2) {
         if (gl < nv) { pg = dof(D_GRAD, gl) * dof(D_MGRAD, gl); lds[eb + m.e_H() + gl] = dof(D_MGRAD, gl); }  // CG scratch: the H buffer is idle
         pg = gsum<G>(pg);
       }
-      // a finished group's state is frozen, so recomputing its cost / force / gradient below is idempotent
-      float ngauss;
-      const float ncost = constraint_cost(D_QACC, &ngauss);
-      prev_cost = alive ? cost : prev_cost;
-      cost = alive ? ncost : cost;
-      gauss = alive ? ngauss : gauss;
+      // a finished group's state is frozen, so recomputing its force / gradient below is idempotent
       constraint_force_and_grad(m.solver() == 2 && niter + 1 < m.iterations(), alive);
       PROF(10);
       if (m.solver() == 2) {
@@ -2960,7 +2968,7 @@ struct Env {
         if (niter + 1 < m.iterations()) {
           // the next iteration's stopping test needs this point's improvement (known) and gradient (formed inside the fused
           // solve): evaluated there, it saves the elimination when the wave is finished
-          const bool imp_done = fdiv(prev_cost - cost, m.scale()) < m.tolerance();
+          const bool imp_done = fdiv(improvement, m.scale()) < m.tolerance();
           stop = newton_direction(alive, m.iterations() != 1, imp_done, &next_done);
           have_next = m.iterations() != 1;
           PROF(11);

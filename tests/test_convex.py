@@ -20,6 +20,19 @@ def two(pb, qb="", gb='type="box" size="0.5 0.5 0.5"', ja="<freejoint/>", g=0, a
     return MjModel.from_xml_string(TWO.format(pb=pb, qb=qb, gb=gb, ja=ja, g=g, asset=asset))
 
 
+def ulp_sensitivity(mj, x0, us, reps=8, seed=5):
+    """Per env: how far the fp64 oracle's state after the rollout moves (relative to the state scale) when every input moves by
+    one fp32 ulp - the conditioning of the problem itself; a backward-stable fp32 computation sits within a small multiple."""
+    o = Oracle(mj, np.float64)
+    ref = o.rollout(x0, us)[:, -1]
+    prng = np.random.default_rng(seed)
+    sens = np.zeros(x0.shape[0])
+    for _ in range(reps):
+        xp = x0.astype(np.float64) * (1 + 6e-8 * prng.choice([-1.0, 1.0], size=x0.shape))
+        sens = np.maximum(sens, np.abs(o.rollout(xp, us)[:, -1] - ref).max(axis=1) / np.maximum(1.0, np.abs(ref).max(axis=1)))
+    return sens
+
+
 def contacts(mj, qpos=None):
     o = Oracle(mj)
     o.set_state(mj.qpos0 if qpos is None else qpos, np.zeros(mj.nv), np.zeros(mj.nu))
@@ -162,9 +175,10 @@ def test_convex_convex_gpu_vs_oracle():
         floor1 = np.median(floor1) * 10  # typical fp32 distance of the CPU oracle itself (robust to envs where its own tie-breaks flip)
         print(f"convex-convex {name}: {nact} active contacts over {nenv} envs; 1-step err {e1.max():.2e} (fp32 oracle's own scale {floor1:.2e}; "
               f"{(e1_64 < 1e-5).mean():.2f} of the envs within 1e-5 of the fp64 oracle), 5-step err median {np.median(e5):.2e} max {e5.max():.2e}")
-        # contacts here start centimetres deep (random placement): the first step's penalty forces are large and the fp32 floor
-        # sits above 1e-5 for a few envs (bound: 3e-5, or 4x the CPU oracle's own fp32 scale); most envs, and every env after five steps, are inside the usual bounds
-        assert e1.max() < max(3e-5, 4 * floor1) and (e1_64 < 1e-5).mean() >= 0.75, (name, e1.max(), floor1)
+        # every env within 1e-5 after one step (r02 needed 3e-5 here and had 0.88 - 0.94 of the envs inside 1e-5: the line search
+        # dropped the last Newton step of a few envs when its improvement fell below the rounding of the full cost - fixed in
+        # r03, see linesearch's acceptance test; now 8e-7 / 1.3e-6 / 5.5e-7, below the CPU fp32 oracle's own distance)
+        assert e1.max() < 1e-5 and (e1_64 < 1e-5).mean() >= 0.97, (name, e1.max(), floor1)
         assert e5.max() < 5e-5, (name, e5.max())
         assert np.median(e5) < 5e-5, (name, np.median(e5))
     xml = """<mujoco><option timestep="0.002" iterations="10" ls_iterations="10"/><worldbody><geom type="plane" size="5 5 .1"/>
@@ -174,7 +188,94 @@ def test_convex_convex_gpu_vs_oracle():
     model = mjx.put_model(mj, dev)
     x0 = np.concatenate([mj.qpos0, np.zeros(12)]).astype(np.float32)
     xs = mjx.rollout(model, torch.tensor(x0), torch.zeros((1, 1000, 0))).cpu().numpy()[0]
-    assert np.isfinite(xs).all() and np.abs(xs[-1, mj.nq:]).max() < 1e-2 and xs[-1, 9] > 0.295 and xs[-1, 2] > 0.095
+    # at rest the stack's active set keeps flipping and the velocities chatter: the oracle's own |v| over the last 200 steps has
+    # median 4.4e-3 and peaks of 2.4e-2 (fp64; fp32 ends on 2.0e-2), so the bounds are on those statistics, not on the last sample
+    vmax = np.abs(xs[-200:, mj.nq:]).max(axis=1)
+    assert np.isfinite(xs).all() and np.median(vmax) < 1e-2 and vmax.max() < 5e-2 and xs[-1, 9] > 0.295 and xs[-1, 2] > 0.095
+
+
+def _gpu_forward(mj, qpos=None):
+    """amx_forward at rest through the C ABI: contact distances and qfrc_constraint of one env."""
+    import ctypes as C
+    import torch
+    from ambersim_amd import _lib, mjx
+    dev = torch.device("cuda", 0)
+    model = mjx.put_model(mj, dev)
+    q = torch.tensor(np.asarray(mj.qpos0 if qpos is None else qpos, dtype=np.float32)[None], device=dev)
+    v = torch.zeros((1, mj.nv), device=dev)
+    cd, fc = torch.zeros((1, mj.ncon), device=dev), torch.zeros((1, mj.nv), device=dev)
+    out = _lib.AmxForwardOut(None, None, None, fc.data_ptr(), None, None, None, cd.data_ptr(), None)
+    _lib.check(_lib.lib().amx_forward(model._h.ptr, 1, q.data_ptr(), v.data_ptr(), torch.zeros((1, 1), device=dev).data_ptr(), None, C.byref(out), None))
+    torch.cuda.synchronize()
+    return cd[0].cpu().numpy().astype(np.float64), fc[0].cpu().numpy().astype(np.float64)
+
+
+def _rot(q):
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+@pytest.mark.gpu
+def test_convex_manifold_kats_gpu():
+    """The hand-computed manifolds of the CPU tests above, on the HIP path alone (no oracle in the loop): depth from the contact
+    distances, normal from the direction of the constraint force on the two free bodies (equal and opposite, along the known
+    normal, no tangential part at rest), contact position from the torque that force exerts about each body's centre
+    (free-joint rotational dofs are in the body frame: R' ((p - c) x f))."""
+    # nearly frictionless geoms (mu = 1e-3): a contact off the bodies' axes makes them turn, the contact points slide and the
+    # pyramid's friction answers - with mu = 1 a tenth of the force is tangential; here at most a thousandth
+    slick = '<default><geom friction="0.001"/></default>'
+
+    def force_checks(mj, q, fc, normal, pos, tol=2e-3):
+        fa, fb = fc[0:3], fc[6:9]
+        F = np.linalg.norm(fb)
+        assert F > 1.0 and np.allclose(fb / F, normal, atol=tol) and np.allclose(fa, -fb, atol=tol * F)
+        for adr, f in ((0, fa), (6, fb)):
+            c, R = q[adr + adr // 6: adr + adr // 6 + 3], _rot(q[adr + adr // 6 + 3: adr + adr // 6 + 7])  # qpos: 7 per free joint, dofs: 6
+            want = R.T @ np.cross(np.asarray(pos) - c, f)
+            assert np.allclose(fc[adr + 3: adr + 6], want, atol=tol * F), (adr, fc[adr + 3: adr + 6], want)
+    # 1. face-face, the upper cube yawed by 25 deg and sunk 0.1: four contacts of depth 0.1, normal +z; the resultant acts at the
+    # centroid of the overlap region's manifold, which by symmetry of nothing in particular is only pinned through the torque
+    # balance: both bodies see the same force at the same points, so torque_a + torque_b about a common point cancels
+    mj = two("0.2 0.1 0.9", qb='euler="0 0 25"', asset=slick)
+    dist, fc = _gpu_forward(mj)
+    assert (dist < 0).all() and np.allclose(dist, -0.1, atol=2e-6)
+    fa, fb = fc[0:3], fc[6:9]
+    F = np.linalg.norm(fb)
+    assert F > 1.0 and np.allclose(fb / F, [0, 0, 1], atol=2e-3) and np.allclose(fa, -fb, atol=2e-4 * F)
+    q = mj.qpos0
+    tau_a, tau_b = _rot(q[3:7]) @ fc[3:6], _rot(q[10:14]) @ fc[9:12]              # world-frame torques about each centre
+    tau_b_about_a = tau_b + np.cross(q[7:10] - q[0:3], fb)                        # moved to body a's centre
+    assert np.allclose(tau_a + tau_b_about_a, 0, atol=2e-4 * F)
+    # 2. edge-edge: crossed cubes, the upper one shifted 0.1 along its own bottom edge (x): the edges still cross above the origin
+    r = 0.5 * np.sqrt(2)
+    s, c = np.sin(np.pi / 8), np.cos(np.pi / 8)
+    mj = two(f"0.1 0 {2 * r - 0.05}", qb=f'quat="{c} {s} 0 0"', asset=slick)
+    q = mj.qpos0.copy()
+    q[3:7] = [c, 0, s, 0]
+    dist, fc = _gpu_forward(mj, q)
+    act = dist < 0
+    assert act.sum() == 1 and np.isclose(dist[act][0], -0.05, atol=2e-6)
+    force_checks(mj, q, fc, [0, 0, 1], [0, 0, r - 0.025])
+    # 3. vertex into face: an octahedron's lower tip 0.03 inside the top face of the cube, off the cube's axis
+    verts = "0.2 0 0  -0.2 0 0  0 0.2 0  0 -0.2 0  0 0 0.2  0 0 -0.2"
+    mj = two("0.1 0.05 0.67", gb='type="mesh" mesh="o"', asset=f'<asset><mesh name="o" vertex="{verts}"/></asset>' + slick)
+    dist, fc = _gpu_forward(mj)
+    act = dist < 0
+    assert act.sum() == 1 and np.isclose(dist[act][0], -0.03, atol=2e-6)
+    force_checks(mj, mj.qpos0, fc, [0, 0, 1], [0.1, 0.05, 0.485])
+    # 4. a tilted corner: the upper cube turned so that its body diagonal points down (corner first), the corner 0.04 inside the
+    # lower cube's top face at (0.15, -0.1): one contact, depth 0.04, normal +z, at the corner's mid-depth
+    d = np.array([1.0, 1.0, 1.0]) / np.sqrt(3)                                     # body diagonal -> world -z
+    axis = np.cross(d, [0, 0, -1.0]); ang = np.arccos(-d[2])
+    axis /= np.linalg.norm(axis)
+    qb = np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * axis])
+    h = 0.5 * np.sqrt(3)                                                           # centre-to-corner distance
+    mj = two(f"0.15 -0.1 {0.5 + h - 0.04}", qb='quat="%.9f %.9f %.9f %.9f"' % tuple(qb), asset=slick)
+    dist, fc = _gpu_forward(mj)
+    act = dist < 0
+    assert act.sum() == 1 and np.isclose(dist[act][0], -0.04, atol=2e-6)
+    force_checks(mj, mj.qpos0, fc, [0, 0, 1], [0.15, -0.1, 0.5 - 0.02])
 
 
 TOUCH_Q = np.array([1.89136115, 0.44176919, 1.60875547, 2.28816911, 0.29384365, 1.74812746, 2.37906276, 0.68614988])  # distal links of fingers 1 and 2 interpenetrate here
@@ -221,7 +322,7 @@ def test_two_finger_fixture_is_current():
 @pytest.mark.gpu
 def test_barrett_two_fingers_gpu_vs_oracle():
     """The two-finger Barrett fixture on the GPU: poses around the touching one (some in contact, some not), one step within
-    3e-5 of the fp64 oracle (the Barrett hand's stiff equality rows, as in test_single_step_parity) and ten steps finite
+    1e-5 of the fp64 oracle (r02: 3e-5; r03 measures 2.1e-6), ten steps within 1e-5 in the median and 5e-5 at worst, finite
     with the same contact activity as the oracle."""
     import torch
     from ambersim_amd import mjx
@@ -245,7 +346,7 @@ def test_barrett_two_fingers_gpu_vs_oracle():
     e1 = np.minimum(np.abs(xs[:, 1] - ref[:, 1]).max(axis=1), np.abs(xs[:, 1] - ref32[:, 1]).max(axis=1)) / np.maximum(1.0, np.abs(ref[:, 1]).max(axis=1))
     e10 = np.minimum(np.abs(xs[:, 10] - ref[:, 10]).max(axis=1), np.abs(xs[:, 10] - ref32[:, 10]).max(axis=1)) / np.maximum(1.0, np.abs(ref[:, 10]).max(axis=1))
     print(f"bh280 two fingers: {nact} of {nenv} envs in contact; 1-step err {e1.max():.2e}, 10-step err median {np.median(e10):.2e} max {e10.max():.2e}")
-    assert np.isfinite(xs).all() and e1.max() < 3e-5 and np.median(e10) < 1e-4
+    assert np.isfinite(xs).all() and e1.max() < 1e-5 and np.median(e10) < 1e-5 and e10.max() < 5e-5
 
 
 SPHERE_BOX = """
@@ -290,7 +391,7 @@ def test_sphere_resting_on_box():
 @pytest.mark.gpu
 def test_sphere_convex_gpu_vs_oracle():
     """The HIP path on seeded random sphere-box and sphere-mesh poses (touching, penetrating, separated, near edges and corners):
-    contact distance within 1e-5 of the oracle's for every env, one step within 3e-5 and five within 1e-4 of the fp64 oracle (relative to the state scale)."""
+    contact distance within 1e-5 of the oracle's for every env, one step within 1e-5 per env (or 10x the env's one-ulp input sensitivity) and five within 2e-5 of the fp64 oracle (relative to the state scale)."""
     import ctypes as C
     import torch
     from ambersim_amd import _lib, mjx
@@ -330,5 +431,14 @@ def test_sphere_convex_gpu_vs_oracle():
         ref = Oracle(mj, np.float64).rollout(x0, us)
         e1 = np.abs(xs[:, 1] - ref[:, 1]).max() / max(1.0, np.abs(ref[:, 1]).max())
         e5 = np.abs(xs[:, 5] - ref[:, 5]).max() / max(1.0, np.abs(ref[:, 5]).max())
-        print(f"{name}: {(ref_d < 0).sum()} of {nenv} envs in contact, 1-step err {e1:.2e}, 5-step err {e5:.2e}")
-        assert e1 < 3e-5 and e5 < 1e-4, (name, e1, e5)
+        # per env, against how far the fp64 answer itself moves when the inputs move by one fp32 ulp: a sphere centre close to
+        # the closest feature of the hull (deep inside the octahedron) makes the contact normal a quotient of small numbers
+        e1_env = np.abs(xs[:, 1] - ref[:, 1]).max(axis=1) / np.maximum(1.0, np.abs(ref[:, 1]).max(axis=1))
+        sens = ulp_sensitivity(mj, x0, us[:, :1])
+        ref32 = Oracle(mj, np.float32).rollout(x0, us[:, :1]).astype(np.float64)
+        e1_cpu32 = np.abs(ref32[:, 1] - ref[:, 1]).max(axis=1) / np.maximum(1.0, np.abs(ref[:, 1]).max(axis=1))
+        print(f"{name}: {(ref_d < 0).sum()} of {nenv} envs in contact, 1-step err {e1:.2e} (worst env {e1_env.max():.2e}, worst err / one-ulp sensitivity "
+              f"{(e1_env / np.maximum(sens, 1e-9)).max():.1f}), 5-step err {e5:.2e}")
+        # (one env of the sphere-mesh draw sits at 1.8e-5 with the CPU restatement in fp32 at 4.5e-5: the loss is in the arithmetic
+        # of the closest-feature computation, which neither the inputs' conditioning nor the precision of one side explains away)
+        assert (e1_env < np.maximum(1e-5, np.maximum(10 * sens, e1_cpu32))).all() and e1 < 2e-5 and e5 < 2e-5, (name, e1, e5)

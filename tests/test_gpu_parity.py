@@ -96,17 +96,18 @@ def test_single_step_parity(cases, golden, name):
                 oo.set_state(q[e].astype(np.float32), v[e].astype(np.float32), u[e].astype(np.float32), np.zeros(nv)); oo.step()
             worst = max(worst, rel(g[e, :nq], o.get("qpos")), rel(g[e, nq:], o.get("qvel")))
             floor = max(floor, rel(o32.get("qpos"), o.get("qpos")), rel(o32.get("qvel"), o.get("qvel")))
-    # 1e-5, or - where the problem is ill-conditioned enough that the CPU fp32 restatement itself is off by more than a
-    # third of that (bh280 started outside its joint limits: tiny finger inertias, stiff rows) - 3x that fp32 floor
-    assert worst < max(TOL, 3 * floor) and worst < 3e-5, (worst, floor)
+    # 1e-5 for every model, the Barrett hand included (r02 needed 3x the fp32 CPU restatement's own error there, up to 3e-5:
+    # the hand starts outside its joint limits, the costs are large and the line search dropped Newton steps whose improvement
+    # fell below the rounding of the full cost - see linesearch's acceptance test in csrc/amx_kernels.hip)
+    assert worst < TOL, (worst, floor)
 
 
-@pytest.mark.parametrize("name,steps,tol", [("bh280", 10, 3e-5), ("quadruped", 5, 5e-5), ("biped", 5, 5e-5)])
+@pytest.mark.parametrize("name,steps,tol", [("bh280", 10, 2e-5), ("quadruped", 5, 2e-5), ("biped", 5, 2e-5)])
 def test_short_rollout_vs_golden(cases, golden, name, steps, tol):
     """Multi-step rollouts vs the committed fp64 fixtures.  The fp32 CPU oracle is itself 1.2e-5 away from the fp64
     fixture on bh280 (10-step horizon of the reference's own fixture, started outside the joint limits) and ~5e-5 away
-    on the contact models after 5 steps (rounding moves active sets): bounds are 3e-5 and 5e-5 (tests/test_golden_cpu.py
-    has the CPU fp32-vs-fp64 counterpart)."""
+    on the contact models after 5 steps (rounding moves active sets; tests/test_golden_cpu.py has the CPU fp32-vs-fp64
+    counterpart).  Bounds: 2e-5 (r03 measures 1.2e-5 on bh280 at step 7 and < 1e-5 on the contact models; r02: 3e-5 / 5e-5)."""
     mj, model, x0, us = cases[name]
     xs = gpu_rollout(model, x0, us)
     ref = golden[name + "_xs"]
@@ -177,8 +178,7 @@ def test_specialised_and_generic_kernels(cases, golden):
         assert generic._h.query("specialised") == 0
         ref = golden[name + "_xs"]
         a, b = gpu_rollout(model, x0, us), gpu_rollout(generic, x0, us)
-        tol = 3e-5 if name == "bh280" else TOL
-        assert rel(a[:, 1], ref[:, 1]) < tol and rel(b[:, 1], ref[:, 1]) < tol, name
+        assert rel(a[:, 1], ref[:, 1]) < TOL and rel(b[:, 1], ref[:, 1]) < TOL, name
         assert rel(a[:, 3], b[:, 3]) < 5e-5, name
     mj, model, x0, us = cases["quadruped"]
     assert model.replace(opt=model.opt.replace(iterations=2))._h.query("specialised") == 0
@@ -698,7 +698,7 @@ def test_forced_lane_group_widths(cases, golden, force, dev):
             assert model._h.query("lanes_per_env") == max(int(force), cases[name][1]._h.query("lanes_per_env"))
             xs = gpu_rollout(model, x0.astype(np.float32), us.astype(np.float32))
             ref = golden[name + "_xs"]
-            assert rel(xs[:, 1], ref[:, 1]) < (TOL if name != "bh280" else 3e-5), (name, force)
+            assert rel(xs[:, 1], ref[:, 1]) < TOL, (name, force)
     finally:
         del os.environ["AMX_FORCE_G"]
 
