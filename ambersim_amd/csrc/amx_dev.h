@@ -47,7 +47,7 @@ enum { CX_MAXV = 32, CX_MAXP = 16, CX_VA = 0, CX_VB = 96, CX_POLY = 192, CX_SCRA
 //   sizes .. options
 #define AMX_MODEL_INTS(X)                                                                                                  \
   X(nconst)                                                                                                                \
-  X(nq) X(nv) X(nu) X(nb) X(njnt) X(ngc) X(npair) X(npc) /* collision pairs: [0, npc); [npc, npair) are the row groups of connect / weld equalities */ X(ncon) X(neq) X(nfri) /* friction-loss rows, between the equality and the limit rows */ X(nlim) X(nefc) X(nlevel) X(nM) X(nroot)                    \
+  X(nq) X(nv) X(nu) X(nb) X(njnt) X(ngc) X(npair) X(npc) /* collision pairs: [0, npc); [npc, npair - nbl) are the row groups of connect / weld equalities */ X(nbl) /* [npair - nbl, npair): ball-joint limit rows */ X(ncon) X(neq) X(nfri) /* friction-loss rows, between the equality and the limit rows */ X(nlim) X(nefc) X(nlevel) X(nM) X(nroot)                    \
   X(ldc) /* contact-row stride: longest pair dof list, odd */                                                              \
   X(ldm) /* row stride of M and H: >= nv, a multiple of 4 */                                                                \
   X(mrot) /* 1: row i of M stores chunk c at position (c + i) mod ldm/4 (fused path with an even chunk count) */          \

@@ -1525,7 +1525,8 @@ struct Env {
   // LDS fields stay current - other routines and the outputs read them - but the solver's own per-dof arithmetic no longer waits for them.
   float r_ma, r_fs, r_as;
   bool aact, cact;  // the slot's row is active at the current iterate (set by constraint_force_and_grad)
-  bool cEq;         // the lane's slot B row belongs to a connect / weld equality (a pseudo-pair, [npc, npair)): active on both sides
+  bool cEq;         // the lane's slot B row belongs to a connect / weld equality (a pseudo-pair, [npc, npair - nbl)): active on both sides
+  bool cBl;         // ... to a ball joint's limit (pseudo-pair [npair - nbl, npair)): single-sided like a contact row, one row per group
   PROF_DECL
 
   DEV int nA() const { return m.nefc() == 0 ? 0 : m.neq() + m.nfri() + m.nlim(); }  // nefc == 0: constraints disabled
@@ -1553,11 +1554,12 @@ struct Env {
     else if (lane < m.neq() + m.nfri()) rd1 = CI(m.c_fri() + (lane - m.neq()) * FRI_S);
     else if (lane < m.neq() + m.nfri() + m.nlim()) rd1 = CI(m.c_lim() + (lane - m.neq() - m.nfri()) * LIM_S + 1);
     vch_base = eb + m.e_vch();
-    cEq = false;
+    cEq = false; cBl = false;
     if (lane < 4 * m.ncon()) {
       const int pr_ = CI(m.c_conpair() + (lane >> 2));
       vch_base += pr_ * m.ldc();
-      cEq = m.npair() > m.npc() && pr_ >= m.npc();
+      cEq = m.npair() > m.npc() && pr_ >= m.npc() && pr_ < m.npair() - m.nbl();
+      cBl = m.nbl() > 0 && pr_ >= m.npair() - m.nbl();
     }
     {
       const int nvch = m.npair() * m.ldc();
@@ -2130,7 +2132,24 @@ struct Env {
     }
     if (m.ncx() > 0 && contacts_on)  // uniform: a property of the model
       convex_convex_pairs<G>(m.cx_first(), m.ncx(), m.c_pair(), eb + m.e_geom(), eb + m.e_con(), eb + m.e_frame(), eb + m.e_cx(), gl, gb4);
-    if (m.npair() > m.npc() && !(m.disableflags() & DIS_EQUALITY) && gl >= m.npc() && gl < np) {
+    if (m.nbl() > 0 && gl >= np - m.nbl() && gl < np) {
+      // A ball joint's limit (MJX constraint._instantiate_limit_ball; oracle: make_constraint): the joint
+      // quaternion (normalised by kinematics) as axis * angle, the angle wrapped to (-pi, pi] and made positive by turning the
+      // axis; distance = max(range) - angle.  The frame slot carries the axis (the row's Jacobian is -axis on the three dofs).
+      const int pr = gl, rec = m.c_pair() + pr * PAIR_S, qa = eb + m.e_qpos() + CI(rec), c0 = CI(rec + 3);
+      const float qw = lds[qa], qx = lds[qa + 1], qy = lds[qa + 2], qz = lds[qa + 3];
+      const float s_ = sqrtf(qx * qx + qy * qy + qz * qz);
+      const float inv = 1.0f / (s_ + (s_ == 0.0f ? 1e-6f : 0.0f));  // math.normalize_with_norm
+      float ang = 2.0f * atan2f(s_, qw);
+      ang = ang > 3.14159265358979f ? ang - 6.28318530717959f : ang;
+      const f3 av = mk3(qx * inv * ang, qy * inv * ang, qz * inv * ang);
+      const float n_ = sqrtf(dot(av, av));
+      const float inv2 = 1.0f / (n_ + (n_ == 0.0f ? 1e-6f : 0.0f));
+      con(0, c0) = CF(rec + 23) - n_;
+      const int fo = eb + m.e_frame() + pr * 9;
+      lds[fo] = av.x * inv2; lds[fo + 1] = av.y * inv2; lds[fo + 2] = av.z * inv2;
+    }
+    if (m.npair() - m.nbl() > m.npc() && !(m.disableflags() & DIS_EQUALITY) && gl >= m.npc() && gl < np - m.nbl()) {
       // Row groups of the connect / weld equalities (oracle: make_constraint, connect and weld): the residual of
       // the group and what its Jacobian entries need, while the body poses are still at hand.  Function 8: a point fixed in
       // body1 against a point fixed in body2; function 9 (second group of a weld): the relative orientation against relpose.
@@ -2317,6 +2336,8 @@ struct Env {
           const f3 fn_ = mk3(lds[fo], lds[fo + 1], lds[fo + 2]), ft1 = mk3(lds[fo + 3], lds[fo + 4], lds[fo + 5]),
                    ft2 = mk3(lds[fo + 6], lds[fo + 7], lds[fo + 8]);
           const f3 w = mk3(dof(0, i), dof(1, i), dof(2, i)), l = mk3(dof(3, i), dof(4, i), dof(5, i));
+          if (m.nbl() > 0 && pr >= m.npair() - m.nbl())  // a ball joint's limit: -axis on the joint's three dofs (slot = 0, 1, 2), rows 1..3 idle
+            return JEnt{Jo + (4 * c) * ldc + slot, -lds[fo + (slot < 3 ? slot : 0)], 0.0f, 0.0f, 0.0f};
           if (eq_groups && pr >= m.npc()) {
             // a connect / weld row group (oracle: make_constraint): body1's Jacobian minus body2's
             const bool s1 = sg & 1, s2 = sg & 2;  // the dof moves body2 / body1
@@ -2413,6 +2434,19 @@ struct Env {
     aFl = fl_;
     // slot B: contact pyramid row gl, or row gl of a connect / weld group
     dd = 0; ar = 0;
+    if (m.nbl() > 0 && cBl) {
+      // a ball joint's limit: row 0 of the group, active when the rotation angle is within the margin of the range
+      const int cr = gl, c = cr >> 2, k = cr & 3;
+      const int prec = m.c_pair() + CI(m.c_conpair() + c) * PAIR_S, rec = prec + 12;
+      const float pos = con(0, c) - CF(prec + 21), invw = CF(prec + 22);
+      const float jv = chain_dot(Jo + cr * ldc);
+      if (con_on && k == 0 && pos < 0 && !(m.disableflags() & DIS_LIMIT)) {
+        const float imp = row_impedance(rec, pos);
+        const float rr = fmaxf(fdiv(invw * (1 - imp), imp), MINVAL);
+        dd = fdiv(1.0f, rr);
+        ar = -CF(rec + 1) * jv - CF(rec) * imp * pos;
+      }
+    } else
     if (eq_groups && cEq) {
       // three rows per group (the fourth idles), always active, impedance at the norm of the equality's whole residual
       const int cr = gl, c = cr >> 2, k = cr & 3;

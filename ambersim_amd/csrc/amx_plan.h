@@ -35,7 +35,7 @@ struct Image {
   int geti(int off) const { int x; memcpy(&x, &v[off], 4); return x; }
   void setf(int off, double x) { v[off] = (float)x; }
 };
-const int PAIR_NCON[10] = {1, 2, 4, 1, 1, 1, 4, 1, 1, 1};  // 8, 9: one row group each (connect / weld-translation, weld-rotation)
+const int PAIR_NCON[11] = {1, 2, 4, 1, 1, 1, 4, 1, 1, 1, 1};  // 8, 9: one row group each (connect / weld-translation, weld-rotation); 10: a ball joint's limit row
 
 // {k, b, dmin, dmax, width, mid, power, ca, cb}: the position-independent part of MuJoCo's solref/solimp
 // mapping (reference physics: constraint._kbi), evaluated once on the host in double precision.
@@ -90,7 +90,12 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
   // connect (3 rows + 1 idle), two per weld (translation, rotation)
   int neqgroups = 0;
   for (int e = 0; e < d->neq; e++) if (d->eq_active[e] && d->eq_type[e] >= 0 && d->eq_type[e] <= 1) neqgroups += d->eq_type[e] == 1 ? 2 : 1;
-  const int nb = d->nbody, nv = d->nv, nq = d->nq, nu = d->nu, nj = d->njnt, npc = d->npair, np = d->npair + neqgroups;
+  // limited ball joints: one row on the joint's three dofs (MJX _instantiate_limit_ball) - a third kind of pseudo-pair, behind the
+  // equality groups: the contact rows' machinery already handles rows over a dof list, single-sided and active by distance
+  std::vector<int> ball_j;
+  for (int j = 0; j < d->njnt; j++) if (d->jnt_limited[j] && d->jnt_type[j] == 1) ball_j.push_back(j);
+  const int nbl = (int)ball_j.size();
+  const int nb = d->nbody, nv = d->nv, nq = d->nq, nu = d->nu, nj = d->njnt, npc = d->npair, np = d->npair + neqgroups + nbl;
   if (nb > AMX_WAVE || nj > AMX_WAVE || np > AMX_WAVE)
     return fail(AMX_ECAPACITY, "lane-role capacity: nbody=%d njnt=%d npair=%d must each be <= %d", nb, nj, np, AMX_WAVE);
 
@@ -136,7 +141,7 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
   }
 
   memset(&m, 0, sizeof(m));
-  m.nq = nq; m.nv = nv; m.nu = nu; m.nb = nb; m.njnt = nj; m.npair = np; m.npc = npc;
+  m.nq = nq; m.nv = nv; m.nu = nu; m.nb = nb; m.njnt = nj; m.npair = np; m.npc = npc; m.nbl = nbl;
   m.iterations = d->iterations; m.ls_iterations = d->ls_iterations; m.solver = d->solver; m.disableflags = d->disableflags;
   m.dt = (float)d->timestep; m.gx = (float)d->gravity[0]; m.gy = (float)d->gravity[1]; m.gz = (float)d->gravity[2];
   m.tolerance = (float)d->tolerance; m.ls_tolerance = (float)d->ls_tolerance; m.impratio = (float)d->impratio;
@@ -199,7 +204,7 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
   for (int j = 0; j < nj; j++) {
     int o = m.c_jnt + j * JNT_S, t = d->jnt_type[j], qa = d->jnt_qposadr[j];
     if (t <= 1 && d->jnt_stiffness[j] != 0) return fail(AMX_EUNSUPPORTED, "spring on free/ball joint %d", j);
-    if (t <= 1 && d->jnt_limited[j]) return fail(AMX_EUNSUPPORTED, "limits on free/ball joint %d", j);
+    if (t == 0 && d->jnt_limited[j]) return fail(AMX_EUNSUPPORTED, "limits on free joint %d", j);
     im.seti(o, t); im.seti(o + 1, qa); im.seti(o + 2, d->jnt_dofadr[j]); im.seti(o + 3, d->jnt_bodyid[j]);
     for (int k = 0; k < 3; k++) { im.setf(o + 4 + k, d->jnt_pos[3 * j + k]); im.setf(o + 7 + k, d->jnt_axis[3 * j + k]); }
     im.setf(o + 10, d->qpos0[qa]); im.setf(o + 11, d->jnt_stiffness[j]); im.setf(o + 12, d->qpos_spring[qa]);
@@ -293,8 +298,20 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
     if (d->eq_active[e] && d->eq_type[e] <= 1) { eqgroup.push_back({e, 8}); if (d->eq_type[e] == 1) eqgroup.push_back({e, 9}); }
   for (int p = 0; p < np; p++) {
     const int o = m.c_pair + p * PAIR_S;
-    int fn, b1, b2, g1 = 0, g2 = 0;
-    if (p >= npc) {
+    int fn, b1 = 0, b2 = 0, g1 = 0, g2 = 0;
+    if (p >= np - nbl) {
+      // a ball joint's limit: the record carries where the quaternion and the three dofs sit, the larger end of the range, the
+      // margin, the limit's stiffness / impedance constants and the joint's invweight
+      const int j = ball_j[p - (np - nbl)];
+      fn = 10;
+      im.seti(o, d->jnt_qposadr[j]); im.seti(o + 1, d->jnt_dofadr[j]); im.seti(o + 2, fn); im.seti(o + 3, ncon); im.seti(o + 4, 1);
+      im.seti(o + 5, 0); im.seti(o + 7, 0); im.seti(o + 8, 0);
+      im.setf(o + 11, 0.0);
+      write_kbi(im, o + 12, d->jnt_solref + 2 * j, d->jnt_solimp + 5 * j, d->timestep, refsafe);
+      im.setf(o + 21, d->jnt_margin[j]);
+      im.setf(o + 22, d->dof_invweight0[d->jnt_dofadr[j]]);
+      im.setf(o + 23, std::max(d->jnt_range[2 * j], d->jnt_range[2 * j + 1]));
+    } else if (p >= npc) {
       // connect / weld: bodies instead of geoms, body-fixed points and the relative orientation instead of shapes
       const int e = eqgroup[p - npc].first;
       fn = eqgroup[p - npc].second;
@@ -330,8 +347,10 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
     im.setf(o + 21, d->pair_margin[p]);
     im.setf(o + 22, d->body_invweight0[2 * b1] + d->body_invweight0[2 * b2]);
     }
-    // union of the ancestor dof chains of both bodies
+    // union of the ancestor dof chains of both bodies (a ball limit: the joint's own three dofs)
     std::vector<int> sign(nv, 0);
+    if (fn == 10) { const int da = d->jnt_dofadr[ball_j[p - (np - nbl)]]; for (int k = 0; k < 3; k++) sign[da + k] = 1; }
+    else
     for (int side = 0; side < 2; side++) {
       int b = side == 0 ? b2 : b1;
       while (b > 0 && d->body_dofnum[b] == 0) b = d->body_parentid[b];
@@ -386,7 +405,7 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
   }
   // limit rows, equality rows
   std::vector<int> lim_j;
-  for (int j = 0; j < nj; j++) if (d->jnt_limited[j]) lim_j.push_back(j);
+  for (int j = 0; j < nj; j++) if (d->jnt_limited[j] && d->jnt_type[j] >= 2) lim_j.push_back(j);  // slide / hinge (ball: pseudo-pairs above)
   m.nlim = (int)lim_j.size();
   m.c_lim = im.reserve(m.nlim * LIM_S);
   for (int l = 0; l < m.nlim; l++) {

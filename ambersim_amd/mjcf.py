@@ -573,8 +573,8 @@ class _Compiler:
         frictionloss = float(at.get("frictionloss", 0))
         if frictionloss < 0:
             raise ValueError("joint frictionloss must be non-negative")
-        if jt == JNT_BALL and limited:
-            raise NotImplementedError("ball joint limits")
+        if jt == JNT_BALL and limited and rng[0] != 0:
+            raise ValueError("ball joint range must start at 0 (the limit is on the rotation angle)")
         return dict(
             name=at.get("name", ""), type=jt, pos=_floats(at.get("pos", "0 0 0"), 3), axis=axis,
             limited=limited, range=rng, damping=float(at.get("damping", 0)), armature=float(at.get("armature", 0)),

@@ -50,6 +50,7 @@ static inline REAL r_sqrt(REAL x) { FLOP1(); return IS_FLOAT ? (REAL)sqrtf((floa
 static inline REAL r_sin(REAL x) { FLOP1(); return IS_FLOAT ? (REAL)sinf((float)x) : (REAL)sin((double)x); }
 static inline REAL r_cos(REAL x) { FLOP1(); return IS_FLOAT ? (REAL)cosf((float)x) : (REAL)cos((double)x); }
 static inline REAL r_pow(REAL x, REAL y) { FLOP1(); return IS_FLOAT ? (REAL)powf((float)x, (float)y) : (REAL)pow((double)x, (double)y); }
+static inline REAL r_atan2(REAL y, REAL x) { FLOP1(); return IS_FLOAT ? (REAL)atan2f((float)y, (float)x) : (REAL)atan2((double)y, (double)x); }
 static inline REAL r_abs(REAL x) { return x < 0 ? -x : x; }
 static inline REAL r_max(REAL a, REAL b) { return a > b ? a : b; }
 static inline REAL r_min(REAL a, REAL b) { return a < b ? a : b; }
@@ -167,7 +168,7 @@ amxo_model *amxo_model_create(const amx_model_desc *d) {
   m->ncon = 0;
   for (size_t p = 0; p < np; p++) { m->pair_conadr[p] = m->ncon; m->ncon += PAIR_NCON[m->pair_fn[p]]; }
   int nlim = 0;
-  for (size_t j = 0; j < nj; j++) nlim += (m->jnt_limited[j] && (m->jnt_type[j] == JSLIDE || m->jnt_type[j] == JHINGE));
+  for (size_t j = 0; j < nj; j++) nlim += (m->jnt_limited[j] && (m->jnt_type[j] == JSLIDE || m->jnt_type[j] == JHINGE || m->jnt_type[j] == JBALL));
   int nfri = 0, neqrows = 0;
   for (size_t i = 0; i < nv; i++) nfri += m->dof_frictionloss[i] > 0;
   for (int e = 0; e < m->neq; e++) neqrows += m->eq_type[e] == 0 ? 3 : (m->eq_type[e] == 1 ? 6 : 1);
@@ -1024,6 +1025,30 @@ static void make_constraint(const amxo_model *m, amxo_data *d) {
   }
   d->nf = row - d->ne;
   if (!(m->disableflags & DIS_LIMIT)) {
+    /* ball joints [mjx:constraint._instantiate_limit_ball; MuJoCo engine_core_constraint.c mj_instantiateLimit, mjJNT_BALL]: the
+     * joint quaternion as axis * angle (angle wrapped to (-pi, pi], then made positive by flipping the axis), one row
+     * J = -axis on the joint's three dofs, pos = max(range) - angle - margin.  math.normalize_with_norm divides by
+     * n + 1e-6 (n == 0): a zero rotation gives a zero axis and angle 0 */
+    for (int j = 0; j < m->njnt; j++) {
+      if (!m->jnt_limited[j] || m->jnt_type[j] != JBALL) continue;
+      const REAL *q = d->qpos + m->jnt_qposadr[j];
+      REAL s = r_sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+      REAL inv = 1 / (s + (s == 0 ? (REAL)1e-6 : 0));
+      REAL ax[3] = {q[1] * inv, q[2] * inv, q[3] * inv};
+      REAL angle = 2 * r_atan2(s, q[0]);
+      if (angle > (REAL)3.14159265358979323846) angle -= 2 * (REAL)3.14159265358979323846;
+      REAL av[3] = {ax[0] * angle, ax[1] * angle, ax[2] * angle};
+      REAL n = r_sqrt(av[0] * av[0] + av[1] * av[1] + av[2] * av[2]);
+      REAL inv2 = 1 / (n + (n == 0 ? (REAL)1e-6 : 0));
+      REAL rmax = r_max(m->jnt_range[2 * j], m->jnt_range[2 * j + 1]);
+      REAL pos = rmax - n - m->jnt_margin[j];
+      if (!(pos < 0)) continue;
+      REAL *J = d->efc_J + row * nv;
+      memset(J, 0, sizeof(REAL) * nv);
+      for (int k = 0; k < 3; k++) J[m->jnt_dofadr[j] + k] = -av[k] * inv2;
+      finish_row(m, d, row, pos, m->dof_invweight0[m->jnt_dofadr[j]], m->jnt_solref + 2 * j, m->jnt_solimp + 5 * j);
+      row++;
+    }
     for (int j = 0; j < m->njnt; j++) {
       if (!m->jnt_limited[j] || (m->jnt_type[j] != JSLIDE && m->jnt_type[j] != JHINGE)) continue;
       REAL q = d->qpos[m->jnt_qposadr[j]];

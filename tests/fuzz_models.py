@@ -1,5 +1,5 @@
 """Random small MJCF models for the fuzz parity tests (seeded, deterministic): random kinematic trees with free / ball /
-hinge / slide joints, joint limits, damping, armature, springs, motors and position actuators, an optional joint
+hinge / slide joints, joint limits (ball joints included), damping, armature, springs, motors and position actuators, an optional joint
 equality, sphere / capsule geoms over a plane, random solver options.  Only features of the supported table are drawn."""
 import numpy as np
 
@@ -12,6 +12,7 @@ def _v(rng, lo, hi, n=3):
 
 def random_mjcf(seed: int) -> str:
     rng = np.random.default_rng(seed)
+    rng_b = np.random.default_rng(seed + 100003)  # ball-joint limits (r03)
     nbody = int(rng.integers(2, 9))
     solver = rng.choice(["Newton", "CG"], p=[0.8, 0.2])
     iters = int(rng.integers(1, 5)) if solver == "Newton" else int(rng.integers(4, 9))
@@ -56,6 +57,8 @@ def random_mjcf(seed: int) -> str:
                     scalar_joints.append(f"j{jid[0]}")
                 else:
                     at += f' damping="{rng.uniform(0, 0.2):.3f}"'
+                    if rng_b.random() < 0.5:  # (a generator of its own: the draws of the older features keep their stream)
+                        at += f' range="0 {rng_b.uniform(0.3, 1.2):.3f}"'
                 out.append(f"{ind}  <joint {at}/>")
                 jid[0] += 1
         nonlocal ngeom_budget

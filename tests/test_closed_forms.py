@@ -128,6 +128,79 @@ def test_limit_row_closed_form_gpu():
         assert f["nefc"] == 1
 
 
+LIMIT_BALL = """<mujoco><compiler angle="radian"/><option gravity="0 0 0" timestep="0.002" iterations="20" ls_iterations="20"/><worldbody>
+  <body><joint name="j" type="ball" limited="true" range="0 0.5"/>
+    <inertial pos="0 0 0" mass="1" diaginertia="0.02 0.02 0.02"/></body>
+</worldbody></mujoco>"""
+LIMIT_BALL_ARM = """<mujoco><compiler angle="radian"/><option timestep="0.002" iterations="10" ls_iterations="10"/><worldbody>
+  <body pos="0 0 1"><joint type="hinge" axis="0 1 0" damping="0.1"/><geom type="capsule" fromto="0 0 0 0.3 0 0" size="0.03" mass="1"/>
+    <body pos="0.3 0 0"><joint type="ball" limited="true" range="0 0.4" damping="0.02"/><geom type="capsule" fromto="0 0 0 0.05 0 -0.3" size="0.025" mass="0.6"/>
+      <body pos="0.05 0 -0.3"><joint type="hinge" axis="1 0 0" limited="true" range="-0.3 0.3"/><geom type="capsule" fromto="0 0 0 0 0 -0.2" size="0.02" mass="0.3"/></body>
+    </body></body>
+</worldbody></mujoco>"""
+# A ball joint turned by 0.6 rad about a = (1, 2, 2)/3 against a limit of 0.5 rad, isotropic inertia I about the joint, no gravity:
+# one row, J = -a on the three dofs (|J| = 1), pos = 0.5 - 0.6, diagApprox = dof_invweight0 = 1/I = J M^-1 J', so the hinge case's
+# algebra carries over: J qacc = imp * aref, qacc = -a * imp * aref: 250 at rest, 350 with the body-frame angular velocity 1 * a
+# (J v = -1; w x I w = 0 for an isotropic inertia).  Turned by 2 pi - 0.6 about a the rotation is -0.6 about a: the angle wraps,
+# the axis flips, and the limit pushes the other way round.
+_BA = np.array([1.0, 2.0, 2.0]) / 3.0
+LIMIT_BALL_CASES = [(0.6, 0.0, -250.0), (0.6, 1.0, -350.0), (2 * np.pi - 0.6, 0.0, 250.0)]
+
+
+def _ball_q(angle):
+    return np.concatenate([[np.cos(angle / 2)], np.sin(angle / 2) * _BA])
+
+
+def test_ball_limit_row_closed_form_oracle():
+    """SURVEY.md A9.6 / MJX _instantiate_limit_ball: the one-row case worked out above, and no row inside the range."""
+    from oracle.oracle import Oracle
+    mj = MjModel.from_xml_string(LIMIT_BALL)
+    assert mj.jnt_limited.tolist() == [1] and np.allclose(mj.dof_invweight0, 50.0)
+    for dt, tol in ((np.float64, 2e-6), (np.float32, 2e-5)):
+        o = Oracle(mj, dt)
+        for ang, w, want in LIMIT_BALL_CASES:
+            o.set_state(_ball_q(ang), w * _BA, np.zeros(0), np.zeros(3)); o.forward()
+            assert np.abs(o.get("qacc") - want * _BA).max() < tol * abs(want), (ang, w, o.get("qacc"), want * _BA)
+        o.set_state(_ball_q(0.45), np.zeros(3), np.zeros(0), np.zeros(3)); o.forward()
+        assert np.abs(o.get("qacc")).max() == 0.0
+
+
+@pytest.mark.gpu
+def test_ball_limit_row_closed_form_gpu():
+    """The same numbers from the HIP path (amx_forward), not through the oracle; then a three-link arm with a limited ball joint
+    in the middle, driven into the limit, against the fp64 oracle over a rollout."""
+    import torch
+    from test_gpu_kat import Gpu
+    from oracle.oracle import Oracle
+    dev = torch.device("cuda", 0)
+    g = Gpu(MjModel.from_xml_string(LIMIT_BALL), dev)
+    for ang, w, want in LIMIT_BALL_CASES:
+        f = g.forward(_ball_q(ang), w * _BA)
+        assert np.abs(f["qacc"] - want * _BA).max() < 2e-5 * abs(want), (ang, w, f["qacc"], want * _BA)
+        assert f["nefc"] == 1
+    f = g.forward(_ball_q(0.45), np.zeros(3))
+    assert f["nefc"] == 0 and np.abs(f["qacc"]).max() == 0.0
+    mj = MjModel.from_xml_string(LIMIT_BALL_ARM)
+    g = Gpu(mj, dev)
+    rng = np.random.default_rng(3)
+    nenv, steps = 16, 50
+    q = np.tile(mj.qpos0, (nenv, 1))
+    for k in range(nenv):
+        a = rng.standard_normal(3); a /= np.linalg.norm(a)
+        ang = rng.uniform(0.2, 0.6)                                                  # some inside the range, some beyond it
+        q[k, 1:5] = np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * a])
+        q[k, 0], q[k, 5] = rng.uniform(-0.5, 0.5), rng.uniform(-0.4, 0.4)
+    v = 0.5 * rng.standard_normal((nenv, mj.nv))
+    x0 = np.concatenate([q, v], axis=1).astype(np.float32)
+    us = np.zeros((nenv, steps, 0), dtype=np.float32)
+    xs = g.rollout(x0, us)
+    ref = Oracle(mj, np.float64).rollout(x0, us)
+    e1 = np.abs(xs[:, 1] - ref[:, 1]).max() / max(1.0, np.abs(ref[:, 1]).max())
+    eN = np.abs(xs[:, -1] - ref[:, -1]).max() / max(1.0, np.abs(ref[:, -1]).max())
+    print(f"ball-limit arm: 1-step err {e1:.2e}, {steps}-step err {eN:.2e}")
+    assert e1 < 1e-5 and eN < 1e-4 and np.isfinite(xs).all()
+
+
 FRICTION_HINGE = """<mujoco><option timestep="0.002" gravity="0 0 0" iterations="30" ls_iterations="30"/><worldbody>
   <body><joint name="h" type="hinge" axis="0 0 1" frictionloss="1.0"/><inertial pos="0 0 0" mass="1" diaginertia="0.05 0.05 0.05"/></body>
 </worldbody><actuator><motor joint="h" gear="1"/></actuator></mujoco>"""
