@@ -169,6 +169,14 @@ def build_specialised_library(mj, verbose: bool = False) -> Path:
         tmp = _unique_tmp(out)
         cmd = [hipcc] + FLAGS + [f'-DAMX_SPECS_HEADER="{hdr}"', "-DAMX_NO_GENERIC=1", "-no-hip-rt", "-shared", "-o", str(tmp), "-x", "hip", str(_CSRC / "amx_api.cpp")]
         r = subprocess.run(cmd, capture_output=True, text=True, cwd=str(_CSRC))
+        if r.returncode != 0 and "frontend command failed due to signal" in r.stderr:
+            # ROCm 7.2's register allocator has crashed on one plan's packed-fp32 spatial sums (r03: a 16-lane model with two free
+            # bodies); the same kernels with those sums as scalar instructions compile.  Same arithmetic, the same HIP path.
+            first = r.stderr
+            cmd = cmd[:1] + ["-DAMX_PK_SV=0", "-DAMX_PK_DOT=0"] + cmd[1:]
+            r = subprocess.run(cmd, capture_output=True, text=True, cwd=str(_CSRC))
+            if r.returncode != 0:
+                r.stderr = first[-1000:] + "\n--- retry without packed fp32 ---\n" + r.stderr
         if r.returncode != 0:
             try:
                 tmp.unlink()

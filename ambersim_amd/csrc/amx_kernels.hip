@@ -1613,6 +1613,7 @@ struct Env {
   //   2. level scan from depth 2 down: world pose = parent's world pose o local pose (one quaternion product, one
   //      rotation); depth-1 bodies hang off the world, whose pose is the identity, and are already final;
   //   3. every joint in parallel: anchor and axis taken to the world frame by the parent body's pose.
+  static constexpr int KIN_MJ = 2;  // joints per body whose anchors / axes ride in registers through the pose composition
   DEV void kinematics() {
     const int b = gl;
     if (gl == 0) {
@@ -1622,14 +1623,18 @@ struct Env {
     // Bodies with at most one joint each (max_jntnum <= 1: every shipped model): the joint's anchor and axis in the parent's frame
     // stay in the body lane's registers and are taken to the world frame in pass 2, where the parent's world pose is at hand -
     // pass 3 (per joint: body -> parent -> pose, three dependent LDS round trips, and another quaternion-to-matrix) is skipped.
-    const bool fuse3 = m.max_jntnum() <= 1;
-    f3 anc_l = mk3(0, 0, 0), ax_l = mk3(0, 0, 1);
-    int jd0 = 0;
+    // (r03: also bodies with two joints - the biped's hips and ankles: a second anchor / axis pair in registers, the joint loop
+    // unrolled with a predicate so that both joints' constants and positions are fetched together)
+    const bool fuse3 = m.max_jntnum() <= KIN_MJ;
+    f3 anc_l[KIN_MJ], ax_l[KIN_MJ];
+    int jd0[KIN_MJ];
+#pragma unroll
+    for (int k = 0; k < KIN_MJ; ++k) { anc_l[k] = mk3(0, 0, 0); ax_l[k] = mk3(0, 0, 1); jd0[k] = 0; }
     if (b > 0 && b < m.nb()) {
       const int br = m.c_body() + b * BODY_S;
       f3 pos = mk3(CF(br + 7), CF(br + 8), CF(br + 9));
       f4 quat = {CF(br + 10), CF(br + 11), CF(br + 12), CF(br + 13)};
-      for (int k = 0; k < b_jntnum; ++k) {
+      auto one_joint = [&](int k, f3 &anc_o, f3 &ax_o, int &jd_o) {
         const int j = b_jntadr + k, jr = m.c_jnt() + j * JNT_S;
         const int t_ = CI(jr), qa = eb + m.e_qpos() + CI(jr + 1), jd = CI(jr + 2);
         const f3 jpos = mk3(CF(jr + 4), CF(jr + 5), CF(jr + 6)), jax = mk3(CF(jr + 7), CF(jr + 8), CF(jr + 9));
@@ -1658,17 +1663,24 @@ struct Env {
             pos = pos + axis * (lds[qa] - CF(jr + 10));
           }
         }
-        anc_l = anchor; ax_l = axis; jd0 = jd;
+        anc_o = anchor; ax_o = axis; jd_o = jd;
         if (!fuse3 || b_level < 2) {  // final for bodies hanging off the world; local values for pass 3 otherwise
           jnt(0, jd) = anchor.x; jnt(1, jd) = anchor.y; jnt(2, jd) = anchor.z;
           jnt(3, jd) = axis.x; jnt(4, jd) = axis.y; jnt(5, jd) = axis.z;
         }
+      };
+      if (fuse3) {
+#pragma unroll
+        for (int k = 0; k < KIN_MJ; ++k) if (k < b_jntnum) one_joint(k, anc_l[k], ax_l[k], jd0[k]);
+      } else {
+        for (int k = 0; k < b_jntnum; ++k) { f3 a_, x_; int d_; one_joint(k, a_, x_, d_); }
       }
       body(0, b) = pos.x; body(1, b) = pos.y; body(2, b) = pos.z;
       body(3, b) = quat.w; body(4, b) = quat.x; body(5, b) = quat.y; body(6, b) = quat.z;
     }
     WSYNC();
-    const bool jfuse = fuse3 && b > 0 && b < m.nb() && b_level >= 2 && b_jntnum == 1;
+    PROF(28);
+    const bool jfuse = fuse3 && b > 0 && b < m.nb() && b_level >= 2 && b_jntnum >= 1;
     if (m.nlevel() > AMX_CHAIN_WALK_MIN_LEVELS && !m.deep_free() && !AMX_LEVEL_SCANS) {  // shallow trees: the level scan is as fast (quadruped, 5 levels: measured)
       // every body walks its own ancestor chain (root first, constants c_anc) and composes the local poses in registers: the
       // same products in the same order as the level-by-level scan, but the loads are independent and nothing waits for a
@@ -1690,16 +1702,20 @@ struct Env {
       const m33 Rp = q2m(aq);  // (ap, aq) is the parent's world pose
       const f3 pos = ap + mulv(Rp, lp);
       const f4 quat = qmul(aq, lq);
-      const f3 anchor = ap + mulv(Rp, anc_l), axis = mulv(Rp, ax_l);
+      f3 anchor[KIN_MJ], axis[KIN_MJ];
+#pragma unroll
+      for (int k = 0; k < KIN_MJ; ++k) { anchor[k] = ap + mulv(Rp, anc_l[k]); axis[k] = mulv(Rp, ax_l[k]); }
       WSYNC();
       if (deep) {
         body(0, b) = pos.x; body(1, b) = pos.y; body(2, b) = pos.z;
         body(3, b) = quat.w; body(4, b) = quat.x; body(5, b) = quat.y; body(6, b) = quat.z;
       }
-      if (jfuse) {
-        jnt(0, jd0) = anchor.x; jnt(1, jd0) = anchor.y; jnt(2, jd0) = anchor.z;
-        jnt(3, jd0) = axis.x; jnt(4, jd0) = axis.y; jnt(5, jd0) = axis.z;
-      }
+#pragma unroll
+      for (int k = 0; k < KIN_MJ; ++k)
+        if (jfuse && k < b_jntnum && (k == 0 || m.max_jntnum() > 1)) {
+          jnt(0, jd0[k]) = anchor[k].x; jnt(1, jd0[k]) = anchor[k].y; jnt(2, jd0[k]) = anchor[k].z;
+          jnt(3, jd0[k]) = axis[k].x; jnt(4, jd0[k]) = axis[k].y; jnt(5, jd0[k]) = axis[k].z;
+        }
       WSYNC();
     } else
     for (int L = 2; L < m.nlevel(); ++L) {
@@ -1711,14 +1727,17 @@ struct Env {
         const f4 quat = qmul(pq, ld_xquat(b));
         body(0, b) = pos.x; body(1, b) = pos.y; body(2, b) = pos.z;
         body(3, b) = quat.w; body(4, b) = quat.x; body(5, b) = quat.y; body(6, b) = quat.z;
-        if (jfuse) {
-          const f3 anchor = pp + mulv(Rp, anc_l), axis = mulv(Rp, ax_l);
-          jnt(0, jd0) = anchor.x; jnt(1, jd0) = anchor.y; jnt(2, jd0) = anchor.z;
-          jnt(3, jd0) = axis.x; jnt(4, jd0) = axis.y; jnt(5, jd0) = axis.z;
-        }
+#pragma unroll
+        for (int k = 0; k < KIN_MJ; ++k)
+          if (jfuse && k < b_jntnum && (k == 0 || m.max_jntnum() > 1)) {
+            const f3 anchor = pp + mulv(Rp, anc_l[k]), axis = mulv(Rp, ax_l[k]);
+            jnt(0, jd0[k]) = anchor.x; jnt(1, jd0[k]) = anchor.y; jnt(2, jd0[k]) = anchor.z;
+            jnt(3, jd0[k]) = axis.x; jnt(4, jd0[k]) = axis.y; jnt(5, jd0[k]) = axis.z;
+          }
       }
       WSYNC();
     }
+    PROF(29);
     if (!fuse3 && gl < m.njnt()) {
       const int jr = m.c_jnt() + gl * JNT_S, jd = CI(jr + 2);
       const int p = CI(m.c_body() + CI(jr + 3) * BODY_S);  // parent of the joint's body
@@ -1762,6 +1781,7 @@ struct Env {
       }
     }
     WSYNC();
+    PROF(31);
     if (b < nb) {
       float r[10];
       if (b == 0) {
@@ -1926,42 +1946,36 @@ struct Env {
     sv vJ = {{0, 0, 0, 0, 0, 0}}, w = {{0, 0, 0, 0, 0, 0}}, loc = {{0, 0, 0, 0, 0, 0}};
     sv cv_own = {{0, 0, 0, 0, 0, 0}}, ca_own = {{0, 0, 0, 0, 0, 0}};
     bool own_in_regs = false;
-    if (b > 0 && b < m.nb()) {
-      for (int k = 0; k < b_jntnum; ++k) {
-        const int jr = m.c_jnt() + (b_jntadr + k) * JNT_S, t_ = CI(jr), da = CI(jr + 2);
-        if (t_ == JFREE) {
+    {
+      // Joint sums by dof group (c_bgrp), without branches: every group fetches three dofs (a one-dof group fetches its dof three
+      // times and weights two of them by zero; lanes without a body and groups a body does not have weigh everything by zero), so
+      // all the loads of all the groups are in flight together.  MJX's cdof_dot of a dof is (velocity before the group) x cdof,
+      // summed with the dof's qvel: by bilinearity one cross product with the group's sum.  The free joint's translations add
+      // to the velocity only (their cdof_dot is zero and they are not part of w).
+      const bool isb = b > 0 && b < m.nb();
+      auto one_group = [&](int g) {
+        const int gi = isb ? CI(m.c_bgrp() + b * m.max_bgrp() + g) : 0;
+        const int st = gi & 255, n = (gi >> 8) & 3;
+        const float cf = (gi >> 12) & 1 ? 1.0f : 0.0f;
+        const sv c0 = ld_dsv(D_CDOF, st), c1 = ld_dsv(D_CDOF, st + (n > 1 ? 1 : 0)), c2 = ld_dsv(D_CDOF, st + (n > 2 ? 2 : 0));
+        const float q0_ = lds[qv + st], q1_ = lds[qv + st + (n > 1 ? 1 : 0)], q2_ = lds[qv + st + (n > 2 ? 2 : 0)];
+        const float q0 = n > 0 ? q0_ : 0.0f, q1 = n > 1 ? q1_ : 0.0f, q2 = n > 2 ? q2_ : 0.0f;
+        sv add = {{0, 0, 0, 0, 0, 0}};
 #pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            const sv c = ld_dsv(D_CDOF, da + i);
-            const float q = lds[qv + da + i];
+        for (int e = 0; e < 6; ++e) add.v[e] = __builtin_fmaf(c2.v[e], q2, __builtin_fmaf(c1.v[e], q1, c0.v[e] * q0));
+        const sv cd = motion_cross(vJ, add);
 #pragma unroll
-            for (int e = 0; e < 1; ++e) sv_axpy(vJ, c, q);
-          }
-          const sv c3 = ld_dsv(D_CDOF, da + 3), c4 = ld_dsv(D_CDOF, da + 4), c5 = ld_dsv(D_CDOF, da + 5);
-          const sv cd3 = motion_cross(vJ, c3), cd4 = motion_cross(vJ, c4), cd5 = motion_cross(vJ, c5);
-          const float q3 = lds[qv + da + 3], q4 = lds[qv + da + 4], q5 = lds[qv + da + 5];
+        for (int e = 0; e < 6; ++e) { loc.v[e] = __builtin_fmaf(cd.v[e], cf, loc.v[e]); w.v[e] = __builtin_fmaf(add.v[e], cf, w.v[e]); }
+        sv_acc(vJ, add);
+      };
+      if constexpr (S::is_static) {
 #pragma unroll
-          for (int e = 0; e < 6; ++e) {
-            const float add = c3.v[e] * q3 + c4.v[e] * q4 + c5.v[e] * q5;
-            loc.v[e] += cd3.v[e] * q3 + cd4.v[e] * q4 + cd5.v[e] * q5;
-            w.v[e] += add;
-            vJ.v[e] += add;
-          }
-        } else {
-          const int n = t_ == JBALL ? 3 : 1;
-          sv add = {{0, 0, 0, 0, 0, 0}};
-          for (int i = 0; i < n; ++i) {
-            const sv c = ld_dsv(D_CDOF, da + i);
-            const sv cd = motion_cross(vJ, c);
-            const float q = lds[qv + da + i];
-#pragma unroll
-            for (int e = 0; e < 1; ++e) { sv_axpy(loc, cd, q); sv_axpy(add, c, q); }
-          }
-#pragma unroll
-          for (int e = 0; e < 1; ++e) { sv_acc(vJ, add); sv_acc(w, add); }
-        }
+        for (int g = 0; g < 4; ++g) if (g < S::max_bgrp) one_group(g);
+      } else {
+        for (int g = 0; g < m.max_bgrp(); ++g) one_group(g);
       }
     }
+    PROF(30);
     if (!m.deep_free() && m.nlevel() > AMX_CHAIN_WALK_MIN_LEVELS && !AMX_LEVEL_SCANS) {
       // The same chain walk as in kinematics(): every body stores its own joint sums (vJ, loc), then accumulates them along its
       // ancestor chain in registers - cvel and cacc of every ancestor are recomputed in the lane, in the order the level scan

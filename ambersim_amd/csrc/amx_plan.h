@@ -479,6 +479,22 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
       for (size_t k = 0; k < chain.size(); k++) anc[(size_t)b * w + k] = chain[chain.size() - 1 - k];
     }
     m.c_anc = add_ints(anc);
+    // dof groups of every body for the velocity pass: a free joint is two groups (translations, rotations), every other joint
+    // one (ball: 3 dofs, hinge / slide: 1).  Within a group the velocity the cdof_dot cross product is taken with is the same
+    // for every dof, and the cross product is bilinear: one product with the group's sum (velocity_and_bias)
+    std::vector<std::vector<int>> grp(nb);
+    m.max_bgrp = 1;
+    for (int b = 1; b < nb; b++) {
+      for (int k = 0; k < d->body_jntnum[b]; k++) {
+        const int j = d->body_jntadr[b] + k, t = d->jnt_type[j], da = d->jnt_dofadr[j];
+        if (t == 0) { grp[b].push_back(da | (3 << 8)); grp[b].push_back((da + 3) | (3 << 8) | (1 << 12)); }
+        else grp[b].push_back(da | ((t == 1 ? 3 : 1) << 8) | (1 << 12));
+      }
+      m.max_bgrp = std::max(m.max_bgrp, (int)grp[b].size());
+    }
+    std::vector<int> bgrp((size_t)nb * m.max_bgrp, 0);
+    for (int b = 1; b < nb; b++) for (size_t g = 0; g < grp[b].size(); g++) bgrp[(size_t)b * m.max_bgrp + g] = grp[b][g];
+    m.c_bgrp = add_ints(bgrp);
     m.deep_free = 0;
     for (int j = 0; j < nj; j++) if (d->jnt_type[j] == 0 && depth[d->jnt_bodyid[j]] > 1) m.deep_free = 1;
     if (force_level) m.deep_free = 1;

@@ -15,7 +15,8 @@ from bench import make_inputs
 NAMES = {0: "step head/ctrl", 1: "kinematics", 2: "com_pos+cinert+cdof", 3: "crb+M", 4: "collision", 5: "make_constraint",
          6: "com_vel+rne", 7: "smooth forces", 8: "factor M + qacc_smooth", 9: "solver init (warm/smooth cost)",
          10: "constraint force+grad", 11: "newton: chol H + solve", 12: "iter cond", 13: "linesearch", 14: "newton: assemble H",
-         15: "solve tail", 16: "euler: damp solve", 17: "euler: integrate", 18: "write xs row", 19: "  H: copy M", 20: "  crb: subtree up-scan", 21: "  ls: Mv, Jv, gauss sums", 22: "  ls: bracketing loop", 23: "  vel: joint sums + down-scan", 24: "  newton: before the matrix cores", 25: "  newton: J'DJ on the matrix cores", 26: "  newton: row assembly", 27: "  newton: elimination"}
+         15: "solve tail", 16: "euler: damp solve", 17: "euler: integrate", 18: "write xs row", 19: "  H: copy M", 20: "  crb: subtree up-scan", 21: "  ls: Mv, Jv, gauss sums", 22: "  ls: bracketing loop", 23: "  vel: joint sums + down-scan", 24: "  newton: before the matrix cores", 25: "  newton: J'DJ on the matrix cores", 26: "  newton: row assembly", 27: "  newton: elimination",
+         28: "  kin: joints to local poses", 29: "  kin: pose composition", 30: "  vel: joint sums", 31: "  com: tree COM"}
 
 model_path = sys.argv[1] if len(sys.argv) > 1 else "models/quadruped/quadruped.xml"
 nenv = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
