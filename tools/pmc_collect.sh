@@ -5,6 +5,7 @@
 TAG=${1:-biped}; shift  # bench.py's default workload is the biped; quadruped: bash tools/pmc_collect.sh quadruped --model models/quadruped/quadruped.xml
 REPO=$(pwd)
 export TMPDIR=/tmp
+mkdir -p $REPO/gpurun_out/pmc_$TAG
 cd /tmp
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" \
