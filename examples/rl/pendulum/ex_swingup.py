@@ -1,5 +1,5 @@
 """Pendulum swing-up with PPO on the HIP physics path (counterpart of reference examples/rl/pendulum/ex_swingup.py,
-same hyper-parameters; no viewer).  Run on an MI355X box: python examples/rl/pendulum/ex_swingup.py [num_timesteps]"""
+same hyper-parameters; no viewer).  Run on an MI355X box: python examples/rl/pendulum/ex_swingup.py [num_timesteps [seed]]"""
 import functools
 import os
 import sys
@@ -35,7 +35,7 @@ if __name__ == "__main__":
         num_envs=num_envs,
         batch_size=512,
         network_factory=network_factory,
-        seed=0,
+        seed=int(sys.argv[2]) if len(sys.argv) > 2 else 0,
     )
     times = [datetime.now()]
 
