@@ -145,12 +145,13 @@ def test_forward_outputs(cases, golden, name):
         assert rel(d.xquat[e].cpu().numpy().ravel(), o.get("xquat")) < TOL
         assert rel(qM[e].cpu().numpy().ravel(), o.get("qM")) < TOL
         assert rel(d.qfrc_bias[e].cpu().numpy(), o.get("qfrc_bias")) < TOL
-        assert rel(d.qacc_smooth[e].cpu().numpy(), o.get("qacc_smooth")) < 2e-5
-        assert rel(d.qacc[e].cpu().numpy(), o.get("qacc")) < 1e-4  # solver output: conditioning of H amplifies fp32 rounding
+        assert rel(d.qacc_smooth[e].cpu().numpy(), o.get("qacc_smooth")) < 1e-5, rel(d.qacc_smooth[e].cpu().numpy(), o.get("qacc_smooth"))
+        # solver outputs: 2e-5 (r02: 1e-4; the conditioning of H amplifies fp32 rounding - measured worst 1.3e-5 on the Barrett hand)
+        assert rel(d.qacc[e].cpu().numpy(), o.get("qacc")) < 2e-5, rel(d.qacc[e].cpu().numpy(), o.get("qacc"))
         assert int(nefc[e]) == int(o.get("nefc")[0])
         # J' * efc_force: the same conditioning as qacc (it is M (qacc - qacc_smooth))
         fc, fc_ref = d.qfrc_constraint[e].cpu().numpy(), o.get("qfrc_constraint")
-        assert np.abs(fc - fc_ref).max() < 1e-4 * max(1.0, np.abs(fc_ref).max())
+        assert np.abs(fc - fc_ref).max() < 2e-5 * max(1.0, np.abs(fc_ref).max()), np.abs(fc - fc_ref).max() / max(1.0, np.abs(fc_ref).max())
         if model.ncon:
             # signed contact distances: the same contacts are active and their depths agree.  (Inactive slots may differ: with
             # every hull vertex above the plane all manifold scores carry the -1e6 mask, which swallows the distances in fp32
