@@ -34,12 +34,12 @@ enum { CX_MAXV = 32, CX_MAXP = 16, CX_VA = 0, CX_VB = 96, CX_POLY = 192, CX_SCRA
 // ActRec : 0 qadr 1 dadr 2 flags(1 ctrllimited,2 forcelimited,4 affine bias) 3 gear 4 gain 5-7 bias 8-9 ctrlrange 10-11 forcerange 12 pad
 // GeomRec: 0 body 1 type 2-4 pos 5-8 quat 9-11 size 12 pad
 // PairRec: 0 g1 1 g2 2 fn 3 conadr 4 ncon 5 vertadr 6 vertnum 7 root1 8 root2 9 dofadr 10 dofnum 11 mu 12 k 13 b 14 dmin 15 dmax
-//          16 width 17 mid 18 power 19 ca 20 cb 21 margin 22 invw 23 hadr 24 hnum 25 hull record of geom1 26 of geom2 (fn 6) 27-32 pad
+//          16 1/width 17 mid 18 power 19 ca 20 cb 21 margin 22 invw 23 hadr 24 hnum 25 hull record of geom1 26 of geom2 (fn 6) 27-32 pad
 //          fn 8 / 9 (rows of a connect / weld equality, carried as pseudo-pairs): 0 body1 1 body2 5 weld? 11 torquescale 22 invweight0 sum
 //          (8: translational, 9: rotational) 23-25 point in body1's frame 26-28 point in body2's frame 29-32 relpose quaternion
 // HullRec: 0 nvert 1 vertices [nvert][3] 2 nface 3 face normals [nface][3] 4 face polygons [nface][9] (count, 8 vertex ids) 5 nedge 6 edges [nedge][2]
-// LimRec : 0 qadr 1 dadr 2 range0 3 range1 4 margin 5 k 6 b 7 dmin 8 dmax 9 width 10 mid 11 power 12 ca 13 cb 14 invw
-// EqRec  : 0 q1 1 d1 2 q2 3 d2 4-8 polycoef 9 k 10 b 11 dmin 12 dmax 13 width 14 mid 15 power 16 ca 17 cb 18 invw 19 qref1 20 qref2
+// LimRec : 0 qadr 1 dadr 2 range0 3 range1 4 margin 5 k 6 b 7 dmin 8 dmax 9 1/width 10 mid 11 power 12 ca 13 cb 14 invw
+// EqRec  : 0 q1 1 d1 2 q2 3 d2 4-8 polycoef 9 k 10 b 11 dmin 12 dmax 13 1/width 14 mid 15 power 16 ca 17 cb 18 invw 19 qref1 20 qref2
 
 // Everything the kernel needs besides the constant image: sizes, options, and a few base offsets.
 // The integer fields are listed ONCE, here: DevModel, the model-view accessors (amx_kernels.hip: MV<S>), the plan dump that

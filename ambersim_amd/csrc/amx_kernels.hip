@@ -144,10 +144,43 @@ DEV float fdiv(float x, float y) {
   return __builtin_fmaf(__builtin_fmaf(-y, q, x), r, q);
 #endif
 }
+// x / y for the line search's Newton steps on the derivative (alpha - d0 / d1): reciprocal and one multiply, 1.5 ulp.  The
+// quotient only places the next trial point; every decision is taken on derivatives evaluated AT the trial points, so the last
+// bit of a trial point's position is immaterial (AMX_LS_FASTDIV=0: the corrected quotient above)
+#ifndef AMX_LS_FASTDIV
+#define AMX_LS_FASTDIV 1
+#endif
+DEV float fdiv_ls(float x, float y) {
+#if AMX_LS_FASTDIV
+  return x * __builtin_amdgcn_rcpf(y);
+#else
+  return fdiv(x, y);
+#endif
+}
+// Unit vector where only the direction is used (the contact frame's axes): one v_rsq_f32 (1 ulp) instead of the correctly rounded
+// square root (a ten-instruction expansion) and a corrected reciprocal.  normalize3 below keeps both: its length is a contact distance.
+#ifndef AMX_FAST_NORM
+#define AMX_FAST_NORM 1  // 0: correctly rounded square root and corrected reciprocal in the normalisations (A/B switch)
+#endif
+DEV float inv_norm(float n2) {
+#if AMX_FAST_NORM
+  return __builtin_amdgcn_rsqf(n2);
+#else
+  return fdiv(1.0f, sqrtf(n2));
+#endif
+}
+// (the joint quaternions keep the correctly rounded form: a body's orientation places its contact points, and one ulp of a unit
+// quaternion is 6e-8 m per metre of lever arm against penetrations of 1e-4 .. 1e-3 m - measured on the sphere-box draw of
+// tests/test_convex.py: 4.9e-6 -> 1.05e-5 after one step with v_rsq_f32 here)
 DEV f4 qnormalize(f4 q) {
   float n = sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
   if (n > 0) { float s = fdiv(1.0f, n); q.w *= s; q.x *= s; q.y *= s; q.z *= s; }
   return q;
+}
+DEV f3 unit3(f3 v) {
+  const float n2 = dot(v, v);
+  const float s = n2 > 0 ? inv_norm(n2) : 1.0f;
+  return mk3(v.x * s, v.y * s, v.z * s);
 }
 DEV f3 normalize3(f3 v, float *len) {
   float n = sqrtf(dot(v, v));
@@ -179,11 +212,10 @@ DEV f4 axisangle(f3 axis, float ang) {
   return r;
 }
 DEV void make_frame(f3 n, float *fr) {  // rows a, b, a x b
-  float len;
-  f3 a = normalize3(n, &len);
+  f3 a = unit3(n);
   f3 b = (a.y > -0.5f && a.y < 0.5f) ? mk3(0, 1, 0) : mk3(0, 0, 1);
   b = b - a * dot(a, b);
-  b = normalize3(b, &len);
+  b = unit3(b);
   f3 c = cross(a, b);
   fr[0] = a.x; fr[1] = a.y; fr[2] = a.z; fr[3] = b.x; fr[4] = b.y; fr[5] = b.z; fr[6] = c.x; fr[7] = c.y; fr[8] = c.z;
 }
@@ -1008,7 +1040,8 @@ AMX_STATIC_SOLVE_ATTR bool newton_solve_fused(int M_off, int ld_, int n_, unsign
       if (owner && store_ok) { lds[fcon_off + gl * DOF_E] = fcon; lds[rhs_off + gl * DOF_E] = b; }
       if (early_out) {
         const float gn = gsum<G>(owner ? b * b : 0.0f);
-        const bool done = imp_done | (fdiv(sqrtf(gn), scale) < tol);  // `|`, `&`: no exec-mask branches (see linesearch)
+        const float ts_ = scale * tol;  // |grad| / scale < tol, squared: no square root, no division
+        const bool done = imp_done | (gn < ts_ * ts_);  // `|`, `&`: no exec-mask branches (see linesearch)
         if (group_done) *group_done = done;  // the caller's next iteration starts with this very test: it need not re-read the gradient
         if (!wave_any(store_ok & !done)) {  // store_ok is the group's `alive`
           if (owner) lds[dg] = d0;
@@ -1122,10 +1155,10 @@ __device__ __noinline__ void chol_solve(int nchol, int A_off, int ld, int n, int
   else chol_solve_rows<(G >= 32 ? 32 : 12), G>(A_off, ld, n, L_off, rhs_off, x_off, vstride, factor, gl, gb4);
 }
 
-// impedance of one constraint row [A9.6]; k and b are folded on the host, rec points at {k,b,dmin,dmax,width,mid,power,ca,cb}
+// impedance of one constraint row [A9.6]; k and b are folded on the host, rec points at {k,b,dmin,dmax,1/width,mid,power,ca,cb}
 DEV float row_impedance(int rec, float pos) {
-  const float dmin = CF(rec + 2), dmax = CF(rec + 3), width = CF(rec + 4), mid = CF(rec + 5), power = CF(rec + 6);
-  const float x = fdiv(fabsf(pos), width);
+  const float dmin = CF(rec + 2), dmax = CF(rec + 3), inv_width = CF(rec + 4), mid = CF(rec + 5), power = CF(rec + 6);
+  const float x = fabsf(pos) * inv_width;
   float ia, ib;
   if (power == 2.0f) { ia = CF(rec + 7) * (x * x); ib = 1.0f - CF(rec + 8) * ((1 - x) * (1 - x)); }
   else { ia = CF(rec + 7) * powf(x, power); ib = 1.0f - CF(rec + 8) * powf(1 - x, power); }
@@ -2438,8 +2471,7 @@ struct Env {
       }
       if (active) {
         const float imp = row_impedance(rec, pos);
-        const float rr = fmaxf(fdiv(invw * (1 - imp), imp), MINVAL);
-        dd = fdiv(1.0f, rr);
+        dd = fdiv(imp, fmaxf(invw * (1 - imp), MINVAL * imp));  // 1 / max(invw (1 - imp) / imp, MINVAL) with one division
         ar = -CF(rec + 1) * jv - CF(rec) * imp * pos;
       }
     }
@@ -2456,8 +2488,7 @@ struct Env {
       const float jv = chain_dot(Jo + cr * ldc);
       if (con_on && k == 0 && pos < 0 && !(m.disableflags() & DIS_LIMIT)) {
         const float imp = row_impedance(rec, pos);
-        const float rr = fmaxf(fdiv(invw * (1 - imp), imp), MINVAL);
-        dd = fdiv(1.0f, rr);
+        dd = fdiv(imp, fmaxf(invw * (1 - imp), MINVAL * imp));  // 1 / max(invw (1 - imp) / imp, MINVAL) with one division
         ar = -CF(rec + 1) * jv - CF(rec) * imp * pos;
       }
     } else
@@ -2469,8 +2500,7 @@ struct Env {
       const float jv = chain_dot(Jo + cr * ldc);
       if (con_on && k < 3 && !(m.disableflags() & DIS_EQUALITY)) {
         const float imp = row_impedance(rec, nrm);
-        const float rr = fmaxf(fdiv(invw * (1 - imp), imp), MINVAL);
-        dd = fdiv(1.0f, rr);
+        dd = fdiv(imp, fmaxf(invw * (1 - imp), MINVAL * imp));  // 1 / max(invw (1 - imp) / imp, MINVAL) with one division
         ar = -CF(rec + 1) * jv - CF(rec) * imp * pos;
       }
     } else
@@ -2479,15 +2509,12 @@ struct Env {
       const int pr = CI(m.c_conpair() + c), prec = m.c_pair() + pr * PAIR_S;
       const float margin = CF(prec + 21), dist = con(0, c);
       const float pos = dist - margin;
-      const float mu = CF(prec + 11), tw = CF(prec + 22);
-      const float f = (k & 1) ? -mu : mu;
-      const float invw = fdiv((tw + f * f * tw) * 2 * f * f, m.impratio());
+      const float invw = CF(prec + 22);  // (tw + mu^2 tw) 2 mu^2 / impratio, folded by the planner
       const float jv = chain_dot(Jo + cr * ldc);  // qvel was staged with the Jacobian entries above
       if (dist < margin) {
         const int rec = prec + 12;
         const float imp = row_impedance(rec, pos);
-        const float rr = fmaxf(fdiv(invw * (1 - imp), imp), MINVAL);
-        dd = fdiv(1.0f, rr);
+        dd = fdiv(imp, fmaxf(invw * (1 - imp), MINVAL * imp));  // 1 / max(invw (1 - imp) / imp, MINVAL) with one division
         ar = -CF(rec + 1) * jv - CF(rec) * imp * pos;
       }
     }
@@ -2856,11 +2883,11 @@ struct Env {
       p0d = ls_derivs(0.0f, q1, q2);
     }
     PROF(21);
-    const float gtol = m.tolerance() * m.ls_tolerance() * sqrtf(sn) * m.scale();
+    const float gtol = m.tolerance() * m.ls_tolerance() * __builtin_amdgcn_sqrtf(sn) * m.scale();  // a threshold: 1 ulp is plenty
 #define PICK(c, a, b) { (c) ? (a).alpha : (b).alpha, (c) ? (a).d0 : (b).d0, (c) ? (a).d1 : (b).d1 }
     LSD p1;
     {
-      const float a1 = p0d.alpha - fdiv(p0d.d0, p0d.d1);
+      const float a1 = p0d.alpha - fdiv_ls(p0d.d0, p0d.d1);
       const LSTerms t = ls_terms(a1, validA, validB, iseq);
       const float r = gsum_pack2<G>(t.q1, t.q2);
       p1 = ls_derivs(a1, quad_value<0>(r) + g1, quad_value<1>(r) + g2);
@@ -2875,7 +2902,7 @@ struct Env {
       // comparisons of values already in registers, so there is nothing to skip
       const bool done = !swap | ((lo.d0 < 0) & (lo.d0 > -gtol)) | ((hi.d0 > 0) & (hi.d0 < gtol));
       if (!wave_any(!done & alive)) return false;
-      const float a_lo = lo.alpha - fdiv(lo.d0, lo.d1), a_hi = hi.alpha - fdiv(hi.d0, hi.d1), a_mid = 0.5f * (lo.alpha + hi.alpha);
+      const float a_lo = lo.alpha - fdiv_ls(lo.d0, lo.d1), a_hi = hi.alpha - fdiv_ls(hi.d0, hi.d1), a_mid = 0.5f * (lo.alpha + hi.alpha);
       const LSTerms t_lo = ls_terms(a_lo, validA, validB, iseq), t_hi = ls_terms(a_hi, validA, validB, iseq), t_mid = ls_terms(a_mid, validA, validB, iseq);
       float u, w;
       gsum_pack6<G>(t_lo.q1, t_lo.q2, t_hi.q1, t_hi.q2, t_mid.q1, t_mid.q2, u, w);
@@ -2994,7 +3021,8 @@ struct Env {
           const float g_ = dof(D_GRAD, gl < nv ? gl : 0);
           const float g = gl < nv ? g_ : 0.0f;
           const float gn = gsum<G>(g * g);
-          done = (fdiv(improvement, m.scale()) < m.tolerance()) | (fdiv(sqrtf(gn), m.scale()) < m.tolerance());
+          const float ts_ = m.scale() * m.tolerance();  // the reference's improvement / scale < tol and |grad| / scale < tol, multiplied out
+          done = (improvement < ts_) | (gn < ts_ * ts_);
         }
         alive = alive & !done;
       }
@@ -3016,7 +3044,7 @@ struct Env {
         if (niter + 1 < m.iterations()) {
           // the next iteration's stopping test needs this point's improvement (known) and gradient (formed inside the fused
           // solve): evaluated there, it saves the elimination when the wave is finished
-          const bool imp_done = fdiv(improvement, m.scale()) < m.tolerance();
+          const bool imp_done = improvement < m.scale() * m.tolerance();
           stop = newton_direction(alive, m.iterations() != 1, imp_done, &next_done);
           have_next = m.iterations() != 1;
           PROF(11);

@@ -49,7 +49,7 @@ void write_kbi(Image &im, int off, const double *solref, const double *solimp, d
   double k = 1.0 / (dmax * dmax * timeconst * timeconst * dampratio * dampratio), b = 2.0 / (dmax * timeconst);
   if (solref[0] <= 0) k = -solref[0] / (dmax * dmax);
   if (solref[1] <= 0) b = -solref[1] / dmax;
-  im.setf(off, k); im.setf(off + 1, b); im.setf(off + 2, dmin); im.setf(off + 3, dmax); im.setf(off + 4, width);
+  im.setf(off, k); im.setf(off + 1, b); im.setf(off + 2, dmin); im.setf(off + 3, dmax); im.setf(off + 4, 1.0 / width);  // the kernel multiplies
   im.setf(off + 5, mid); im.setf(off + 6, power);
   im.setf(off + 7, 1.0 / pow(mid, power - 1)); im.setf(off + 8, 1.0 / pow(1 - mid, power - 1));
 }
@@ -345,7 +345,11 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
     im.setf(o + 11, d->pair_friction[3 * p]);
     write_kbi(im, o + 12, d->pair_solref + 2 * p, d->pair_solimp + 5 * p, d->timestep, refsafe);
     im.setf(o + 21, d->pair_margin[p]);
-    im.setf(o + 22, d->body_invweight0[2 * b1] + d->body_invweight0[2 * b2]);
+    {
+      // the pyramid rows' diagApprox, the same for all four rows of a contact (f = +-mu enters squared): folded here in double
+      const double tw = d->body_invweight0[2 * b1] + d->body_invweight0[2 * b2], mu = d->pair_friction[3 * p];
+      im.setf(o + 22, (tw + mu * mu * tw) * 2 * mu * mu / d->impratio);
+    }
     }
     // union of the ancestor dof chains of both bodies (a ball limit: the joint's own three dofs)
     std::vector<int> sign(nv, 0);
