@@ -46,6 +46,12 @@
 #ifndef AMX_LEVEL_SCANS
 #define AMX_LEVEL_SCANS 0  // 1: poses and velocities travel down the tree level by level as before (A/B switch)
 #endif
+#ifndef AMX_MFMA_AUG
+#define AMX_MFMA_AUG 1  // 0: the fused Newton solve adds M's rows after the matrix cores and takes J'f from column 31 (r02 / r03a), A/B switch
+#endif
+#ifndef AMX_MFMA_AUG_MIN_NV
+#define AMX_MFMA_AUG_MIN_NV 24  // measured: biped (30 dofs) +0.5 %, C4 +1 %; quadruped (18 dofs: three of the tile's eight chunks are zero fill) -1.2 %
+#endif
 #ifndef AMX_NO_GRADCOL
 #define AMX_NO_GRADCOL 0  // 1: J'f of the contact rows always by the per-dof gather (A/B switch)
 #endif
@@ -588,13 +594,18 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 // D_r J_r[31] = 0, so row 31 of the product is sum_r f_r J_r[i] = the contact rows' part of J'f = qfrc_constraint.  Lane i
 // holds column i of the accumulator: the entry reaches it as hi[3][3] with its Hessian row, for four more broadcast loads per
 // contact.
-template <int G, bool COL31 = false>
-DEV void jtdj_rows_mfma(unsigned long long crows, int row_base, int J_base, int ldc, int slot_base, int gl, unsigned (&lo)[4][4], unsigned (&hi)[4][4]) {
+// AUGN >= 0 (32-lane groups): the accumulator starts from *cinit instead of zero, and every row's Jacobian is extended by one
+// entry at index AUGN holding the row's residual Jaref (field 2 of its record), so that row / column AUGN of the product collect
+// sum_r D_r J_r[k] Jaref_r = -(J' f)[k] next to whatever cinit put there (see newton_solve_fused)
+template <int G, bool COL31 = false, int AUGN = -1>
+DEV void jtdj_rows_mfma(unsigned long long crows, int row_base, int J_base, int ldc, int slot_base, int gl, unsigned (&lo)[4][4], unsigned (&hi)[4][4],
+                        const v32f *cinit = nullptr) {
   const int j = gl & 31, h = gl >> 5;
   // one bit per contact that is active in some environment of the wave (wave-uniform scalar loop over the set bits)
   unsigned long long cm = (crows | (crows >> 1) | (crows >> 2) | (crows >> 3)) & 0x1111111111111111ull;
   if (G == 32) {
     v32f C = {};
+    if constexpr (AUGN >= 0) C = *cinit;
     // the first active contact starts the accumulator from the instruction's constant 0 operand: clearing 32 registers
     // with v_mov costs as much VALU time as two more contacts' operand loads
     auto contact = [&](auto first) {
@@ -608,15 +619,17 @@ DEV void jtdj_rows_mfma(unsigned long long crows, int row_base, int J_base, int 
       for (int r = 0; r < 4; ++r) {
         d[r] = lds[Dr + r * ROW_E]; jv[r] = lds[Jr + r * ldc];
         if (COL31) g[r] = lds[Dr + r * ROW_E + 1];
+        if (AUGN >= 0) g[r] = lds[Dr + r * ROW_E + 2];
       }
       // a pyramid row that is inactive in both environments has D = 0 and f = 0 everywhere: its instruction (64 cycles of the
       // matrix pipe, on the dependent chain) is skipped on a scalar test of its bit - except the one that starts the accumulator
       const unsigned rbits = (unsigned)(crows >> (4 * c)) & 15u;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float v = has ? jv[r] : 0.0f;
+        const float v0 = has ? jv[r] : 0.0f;
+        const float v = (AUGN >= 0 && j == AUGN) ? g[r] : v0;
         const float aop = (COL31 && j == 31) ? g[r] : d[r] * v;
-        if (decltype(first)::value && r == 0) { const v32f Z = {}; C = __builtin_amdgcn_mfma_f32_32x32x1f32(aop, v, Z, 0, 0, 0); }
+        if (AUGN < 0 && decltype(first)::value && r == 0) { const v32f Z = {}; C = __builtin_amdgcn_mfma_f32_32x32x1f32(aop, v, Z, 0, 0, 0); }
         else if (AMX_MFMA_ALL_ROWS || ((rbits >> r) & 1u)) C = __builtin_amdgcn_mfma_f32_32x32x1f32(aop, v, C, 0, 0, 0);
       }
     };
@@ -1029,6 +1042,72 @@ AMX_STATIC_SOLVE_ATTR bool newton_solve_fused(int M_off, int ld_, int n_, unsign
     float d0 = 0.0f;
     if (owner) { d0 = lds[dg]; lds[dg] = d0 + dlim; }
     float b;
+    if constexpr (GRADCOL && AMX_MFMA_AUG && (S::ldm > S::nv) && (S::nv >= AMX_MFMA_AUG_MIN_NV)) {
+      // r03: the rows of M, the gradient and the mirrored right-hand-side row all come out of the matrix cores' accumulator.
+      //  * The accumulator starts from M instead of zero.  In the 2-block instruction's layout lane l of the wave holds, for block
+      //    0 (the wave's first environment) and block 1 (its second), rows 8q + 4 (l / 32) + r of column l % 32; after the
+      //    half-wave swaps each lane keeps its own environment's whole column = its row of the symmetric matrix.  So every lane
+      //    loads the chunks 2q + (l / 32) of row l % 32 of BOTH environments' M (four 16-byte loads from its own slab, four from
+      //    its wave mate's) into the accumulator's registers: the same eight loads as before, no additions afterwards.
+      //  * Column NS of the rows of M (padding: ldm > nv) is set to ma - fs - flim of the row's dof, and row NS is that vector as
+      //    a row (staged through bt_off): the symmetric (NS+1) x (NS+1) matrix the elimination works on, before the contacts.
+      //  * Every contact row's Jacobian gets one more entry at index NS: its residual Jaref.  Row / column NS of J'DJ is then
+      //    sum_r D_r J_r[k] Jaref_r = -(J'f)[k]: entry NS of a dof's row becomes the gradient ma - fs - flim - J'f, which is the
+      //    right-hand side, and lane NS receives the same values as a row - no staging after the matrix cores, no column 31.
+      const int hw = (gb4 >> 7) & 1;  // wave half = which environment of the wave is mine
+      const float pre = owner ? ma_v - fs_v - flim : 0.0f;
+      if (gl < lds_) lds[bt_off + gl] = pre;
+      int apc = (NS >> 2) + (S::mrot ? rot : 0);
+      apc -= apc >= nchs ? nchs : 0;
+      if (owner) lds[M_off + li * lds_ + 4 * apc + (NS & 3)] = pre;  // (padding column: nothing to restore)
+      const int dA = hw ? -S::env_floats : 0, dB = hw ? 0 : S::env_floats;  // from my slab to the first / second environment's
+      const int src = brow ? bt_off : (owner ? M_off + li * lds_ : S::c_zero), dsl = (brow | owner) ? 1 : 0;
+      const float4 *rowA = reinterpret_cast<const float4 *>(lds + src + dsl * dA), *rowB = reinterpret_cast<const float4 *>(lds + src + dsl * dB);
+      const int rot_c = owner ? rot : 0;
+      v32f C0;
+      PROF_CTX(pc, 24);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = 2 * q + hw;  // chunk of the row this lane's accumulator registers 4q .. 4q+3 (16 + 4q ..) hold
+        int pcc = c + (S::mrot ? rot_c : 0);
+        pcc -= pcc >= nchs ? nchs : 0;
+        const bool in = c < nchs;  // a tile column past the row's end
+        const float4 vA = rowA[in ? pcc : 0], vB = rowB[in ? pcc : 0];
+        C0[4 * q + 0] = in ? vA.x : 0.0f; C0[4 * q + 1] = in ? vA.y : 0.0f; C0[4 * q + 2] = in ? vA.z : 0.0f; C0[4 * q + 3] = in ? vA.w : 0.0f;
+        C0[16 + 4 * q + 0] = in ? vB.x : 0.0f; C0[16 + 4 * q + 1] = in ? vB.y : 0.0f; C0[16 + 4 * q + 2] = in ? vB.z : 0.0f; C0[16 + 4 * q + 3] = in ? vB.w : 0.0f;
+      }
+      jtdj_rows_mfma<G, false, NS>(crows_u, row_base, J_base, S::ldc, S::c_slot, gl, lo, hi, &C0);
+      PROF_CTX(pc, 25);
+      if (owner) lds[dg] = d0;  // M's own diagonal back (the loads above are done: one wave's LDS operations execute in order)
+      float a[NS + 1];
+#pragma unroll
+      for (int c = 0; c < (NS + 4) / 4; ++c) {
+        const unsigned *srcr = (c & 1) ? hi[c >> 1] : lo[c >> 1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int k = 4 * c + q;
+          if (k <= NS) a[k] = __uint_as_float(srcr[q]);
+        }
+      }
+      b = owner ? a[NS] : 0.0f;
+      const float fcon = ma_v - fs_v - b;  // = flim + J'f of the contact rows
+      if (owner && store_ok) { lds[fcon_off + gl * DOF_E] = fcon; lds[rhs_off + gl * DOF_E] = b; }
+      if (early_out) {
+        const float gn = gsum<G>(b * b);
+        const float ts_ = scale * tol;
+        const bool done = imp_done | (gn < ts_ * ts_);
+        if (group_done) *group_done = done;
+        if (!wave_any(store_ok & !done)) { WSYNC(); return true; }
+      }
+      a[NS] = b;
+      float d = 1.0f;
+      PROF_CTX(pc, 26);
+      sym_eliminate<S, G, TREE, true>(a, gle, d);
+      PROF_CTX(pc, 27);
+      if (owner) lds[x_off + gl * DOF_E] = fdiv(a[NS], AMX_PIVOT_CLAMP ? d : fmaxf(d, MINVAL));
+      WSYNC();
+      return false;
+    } else
     if constexpr (GRADCOL) {
       static_assert(NS <= 31, "column 31 must be spare");
       const float ma = ma_v, fs = fs_v;  // M*qacc and qfrc_smooth of the lane's dof, from the caller's registers
@@ -1810,7 +1889,7 @@ struct Env {
       if (b == rb) {  // the root body itself writes the tree's COM
         const int o = eb + m.e_com() + 3 * r;
         if (sm < MINVAL) { lds[o] = xi.x; lds[o + 1] = xi.y; lds[o + 2] = xi.z; }
-        else { lds[o] = sx / sm; lds[o + 1] = sy / sm; lds[o + 2] = sz / sm; }
+        else { lds[o] = fdiv(sx, sm); lds[o + 1] = fdiv(sy, sm); lds[o + 2] = fdiv(sz, sm); }  // (three IEEE expansions: 30 instructions)
       }
     }
     WSYNC();
@@ -2685,7 +2764,7 @@ struct Env {
       aact = fri ? (fabsf(fq) < aFl) : aact;
     }
     if (gl < nA()) { row(0, gl) = aact ? aD : 0.0f; row(1, gl) = f; }
-    if (gl < nB()) { row(0, row0 + gl) = cact ? cD : 0.0f; row(1, row0 + gl) = fc; }
+    if (gl < nB()) { row(0, row0 + gl) = cact ? cD : 0.0f; row(1, row0 + gl) = fc; row(2, row0 + gl) = cJaref; }  // field 2: for the augmented J'DJ (newton_solve_fused)
     WSYNC();
     if (grad_in_solve() && defer) {
       float fl = 0.0f;
@@ -3216,6 +3295,8 @@ amx_rollout_kernel(const DevModel m_in, int nenv, int nsteps, int x0_batched, co
   const float *us = usg + (live ? (size_t)e * nsteps * nu : 0);
   // control row prefetched one step ahead (rows wider than a group are read in place)
   float unext = (live && gl < nu && nsteps > 0) ? us[gl] : 0.0f;
+  const float *urow = us;                                                  // control row of the current step
+  float *xrow = xs ? xs + (live ? (size_t)e * (nsteps + 1) * nx : 0) : xs;  // state row written last
   WSYNC();
   // t = -1 is shoot()'s forward before the scan (ctrl = 0): it only seeds qacc_warmstart
 #ifndef AMX_FAIR_SIMD
@@ -3236,16 +3317,17 @@ amx_rollout_kernel(const DevModel m_in, int nenv, int nsteps, int x0_batched, co
     }
     if (t >= 0) {
       if (gl < nu) lds[eb + m.e_ctrl() + gl] = unext;
-      if (live) for (int i = gl + G; i < nu; i += G) lds[eb + m.e_ctrl() + i] = us[(size_t)t * nu + i];
-      if (live && t + 1 < nsteps && gl < nu) unext = us[(size_t)(t + 1) * nu + gl];
+      if (live) for (int i = gl + G; i < nu; i += G) lds[eb + m.e_ctrl() + i] = urow[i];
+      urow += nu;  // row t + 1 (a running pointer: the 64-bit row products cost a dozen vector instructions per step)
+      if (live && t + 1 < nsteps && gl < nu) unext = urow[gl];
       WSYNC();
     }
     env.forward();
     if (t >= 0) {
       env.euler();
       if (xs && live) {
-        float *rowp = xs + ((size_t)e * (nsteps + 1) + t + 1) * nx;
-        for (int i = gl; i < nx; i += G) rowp[i] = i < nq ? lds[qp + i] : lds[qv + i - nq];
+        xrow += nx;
+        for (int i = gl; i < nx; i += G) xrow[i] = i < nq ? lds[qp + i] : lds[qv + i - nq];
       }
     }
 #ifdef AMX_PROFILE
