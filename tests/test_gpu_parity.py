@@ -704,6 +704,21 @@ def test_forced_lane_group_widths(cases, golden, force, dev):
         del os.environ["AMX_FORCE_G"]
 
 
+@pytest.mark.parametrize("name", ["biped", "quadruped"])
+def test_odd_batches_match_even_ones_bitwise(cases, dev, name):
+    """A batch with an odd number of environments leaves the last wave's second lane group without an environment (its LDS slab is
+    never initialised).  The live environments must come out bit for bit as in an even batch: since r03 the fused Newton solve of
+    the large models reads its wave mate's slab for the other block of the matrix cores' accumulator."""
+    from ambersim_amd import mjx
+    from bench import make_inputs
+    mj, model, _, _ = cases[name]
+    x0, us = make_inputs(mj, 38, 30, 1, 2, dev)
+    ref = mjx.rollout(model, x0, us)
+    for n in (1, 5, 17, 33, 37):
+        xs = mjx.rollout(model, x0[:n].contiguous(), us[:n].contiguous())
+        assert torch.isfinite(xs).all() and torch.equal(xs, ref[:n]), (name, n)
+
+
 @pytest.mark.parametrize("S,N,nx,nu", [(7, 1, 2, 1), (5, 33, 37, 12), (9, 64, 61, 24), (3, 100, 33, 0), (4, 40, 96, 32), (3, 20, 100, 5)])
 def test_quadcost_shapes_vs_einsum(dev, S, N, nx, nu):
     """amx_quadcost against an fp64 einsum at the shapes of every configuration: tiles that end mid-way, several 32-column
