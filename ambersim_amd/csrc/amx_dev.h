@@ -72,7 +72,7 @@ enum { CX_MAXV = 32, CX_MAXP = 16, CX_VA = 0, CX_VB = 96, CX_POLY = 192, CX_SCRA
   X(e_com) X(e_actf)                                                                                                       \
   X(e_M) /* full symmetric [nv][ldm], 16-byte aligned rows */ X(e_H) /* the same for H when it is stored; else the M*v staging vector */                                                       \
   X(e_Lb) /* packed lower-triangular Cholesky factor, only allocated for the CG solver */                                  \
-  X(e_row) /* records [nefc][ROW_E]: Dact 0 frow 1 */                                                                      \
+  X(e_row) /* records [nefc][ROW_E]: Dact 0 frow 1 Jaref 2 (contact rows) */                                                                      \
   X(e_J) /* contact rows only, chain-compressed: [4*ncon][ldc] */ X(e_vch) /* [npair][ldc]: the vector of the current J*v products gathered in the order of each pair's dof list (0 past its end) */                                                          \
   X(e_con) /* records [ncon][CON_E]: dist 0 pos 1-3 */ X(e_frame) /* [npair][9] */                                         \
   X(e_geom) /* records [ngc][GEO_E]: pos 0-2 mat 3-11 */                                                                   \
