@@ -1,6 +1,7 @@
 """Multi-GPU sharding of the env axis: one process per GPU, contiguous env blocks, no
-collective during the rollout, one all-gather (RCCL over xGMI on GPUs, gloo on CPU tensors) for the
-returned trajectories."""
+collective during the rollout, one all-gather for the returned trajectories - as an RCCL collective over xGMI
+(gloo on CPU tensors), or as peer-to-peer copies on the copy engines (PeerCopyGather), which unlike a collective's
+kernels can proceed while the next rollout occupies every CU."""
 from __future__ import annotations
 
 import os
@@ -96,6 +97,89 @@ def gather_trajectories_async(xs_local: torch.Tensor) -> PendingGather:
     out = torch.empty((world * xs_local.shape[0],) + tuple(xs_local.shape[1:]), dtype=xs_local.dtype, device=xs_local.device)
     work = dist.all_gather_into_tensor(out, xs_local, async_op=True)
     return PendingGather(out, work, xs_local)
+
+
+class PeerCopyGather:
+    """Equal-block all-gather of trajectories by peer-to-peer copies instead of a collective kernel (r03).
+
+    Why: the rollout kernel leaves nothing on a CU for another kernel to live on - two waves per SIMD hold 464 of its 512 vector
+    registers and the workgroup all but 0.9 KB of the LDS - so a collective's kernels are never resident next to it: whichever is
+    launched first runs first (profiles/r03_coresidency.txt: 33.9 ms + 20.9 ms = 55.4 ms either way).  A device-to-device copy
+    between two GPUs is carried out by the copy (SDMA) engines over xGMI and needs no compute unit, so it does run under the
+    next rollout.
+
+    Every rank owns `nbuf` gather buffers [world, *block]; their IPC handles are exchanged once (torch's CUDA IPC, pickled through
+    a gloo group), and a gather is `world` asynchronous copies of the rank's block into slot `rank` of every peer's buffer on a
+    side stream, ordered after the kernels already queued on the current stream.  `wait()` synchronises the side stream and meets
+    the other ranks at a CPU (gloo) barrier: after it every rank's copies have landed, the buffer is complete.  Buffers rotate,
+    so at most `nbuf` gathers may be in flight.  Raises (at construction) if the IPC exchange or the probe transfer fails: the
+    caller falls back to the RCCL all-gather."""
+
+    def __init__(self, block_shape, dtype, device, nbuf: int = 2):
+        from torch.multiprocessing.reductions import reduce_tensor
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.device, self.nbuf, self.k = device, nbuf, 0
+        self.cpu_group = dist.new_group(backend="gloo")
+        self.block_shape = tuple(block_shape)
+        self.bufs = [torch.empty((self.world,) + self.block_shape, dtype=dtype, device=device) for _ in range(nbuf)]
+        self.probe = torch.full((self.world, 4), -1.0, device=device)
+        mine = [reduce_tensor(t) for t in self.bufs + [self.probe]]
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, mine, group=self.cpu_group)
+        self.peer = []  # peer[p] = [buffers of rank p ..., probe of rank p] as tensors of this process
+        for p in range(self.world):
+            self.peer.append(self.bufs + [self.probe] if p == self.rank else [fn(*a) for fn, a in everyone[p]])
+        self.stream = torch.cuda.Stream(device)
+        # probe: every rank writes its number into its slot of every peer's probe; all slots must arrive
+        with torch.cuda.stream(self.stream):
+            src = torch.full((4,), float(self.rank), device=device)
+            for p in range(self.world):
+                self.peer[p][nbuf][self.rank].copy_(src, non_blocking=True)
+        self.stream.synchronize()
+        dist.barrier(group=self.cpu_group)
+        want = torch.arange(self.world, dtype=torch.float32, device=device)[:, None].expand(self.world, 4)
+        ok = torch.tensor([int(torch.equal(self.probe, want))])
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.cpu_group)
+        if int(ok.item()) != 1:
+            raise RuntimeError("peer-copy gather: the probe transfer did not arrive on every rank")
+
+    def start(self, xs_local: torch.Tensor) -> "PendingPeerCopy":
+        """Starts the gather of `xs_local` (ordered after the current stream's queued work); returns the handle to wait on."""
+        assert tuple(xs_local.shape) == self.block_shape, (tuple(xs_local.shape), self.block_shape)
+        b = self.k % self.nbuf
+        self.k += 1
+        xs_local = xs_local.contiguous()
+        ready = torch.cuda.Event()
+        ready.record()
+        self.stream.wait_event(ready)
+        with torch.cuda.stream(self.stream):
+            for d in range(self.world):
+                p = (self.rank + d) % self.world  # every rank starts with a different peer: the links are used evenly
+                self.peer[p][b][self.rank].copy_(xs_local, non_blocking=True)
+        xs_local.record_stream(self.stream)
+        return PendingPeerCopy(self, b)
+
+
+    def close(self) -> None:
+        """Drops this process's mappings of the peers' buffers, then meets the peers: a rank must not free buffers its peers still map."""
+        self.stream.synchronize()
+        self.peer = None
+        dist.barrier(group=self.cpu_group)
+
+
+class PendingPeerCopy:
+    __slots__ = ("owner", "b")
+
+    def __init__(self, owner, b):
+        self.owner, self.b = owner, b
+
+    def wait(self) -> torch.Tensor:
+        """Blocks the host until every rank's block has landed in this rank's buffer; returns it as [world * nenv_local, ...]."""
+        o = self.owner
+        o.stream.synchronize()              # my outgoing copies are done
+        dist.barrier(group=o.cpu_group)     # ... and so are everybody else's (a CPU barrier: no kernel behind the rollout)
+        buf = o.bufs[self.b]
+        return buf.view((o.world * o.block_shape[0],) + o.block_shape[1:])
 
 
 def backend_report() -> dict:

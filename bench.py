@@ -11,8 +11,11 @@ biped (models/biped/biped.xml), 4096 envs per GPU, random ctrl, 1000-step fused 
           file's Newton 3 / 5, A8 (trajectory cost) and the FP32 figure (recorded flop census,
           profiles/rNN_flop_census.json, / 157.3 TFLOP/s; VALU-busy from the committed PMC pass); `cpu_baseline`; the MJX-CPU probe.
   N > 1   every rank runs its own 4096 envs (weak scaling, no collective in the data path) and the returned trajectories
-          are all-gathered over RCCL once per step, overlapped with the next rollout; the line carries `scaling_report`
-          (rollout alone, gather alone, with / without overlap, RCCL version, world size as the backend reports it).
+          are all-gathered once per step, overlapped with the next rollout: by peer-to-peer copies on the copy engines
+          (ambersim_amd.dist.PeerCopyGather; `--gather auto`, the default, falls back to the RCCL collective if the IPC set-up
+          or its probe fails; `--gather traj` forces RCCL).  The rollout's workgroups fill every CU, so a collective's KERNELS
+          cannot run next to it (profiles/r03_coresidency.txt); copy-engine transfers can.  The line carries `scaling_report`:
+          rollout alone, both gather methods alone / serialised / overlapped, RCCL version, world size as the backend reports it.
 
 `python bench.py --gpus N` is self-contained: with WORLD_SIZE unset and N > 1 the parent - which has not imported torch
 or touched the GPU - starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process, relays
@@ -46,7 +49,10 @@ def parse_args(argv=None):
     ap.add_argument("--nenv", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--horizon", type=int, default=1000)
     ap.add_argument("--model", default=None, help=f"default: {BIPED} (C3 / C5) at every N")
-    ap.add_argument("--gather", choices=["traj", "none"], default="traj", help="N>1: all-gather returned trajectories")
+    ap.add_argument("--gather", choices=["auto", "p2p", "traj", "none"], default="auto",
+                    help="N>1: how the returned trajectories are all-gathered: p2p = peer-to-peer copies on the copy engines (they run under "
+                         "the next rollout; ambersim_amd.dist.PeerCopyGather), traj = one RCCL all-gather (its kernels cannot be resident next "
+                         "to the rollout's), auto = p2p when its set-up and probe succeed, else traj; none = no gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="N=1: skip the C2 / C4 / solver-option / FP32 secondary measurements")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: wait for each all-gather before the next rollout")
@@ -195,10 +201,15 @@ def worker(args):
     import numpy as np
     import torch
     import torch.distributed as dist
-    from ambersim_amd.dist import backend_report, gather_trajectories, gather_trajectories_async, init_from_env
+    from ambersim_amd.dist import PeerCopyGather, backend_report, gather_trajectories, gather_trajectories_async, init_from_env
     from ambersim_amd.utils.io_utils import load_mj_model_from_file
 
-    rank, world, local = init_from_env("gloo" if args.dry_run else None)
+    # AMX_BENCH_SHARE_DEVICE=1: every rank on cuda:0 with a gloo process group - the only way to run more than one rank on a
+    # one-GPU box (RCCL refuses two ranks on one device); exercises the launcher and the peer-copy gather, not RCCL
+    share = os.environ.get("AMX_BENCH_SHARE_DEVICE") == "1"
+    rank, world, local = init_from_env("gloo" if (args.dry_run or share) else None)
+    if share:
+        local = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dry = args.dry_run
@@ -223,10 +234,28 @@ def worker(args):
         x0, us = make_inputs(mj, args.nenv, args.horizon, 1 + 1000 * rank, 2 + 1000 * rank, dev)
         rollout = lambda: mjx.rollout(model, x0, us)
 
-    def run_steps(nsteps, mode, events=None):
-        """`nsteps` rollouts.  mode "overlap": the all-gather of step k runs on the communication stream while rollout k+1
-        runs on the compute stream (at most two gathers in flight); "serial": each gather is waited for; "none": no
-        gather.  Everything is complete when this returns (the caller synchronises)."""
+    red_dev = "cpu" if (dry or share) else dev  # small host-side reductions: gloo takes CPU tensors
+    # the gather method: peer-to-peer copies (copy engines) or the RCCL collective (kernels)
+    p2p, p2p_note = None, None
+    if world > 1 and not dry and args.gather in ("auto", "p2p"):
+        try:
+            p2p = PeerCopyGather((args.nenv, args.horizon + 1, nx), torch.float32, dev, nbuf=2)
+        except Exception as e:  # IPC not available, peer access refused, probe lost: the collective still works
+            if args.gather == "p2p":
+                raise
+            p2p_note = f"peer-copy set-up failed ({type(e).__name__}: {str(e)[:160]}): RCCL all-gather instead"
+        # every rank must take the same path
+        ok = torch.tensor([1 if p2p is not None else 0], device=red_dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            p2p = None
+    method = "none" if (world == 1 or args.gather == "none") else ("p2p" if p2p is not None else "rccl")
+
+    def run_steps(nsteps, mode, events=None, how=None):
+        """`nsteps` rollouts.  mode "overlap": the gather of step k proceeds while rollout k+1 runs (at most two gathers in
+        flight); "serial": each gather is waited for; "none": no gather.  how: "p2p" (peer copies) or "rccl" (the collective);
+        default: the run's method.  Everything is complete when this returns (the caller synchronises)."""
+        how = how or method
         pending, xs = [], None
         for k in range(nsteps):
             if events is not None:
@@ -235,16 +264,17 @@ def worker(args):
             if events is not None:
                 events[k][1].record()
             if world > 1 and mode == "overlap":
-                pending.append(gather_trajectories_async(xs))  # holds xs until waited for: the name is rebound by the next rollout
-                if len(pending) > 2:
+                # (the pending handle holds xs until waited for: the name is rebound by the next rollout)
+                pending.append(p2p.start(xs) if how == "p2p" else gather_trajectories_async(xs))
+                if len(pending) > 1:
                     pending.pop(0).wait()
             elif world > 1 and mode == "serial":
-                xs = gather_trajectories(xs, equal_blocks=True)
+                xs = p2p.start(xs).wait() if how == "p2p" else gather_trajectories(xs, equal_blocks=True)
         for pg in pending:
             xs = pg.wait()
         return xs
 
-    def timed(nsteps, mode, with_events=False):
+    def timed(nsteps, mode, with_events=False, how=None):
         sync()
         if world > 1:
             dist.barrier()
@@ -253,14 +283,14 @@ def worker(args):
         if with_events and not dry:
             ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nsteps)]
         t0 = time.perf_counter()
-        xs = run_steps(nsteps, mode, ev)
+        xs = run_steps(nsteps, mode, ev, how)
         sync()
         if world > 1:
             dist.barrier()
         sync()
         elapsed = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
@@ -278,28 +308,42 @@ def worker(args):
     report = None
     if world > 1 and not args.no_scaling_report:
         k = args.steps
-        t_roll, _, _ = timed(k, "none")
-        t_serial, _, _ = timed(k, "serial")
-        t_over, _, _ = timed(k, "overlap")
-        xs_local = rollout()
-        sync()
-        dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(k):
-            gather_trajectories(xs_local, equal_blocks=True)
-        sync()
-        dist.barrier()
-        t_gather = time.perf_counter() - t0
-        tg = torch.tensor([t_gather], dtype=torch.float64, device=dev)
-        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
-        t_gather = float(tg.item())
         es = args.nenv * args.horizon * k * world
-        gb = xs_local.numel() * 4 * world / 1e9
-        report = {"rollout_only_env_steps_per_s": es / t_roll, "with_gather_serial_env_steps_per_s": es / t_serial,
-                  "with_gather_overlapped_env_steps_per_s": es / t_over, "gather_alone_ms": 1e3 * t_gather / k,
-                  "gathered_GB_per_rank": gb, "gather_GBps_per_rank_received": gb * (world - 1) / world / (t_gather / k),
-                  "note": "single-GPU throughput of this workload = `value` of the N=1 line (same model, same envs per GPU)",
-                  **backend_report()}
+        gb = args.nenv * (args.horizon + 1) * nx * 4 * world / 1e9
+
+        def alone(gather_once):  # k gathers of one resident block, nothing else on the GPU
+            xs_local = rollout()
+            sync()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                gather_once(xs_local)
+            sync()
+            dist.barrier()
+            tg = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+            return float(tg.item())
+
+        t_roll, _, _ = timed(k, "none")
+        report = {"rollout_only_env_steps_per_s": es / t_roll, "gathered_GB_per_rank": gb,
+                  "note": "single-GPU throughput of this workload = `value` of the N=1 line (same model, same envs per GPU); the rollout's "
+                          "workgroups fill every CU (LDS and registers), so a collective's kernels run before or after a rollout, never "
+                          "next to it (profiles/r03_coresidency.txt) - copies on the copy engines do"}
+        if not share:  # the RCCL collective (skipped when the ranks share one device: no RCCL there)
+            t_serial, _, _ = timed(k, "serial", how="rccl")
+            t_over, _, _ = timed(k, "overlap", how="rccl")
+            t_gather = alone(lambda x: gather_trajectories(x, equal_blocks=True))
+            report.update({"with_gather_serial_env_steps_per_s": es / t_serial, "with_gather_overlapped_env_steps_per_s": es / t_over,
+                           "gather_alone_ms": 1e3 * t_gather / k, "gather_GBps_per_rank_received": gb * (world - 1) / world / (t_gather / k)})
+        if p2p is not None:
+            t_pser, _, _ = timed(k, "serial", how="p2p")
+            t_pover, _, _ = timed(k, "overlap", how="p2p")
+            t_pg = alone(lambda x: p2p.start(x).wait())
+            report.update({"with_peer_copy_serial_env_steps_per_s": es / t_pser, "with_peer_copy_overlapped_env_steps_per_s": es / t_pover,
+                           "peer_copy_alone_ms": 1e3 * t_pg / k, "peer_copy_GBps_per_rank_received": gb * (world - 1) / world / (t_pg / k)})
+        if p2p_note:
+            report["peer_copy"] = p2p_note
+        report.update(backend_report())
 
     if rank == 0:
         env_steps = args.nenv * args.horizon * args.steps * world
@@ -313,7 +357,8 @@ def worker(args):
                                    f"{args.horizon}-step fused rollout, random ctrl ~U(ctrlrange), Newton {mj.opt.iterations} it / "
                                    f"{mj.opt.ls_iterations} ls, dt={mj.opt.timestep}",
                        "nenv_per_gpu": args.nenv, "horizon": args.horizon, "nq": mj.nq, "nv": mj.nv, "nu": mj.nu,
-                       "gather": {"none": "none", "serial": "traj", "overlap": "traj+overlapped"}[mode], "outputs_finite": finite},
+                       "gather": {"none": "none", "serial": "traj", "overlap": "traj+overlapped"}[mode] + ("" if method != "p2p" else " (peer-to-peer copies on the copy engines)"),
+                       "outputs_finite": finite},
         }
         if not dry:
             out["roofline"] = roofline(mj, args.nenv, args.horizon, kern_ms, model_path)
@@ -328,6 +373,8 @@ def worker(args):
                 out["cpu_baseline"] = cpu_baseline(mj, x0_np, us_np, target_s=10.0)
         print(json.dumps(out), flush=True)
     if world > 1:
+        if p2p is not None:
+            p2p.close()
         dist.barrier()
         dist.destroy_process_group()
 

@@ -704,6 +704,17 @@ def test_forced_lane_group_widths(cases, golden, force, dev):
         del os.environ["AMX_FORCE_G"]
 
 
+def test_peer_copy_gather_two_ranks_on_one_device():
+    """ambersim_amd.dist.PeerCopyGather between two processes (both on cuda:0, gloo process group - RCCL refuses two ranks on one
+    device): IPC exchange of the gather buffers, probe, five gathers with two in flight, contents and block order."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
+                        os.path.join(root, "tools", "dbg", "p2p_gather_test.py")], capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0 and "contents and order correct on 2 ranks" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])
+
+
 @pytest.mark.parametrize("name", ["biped", "quadruped"])
 def test_odd_batches_match_even_ones_bitwise(cases, dev, name):
     """A batch with an odd number of environments leaves the last wave's second lane group without an environment (its LDS slab is
