@@ -121,27 +121,56 @@ class PeerCopyGather:
         self.device, self.nbuf, self.k = device, nbuf, 0
         self.cpu_group = dist.new_group(backend="gloo")
         self.block_shape = tuple(block_shape)
-        self.bufs = [torch.empty((self.world,) + self.block_shape, dtype=dtype, device=device) for _ in range(nbuf)]
-        self.probe = torch.full((self.world, 4), -1.0, device=device)
-        mine = [reduce_tensor(t) for t in self.bufs + [self.probe]]
+
+        # Every phase ends in a collective that all ranks reach whether or not their own part failed: a rank that raised early
+        # would otherwise leave its peers waiting in the next exchange.
+        def all_ok(err, what):
+            msgs = [None] * self.world
+            dist.all_gather_object(msgs, None if err is None else f"rank {self.rank}: {type(err).__name__}: {err}", group=self.cpu_group)
+            bad = [m for m in msgs if m is not None]
+            if bad:
+                raise RuntimeError(f"peer-copy gather, {what}: " + "; ".join(bad)[:400])
+
+        err, mine = None, None
+        try:
+            self.bufs = [torch.empty((self.world,) + self.block_shape, dtype=dtype, device=device) for _ in range(nbuf)]
+            self.probe = torch.full((self.world, 4), -1.0, device=device)
+            mine = [reduce_tensor(t) for t in self.bufs + [self.probe]]
+        except Exception as e:
+            err = e
         everyone = [None] * self.world
         dist.all_gather_object(everyone, mine, group=self.cpu_group)
-        self.peer = []  # peer[p] = [buffers of rank p ..., probe of rank p] as tensors of this process
-        for p in range(self.world):
-            self.peer.append(self.bufs + [self.probe] if p == self.rank else [fn(*a) for fn, a in everyone[p]])
-        self.stream = torch.cuda.Stream(device)
-        # probe: every rank writes its number into its slot of every peer's probe; all slots must arrive
-        with torch.cuda.stream(self.stream):
-            src = torch.full((4,), float(self.rank), device=device)
+        all_ok(err, "allocating and exporting the buffers")
+        try:
+            if os.environ.get("AMX_P2P_FAIL_RANK") == str(self.rank):  # test hook: one rank fails, nobody may hang
+                raise OSError("injected failure (AMX_P2P_FAIL_RANK)")
+            self.peer = []  # peer[p] = [buffers of rank p ..., probe of rank p] as tensors of this process
             for p in range(self.world):
-                self.peer[p][nbuf][self.rank].copy_(src, non_blocking=True)
-        self.stream.synchronize()
+                self.peer.append(self.bufs + [self.probe] if p == self.rank else [fn(*a) for fn, a in everyone[p]])
+        except Exception as e:
+            err = e
+        all_ok(err, "opening the peers' buffers")
+        # probe: every rank writes its number into its slot of every peer's probe; all slots must arrive
+        ok = 0
+        try:
+            self.stream = torch.cuda.Stream(device)
+            with torch.cuda.stream(self.stream):
+                src = torch.full((4,), float(self.rank), device=device)
+                for p in range(self.world):
+                    self.peer[p][nbuf][self.rank].copy_(src, non_blocking=True)
+            self.stream.synchronize()
+        except Exception as e:
+            err = e
         dist.barrier(group=self.cpu_group)
-        want = torch.arange(self.world, dtype=torch.float32, device=device)[:, None].expand(self.world, 4)
-        ok = torch.tensor([int(torch.equal(self.probe, want))])
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.cpu_group)
-        if int(ok.item()) != 1:
-            raise RuntimeError("peer-copy gather: the probe transfer did not arrive on every rank")
+        try:
+            if err is None:
+                want = torch.arange(self.world, dtype=torch.float32, device=device)[:, None].expand(self.world, 4)
+                ok = int(torch.equal(self.probe, want))
+                if not ok:
+                    err = RuntimeError("the probe transfer did not arrive")
+        except Exception as e:
+            err = e
+        all_ok(err, "probe transfer")
 
     def start(self, xs_local: torch.Tensor) -> "PendingPeerCopy":
         """Starts the gather of `xs_local` (ordered after the current stream's queued work); returns the handle to wait on."""

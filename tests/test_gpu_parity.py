@@ -713,6 +713,11 @@ def test_peer_copy_gather_two_ranks_on_one_device():
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
                         os.path.join(root, "tools", "dbg", "p2p_gather_test.py")], capture_output=True, text=True, timeout=300, cwd=root)
     assert r.returncode == 0 and "contents and order correct on 2 ranks" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])
+    # a rank that fails during the set-up is reported on every rank (bench.py then falls back to the collective); nobody hangs
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29518",
+                        os.path.join(root, "tools", "dbg", "p2p_gather_test.py")], capture_output=True, text=True, timeout=300, cwd=root,
+                       env=dict(os.environ, AMX_P2P_FAIL_RANK="1"))
+    assert r.returncode == 0 and "a failing rank is reported on every rank" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])
 
 
 @pytest.mark.parametrize("name", ["biped", "quadruped"])

@@ -9,6 +9,16 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
+if os.environ.get("AMX_P2P_FAIL_RANK") is not None:  # one rank fails during the set-up: every rank must get the error, none may hang
+    try:
+        PeerCopyGather((64, 11, 7), torch.float32, dev)
+        raise SystemExit("the injected failure was not reported")
+    except RuntimeError as e:
+        assert "injected failure" in str(e), e
+    dist.barrier()
+    if rank == 0: print("peer-copy gather: a failing rank is reported on every rank")
+    dist.destroy_process_group()
+    raise SystemExit(0)
 g = PeerCopyGather((64, 11, 7), torch.float32, dev)
 pend = []
 for k in range(5):
