@@ -185,8 +185,10 @@ class PeerCopyGather:
             for d in range(self.world):
                 p = (self.rank + d) % self.world  # every rank starts with a different peer: the links are used evenly
                 self.peer[p][b][self.rank].copy_(xs_local, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self.stream)  # this gather's copies only: wait() must not wait for a later gather queued behind a later rollout
         xs_local.record_stream(self.stream)
-        return PendingPeerCopy(self, b)
+        return PendingPeerCopy(self, b, done)
 
 
     def close(self) -> None:
@@ -197,15 +199,15 @@ class PeerCopyGather:
 
 
 class PendingPeerCopy:
-    __slots__ = ("owner", "b")
+    __slots__ = ("owner", "b", "done")
 
-    def __init__(self, owner, b):
-        self.owner, self.b = owner, b
+    def __init__(self, owner, b, done):
+        self.owner, self.b, self.done = owner, b, done
 
     def wait(self) -> torch.Tensor:
         """Blocks the host until every rank's block has landed in this rank's buffer; returns it as [world * nenv_local, ...]."""
         o = self.owner
-        o.stream.synchronize()              # my outgoing copies are done
+        self.done.synchronize()             # my outgoing copies of THIS gather are done
         dist.barrier(group=o.cpu_group)     # ... and so are everybody else's (a CPU barrier: no kernel behind the rollout)
         buf = o.bufs[self.b]
         return buf.view((o.world * o.block_shape[0],) + o.block_shape[1:])
