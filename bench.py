@@ -297,6 +297,15 @@ def worker(args):
         return elapsed, kern_ms, xs
 
     mode = "none" if (world == 1 or args.gather == "none") else ("serial" if args.no_overlap else "overlap")
+    picked = None
+    if args.gather == "auto" and method == "p2p" and not share:
+        # both methods work: two steps of each, the faster one carries the headline (the copy engines' rate over xGMI is a property
+        # of the node; the collective is the known quantity)
+        run_steps(1, mode, how="p2p"); run_steps(1, mode, how="rccl")
+        tp, _, _ = timed(2, mode, how="p2p")
+        tr, _, _ = timed(2, mode, how="rccl")
+        method = "p2p" if tp <= tr else "rccl"
+        picked = {"peer_copy_ms_per_step": 1e3 * tp / 2, "rccl_ms_per_step": 1e3 * tr / 2, "picked": method}
     run_steps(args.warmup, mode)
     elapsed, kern_ms, xs = timed(args.steps, mode, with_events=True)
     finite = bool(torch.isfinite(xs).all().item())
@@ -343,6 +352,8 @@ def worker(args):
                            "peer_copy_alone_ms": 1e3 * t_pg / k, "peer_copy_GBps_per_rank_received": gb * (world - 1) / world / (t_pg / k)})
         if p2p_note:
             report["peer_copy"] = p2p_note
+        if picked:
+            report["gather_method_calibration"] = picked
         report.update(backend_report())
 
     if rank == 0:
