@@ -153,6 +153,9 @@ DEV float fdiv(float x, float y) {
 // x / y for the line search's Newton steps on the derivative (alpha - d0 / d1): reciprocal and one multiply, 1.5 ulp.  The
 // quotient only places the next trial point; every decision is taken on derivatives evaluated AT the trial points, so the last
 // bit of a trial point's position is immaterial (AMX_LS_FASTDIV=0: the corrected quotient above)
+#ifndef AMX_LS_END_FROM_DERIVS
+#define AMX_LS_END_FROM_DERIVS 1  // 0: the bracket ends' quadratic coefficients are summed again at the end of the line search (A/B switch)
+#endif
 #ifndef AMX_LS_FASTDIV
 #define AMX_LS_FASTDIV 1
 #endif
@@ -3025,6 +3028,16 @@ struct Env {
     // quadratic terms themselves.
     float lo_delta, hi_delta;
     {
+#if AMX_LS_END_FROM_DERIVS
+      // the quadratic part of cost(alpha) - cost(0) is already in the bracket ends' derivatives (d1 = 2 q2, d0 = 2 alpha q2 + q1:
+      // alpha^2 q2 + alpha q1 = alpha d0 - alpha^2 d1 / 2); only the constant terms' difference needs a sum
+      float q0l, q0h;
+      ls_terms(lo.alpha, validA, validB, iseq, &q0l);
+      ls_terms(hi.alpha, validA, validB, iseq, &q0h);
+      const float r = gsum_pack2<G>(q0l - q0_start, q0h - q0_start);
+      lo_delta = lo.alpha * (lo.d0 - 0.5f * lo.alpha * lo.d1) + quad_value<0>(r);
+      hi_delta = hi.alpha * (hi.d0 - 0.5f * hi.alpha * hi.d1) + quad_value<1>(r);
+#else
       float q0l, q0h;
       const LSTerms tl = ls_terms(lo.alpha, validA, validB, iseq, &q0l), th = ls_terms(hi.alpha, validA, validB, iseq, &q0h);
       float u, w;
@@ -3032,6 +3045,7 @@ struct Env {
       const float q1l = quad_value<0>(u) + g1, q2l = quad_value<1>(u) + g2, q1h = quad_value<3>(u) + g1, q2h = quad_value<2>(u) + g2;
       lo_delta = lo.alpha * lo.alpha * q2l + lo.alpha * q1l + quad_value<0>(w);
       hi_delta = hi.alpha * hi.alpha * q2h + hi.alpha * q1h + quad_value<1>(w);
+#endif
     }
     const bool improved = alive & ((lo_delta < 0.0f) | (hi_delta < 0.0f));
     const float alpha = lo_delta < hi_delta ? lo.alpha : hi.alpha;
