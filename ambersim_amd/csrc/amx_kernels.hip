@@ -825,6 +825,9 @@ template <class S, int G, int K> struct SymRest {  // dense order: every column 
 #ifndef AMX_PIVOT_VCMP
 #define AMX_PIVOT_VCMP 0  // 1: the pivot-lane test as v_cmp per pivot (r02), A/B switch
 #endif
+#ifndef AMX_PIVOT_RCP_BUILTIN
+#define AMX_PIVOT_RCP_BUILTIN 1  // 0: the pivot's reciprocal as assembly with a fixed s_nop 1 in front (A/B switch)
+#endif
 #ifndef AMX_PIVOT_CLAMP
 #define AMX_PIVOT_CLAMP 0  // 1: every pivot clamped to MINVAL before its reciprocal (r02/r03a: one v_max_f32_dpp per pivot), A/B switch
 #endif
@@ -856,7 +859,14 @@ template <class S, int G, int J, bool TREE, bool BCOL> DEV void sym_pivot(float 
   // after the swap / the last writer.  The pivots of a positive definite matrix need no clamp (the reference's Cholesky has
   // none either); the solution's final division clamps the stored diagonal once per elimination instead of once per pivot.
   float rinv;
+#if AMX_PIVOT_RCP_BUILTIN
+  // compiler-visible (the DPP combiner does fold the broadcast into v_rcp_f32_dpp): the hazard recogniser pads only the wait states
+  // the schedule leaves open between the lane swap and this read - the assembly form carried a fixed s_nop 1 per pivot, 8 cycles
+  // on every pivot's dependent chain (biped +1 %, C4 +1.7 %).  The assembly multiply-adds below still depend on it through nf.
+  rinv = __builtin_amdgcn_rcpf(bcast_row<J>(p));
+#else
   asm("s_nop 1\n\tv_rcp_f32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(rinv) : "v"(J < 16 ? p.r0 : p.r1), "n"(J & 15));
+#endif
   piv = c;  // on the pivot lane, the only one whose `diag` takes it
 #elif AMX_PIVOT_ASM_MAX
   // max(lane J of p, MINVAL) in one instruction; the leading s_nop 1 is the 2 wait states after the swap / the last writer
