@@ -69,6 +69,20 @@ typedef struct amxo_model {
   int nq, nv, nu, nbody, njnt, ngeom, neq, npair, nvert, ncon, nefc_max;
   REAL timestep, gravity[3], tolerance, ls_tolerance, impratio, meaninertia;
   int iterations, ls_iterations, solver, integrator, disableflags;
+  /* line-search rule (amxo_model_set_int "ls_rule"; 0 = MJX's formulation, the default).  Bit 0: the HIP kernel's ACCEPTANCE rule -
+   * a step is taken on the sign of cost(alpha) - cost(0) = alpha^2 q2 + alpha q1 + sum_rows (q0_row(alpha) - q0_row(0)), and that
+   * decrease is the solver's `improvement` (ambersim_amd/csrc/amx_kernels.hip: Env::linesearch, Env::solve).  Bit 1: the kernel's
+   * ARITHMETIC around it - trial points alpha - d0 * (1 / d1), d1 = max(2 q2, MINVAL), the stopping tests multiplied out, the
+   * quadratic part of the decrease taken from the bracket ends' derivatives.  Same algebra, so in exact arithmetic every
+   * decision is the same; tests/test_ls_rule.py shows it for fp64 and measures where fp32 parts ways. */
+  int ls_rule, ls_stats_on;
+  long long ls_stat[12]; /* line searches, accepted under rule 0, accepted under rule 1, accept decisions that differ, Newton iterations,
+                         * solver calls, both accept but pick different bracket ends, solver calls with a differing accept decision,
+                         * [8] stopping tests on the improvement that differ between `prev_cost - cost` and the line search's own decrease */
+  double ls_gap_max;    /* largest |decrease(lo) - decrease(hi)| / max(|decrease|) over the differing bracket-end picks: they are ties */
+  double ls_stop_max;   /* largest |(prev_cost - cost) - decrease| / max(|cost|, |prev_cost|, tolerance * scale) over the differing stopping
+                         * tests: the cancellation noise of two full costs */
+  double ls_acc_max;    /* largest |decrease| / |cost(0)| over the differing accept decisions: improvements the full-cost comparison cannot resolve */
   int *body_parentid, *body_rootid, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum;
   REAL *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_invweight0;
   int *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid, *jnt_limited;
@@ -212,6 +226,8 @@ typedef struct amxo_data {
   int nefc, ne, nf; /* rows: [0, ne) equality, [ne, ne + nf) friction loss, then limits, then contacts */
   REAL *efc_J, *efc_D, *efc_aref, *efc_pos, *efc_force, *efc_floss; /* efc_floss: the friction rows' force bound, 0 elsewhere */
   int solver_niter;
+  long long ls_stat[12];
+  double ls_gap_max, ls_acc_max, ls_stop_max; int ls_differed;
   /* scratch */
   REAL *w_a, *w_b, *w_c, *w_d, *w_e, *w_f, *w_g, *w_H, *w_L, *w_jv, *w_jaref, *w_mass, *w_quad;
   REAL *w_support;
@@ -1185,7 +1201,7 @@ static void fwd_acceleration(const amxo_model *m, amxo_data *d) {
 
 /* ------------------------------------------------------------------ A9.13 solver [mjx:solver.solve] */
 typedef struct { REAL *qacc, *Ma, *grad, *Mgrad, *search, *Jaref; REAL gauss, cost, prev_cost; } sctx;
-typedef struct { REAL alpha, cost, deriv0, deriv1; } lspoint;
+typedef struct { REAL alpha, cost, deriv0, deriv1, q1, q2; } lspoint;
 
 static void update_constraint(const amxo_model *m, amxo_data *d, sctx *c) {
   int nv = m->nv, ne = d->nefc;
@@ -1255,9 +1271,35 @@ static lspoint ls_point(const amxo_data *d, const sctx *c, const REAL *jv, const
   p.cost = alpha * alpha * q2 + alpha * q1 + q0;
   p.deriv0 = 2 * alpha * q2 + q1;
   p.deriv1 = 2 * q2 + (q2 == 0 ? MINVAL : 0);
+  p.q1 = q1; p.q2 = q2;
   return p;
 }
-static void linesearch(const amxo_model *m, amxo_data *d, sctx *c) {
+/* sum over the rows of q0_row(alpha) - q0_row(0), each difference formed before it is added: exactly zero for every row whose
+ * activity (friction rows: zone) is the same at alpha as at 0 [amx_kernels.hip: Env::linesearch, "q0l - q0_start"] */
+static REAL ls_q0_delta(const amxo_data *d, const sctx *c, const REAL *jv, REAL alpha) {
+  REAL s = 0;
+  for (int r = 0; r < d->nefc; r++) {
+    REAL z = c->Jaref[r], x = z + alpha * jv[r], D = d->efc_D[r], qa, qz;
+    if (d->efc_floss[r] > 0) {
+      REAL f = d->efc_floss[r], rf = f / D;
+      qa = x <= -rf ? f * (-(REAL)0.5 * rf - z) : (x >= rf ? f * (-(REAL)0.5 * rf + z) : (REAL)0.5 * z * z * D);
+      qz = z <= -rf ? f * (-(REAL)0.5 * rf - z) : (z >= rf ? f * (-(REAL)0.5 * rf + z) : (REAL)0.5 * z * z * D);
+    } else {
+      REAL q = (REAL)0.5 * z * z * D;
+      qa = (x < 0 || r < d->ne) ? q : 0;
+      qz = (z < 0 || r < d->ne) ? q : 0;
+    }
+    s += qa - qz;
+  }
+  return s;
+}
+/* the next trial point of the 1-D Newton iteration on the derivative; rule bit 1: reciprocal and multiply, d1 clamped from below */
+static inline REAL ls_next_alpha(const amxo_model *m, const lspoint *p) {
+  if (m->ls_rule & 2) { REAL d1 = r_max(p->deriv1, MINVAL); return p->alpha - p->deriv0 * ((REAL)1 / d1); }
+  return p->alpha - p->deriv0 / p->deriv1;
+}
+/* returns the cost decrease of the accepted step as the search itself knows it (0: no step) - the solver's `improvement` under rule bit 0 */
+static REAL linesearch(const amxo_model *m, amxo_data *d, sctx *c) {
   int nv = m->nv, ne = d->nefc;
   REAL *mv = d->w_e, *jv = d->w_jv;
   REAL sn = 0;
@@ -1276,7 +1318,7 @@ static void linesearch(const amxo_model *m, amxo_data *d, sctx *c) {
     qg[2] += (REAL)0.5 * c->search[i] * mv[i];
   }
   lspoint p0 = ls_point(d, c, jv, qg, 0);
-  lspoint lo = ls_point(d, c, jv, qg, p0.alpha - p0.deriv0 / p0.deriv1), hi;
+  lspoint lo = ls_point(d, c, jv, qg, ls_next_alpha(m, &p0)), hi;
   if (lo.deriv0 < p0.deriv0) { hi = p0; } else { hi = lo; lo = p0; }
   int swap = 1, it = 0;
   while (1) {
@@ -1285,8 +1327,8 @@ static void linesearch(const amxo_model *m, amxo_data *d, sctx *c) {
     done |= (lo.deriv0 < 0) && (lo.deriv0 > -gtol);
     done |= (hi.deriv0 > 0) && (hi.deriv0 < gtol);
     if (done) break;
-    lspoint lo_next = ls_point(d, c, jv, qg, lo.alpha - lo.deriv0 / lo.deriv1);
-    lspoint hi_next = ls_point(d, c, jv, qg, hi.alpha - hi.deriv0 / hi.deriv1);
+    lspoint lo_next = ls_point(d, c, jv, qg, ls_next_alpha(m, &lo));
+    lspoint hi_next = ls_point(d, c, jv, qg, ls_next_alpha(m, &hi));
     lspoint mid = ls_point(d, c, jv, qg, (REAL)0.5 * (lo.alpha + hi.alpha));
     int s_lo_next = (lo.deriv0 > 0) || (lo.deriv0 < lo_next.deriv0);
     if (s_lo_next) lo = lo_next;
@@ -1299,12 +1341,51 @@ static void linesearch(const amxo_model *m, amxo_data *d, sctx *c) {
     swap = s_lo_next | s_lo_mid | s_hi_next | s_hi_mid;
     it++;
   }
-  int improved = (lo.cost < p0.cost) || (hi.cost < p0.cost);
-  REAL alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
+  /* rule 0 [mjx:solver._linesearch]: both sides carry the whole constant term */
+  int improved0 = (lo.cost < p0.cost) || (hi.cost < p0.cost);
+  int pick_lo0 = lo.cost < hi.cost;
+  /* rule bit 0 [amx_kernels.hip: Env::linesearch]: the decrease itself, constant terms differenced per row */
+  int improved1 = improved0, pick_lo1 = pick_lo0;
+  REAL lo_delta = lo.cost - p0.cost, hi_delta = hi.cost - p0.cost;
+  REAL dl1 = 0, dh1 = 0;
+  if ((m->ls_rule & 1) || m->ls_stats_on) {
+    REAL ql, qh;
+    if (m->ls_rule & 2) { /* alpha^2 q2 + alpha q1 = alpha d0 - alpha^2 d1 / 2, from the ends' own derivatives */
+      ql = lo.alpha * (lo.deriv0 - (REAL)0.5 * lo.alpha * lo.deriv1);
+      qh = hi.alpha * (hi.deriv0 - (REAL)0.5 * hi.alpha * hi.deriv1);
+    } else { /* the same quadratic from the ends' summed coefficients */
+      ql = lo.alpha * lo.alpha * lo.q2 + lo.alpha * lo.q1;
+      qh = hi.alpha * hi.alpha * hi.q2 + hi.alpha * hi.q1;
+    }
+    REAL dl = ql + ls_q0_delta(d, c, jv, lo.alpha), dh = qh + ls_q0_delta(d, c, jv, hi.alpha);
+    improved1 = (dl < 0) || (dh < 0);
+    pick_lo1 = dl < dh;
+    dl1 = dl; dh1 = dh;
+    if (m->ls_rule & 1) { lo_delta = dl; hi_delta = dh; }
+  }
+  if (m->ls_stats_on) {
+    d->ls_stat[0]++; d->ls_stat[1] += improved0; d->ls_stat[2] += improved1;
+    d->ls_stat[3] += improved0 != improved1;
+    d->ls_differed |= improved0 != improved1;
+    if (improved0 != improved1) {
+      double dec = fabs((double)r_min(dl1, dh1)) / fmax(fabs((double)p0.cost), 1e-300);
+      if (dec > d->ls_acc_max) d->ls_acc_max = dec;
+    }
+    if (improved0 && improved1 && pick_lo0 != pick_lo1 && lo.alpha != hi.alpha) {
+      double a = (double)(lo.cost - p0.cost), b = (double)(hi.cost - p0.cost);
+      double gap = fabs(a - b) / fmax(fmax(fabs(a), fabs(b)), 1e-300);
+      d->ls_stat[6]++;
+      if (gap > d->ls_gap_max) d->ls_gap_max = gap;
+    }
+  }
+  int improved = (m->ls_rule & 1) ? improved1 : improved0;
+  int pick_lo = (m->ls_rule & 1) ? pick_lo1 : pick_lo0;
+  REAL alpha = pick_lo ? lo.alpha : hi.alpha;
   if (improved) {
     for (int i = 0; i < nv; i++) { c->qacc[i] += alpha * c->search[i]; c->Ma[i] += alpha * mv[i]; }
     for (int r = 0; r < ne; r++) c->Jaref[r] += alpha * jv[r];
   }
+  return improved ? -r_min(lo_delta, hi_delta) : 0;
 }
 static REAL ctx_cost_at(const amxo_model *m, amxo_data *d, sctx *c, const REAL *qacc) {
   int nv = m->nv;
@@ -1335,16 +1416,32 @@ static void solve(const amxo_model *m, amxo_data *d) {
   REAL scale = m->meaninertia * (REAL)(nv > 1 ? nv : 1);
   REAL *prev_grad = d->w_f, *prev_Mgrad = d->w_g;
   int niter = 0;
+  REAL improvement = (REAL)INFINITY; /* rule bit 0: the accepted step's decrease as the line search knows it, instead of prev_cost - cost */
   while (1) {
     if (m->iterations != 1 || niter > 0) { /* iterations==1 runs the body once unconditionally */
       REAL gn = 0;
       for (int i = 0; i < nv; i++) gn += c.grad[i] * c.grad[i];
       int done = niter >= m->iterations;
-      done |= ((c.prev_cost - c.cost) / scale) < m->tolerance;
-      done |= (r_sqrt(gn) / scale) < m->tolerance;
+      REAL imp = (m->ls_rule & 1) ? improvement : c.prev_cost - c.cost;
+      if (m->ls_stats_on && niter > 0 && niter < m->iterations) { /* both forms of the improvement against the threshold */
+        REAL i0 = c.prev_cost - c.cost, i1 = improvement, ts = scale * m->tolerance;
+        if ((i0 < ts) != (i1 < ts)) {
+          double gap = fabs((double)(i0 - i1)) / fmax(fmax(fabs((double)c.cost), fabs((double)c.prev_cost)), (double)ts);
+          d->ls_stat[8]++;
+          if (gap > d->ls_stop_max) d->ls_stop_max = gap;
+        }
+      }
+      if (m->ls_rule & 2) { /* multiplied out [amx_kernels.hip: Env::solve] */
+        REAL ts = scale * m->tolerance;
+        done |= imp < ts;
+        done |= gn < ts * ts;
+      } else {
+        done |= (imp / scale) < m->tolerance;
+        done |= (r_sqrt(gn) / scale) < m->tolerance;
+      }
       if (done) break;
     }
-    linesearch(m, d, &c);
+    improvement = linesearch(m, d, &c);
     memcpy(prev_grad, c.grad, sizeof(REAL) * nv); memcpy(prev_Mgrad, c.Mgrad, sizeof(REAL) * nv);
     update_constraint(m, d, &c);
     update_gradient(m, d, &c);
@@ -1360,6 +1457,7 @@ static void solve(const amxo_model *m, amxo_data *d) {
     if (m->iterations == 1) break;
   }
   d->solver_niter = niter;
+  if (m->ls_stats_on) { d->ls_stat[4] += niter; d->ls_stat[5]++; d->ls_stat[7] += d->ls_differed; d->ls_differed = 0; }
   memcpy(d->qacc_warmstart, d->qacc, sizeof(REAL) * nv);
 }
 
@@ -1453,7 +1551,29 @@ int amxo_get(const amxo_model *m, const amxo_data *d, const char *name, REAL *ou
   memcpy(out, src, sizeof(REAL) * n);
   return n;
 }
+/* ls_rule / ls_stats: test-side switches of a model handle (not thread-safe against a running rollout) */
+int amxo_model_set_int(amxo_model *m, const char *name, int v) {
+  if (!strcmp(name, "ls_rule")) { m->ls_rule = v; return 0; }
+  if (!strcmp(name, "ls_stats")) { m->ls_stats_on = v; memset(m->ls_stat, 0, sizeof(m->ls_stat)); m->ls_gap_max = 0; m->ls_acc_max = 0; m->ls_stop_max = 0; return 0; }
+  return -1;
+}
+void amxo_ls_stats(const amxo_model *m, long long *out, double *gap_max) { memcpy(out, m->ls_stat, sizeof(m->ls_stat)); if (gap_max) { gap_max[0] = m->ls_gap_max; gap_max[1] = m->ls_acc_max; gap_max[2] = m->ls_stop_max; } }
+/* folds one data block's counters into its model's (amxo_rollout does it per thread; single-env users call it themselves) */
+void amxo_ls_stats_flush(amxo_model *m, amxo_data *d) {
+#ifdef _OPENMP
+#pragma omp critical(amxo_ls_stats)
+#endif
+  {
+    for (int i = 0; i < 12; i++) { m->ls_stat[i] += d->ls_stat[i]; d->ls_stat[i] = 0; }
+    if (d->ls_stop_max > m->ls_stop_max) m->ls_stop_max = d->ls_stop_max;
+    d->ls_stop_max = 0;
+    if (d->ls_gap_max > m->ls_gap_max) m->ls_gap_max = d->ls_gap_max;
+    if (d->ls_acc_max > m->ls_acc_max) m->ls_acc_max = d->ls_acc_max;
+    d->ls_gap_max = 0; d->ls_acc_max = 0;
+  }
+}
 int amxo_model_int(const amxo_model *m, const char *name) {
+  if (!strcmp(name, "ls_rule")) return m->ls_rule;
   if (!strcmp(name, "ncon")) return m->ncon;
   if (!strcmp(name, "nefc_max")) return m->nefc_max;
   if (!strcmp(name, "nq")) return m->nq;
@@ -1489,6 +1609,7 @@ int amxo_rollout(const amxo_model *m, int nenv, int nsteps, const REAL *x0, int 
         if (out) { memcpy(out + (size_t)(t + 1) * nx, d->qpos, sizeof(REAL) * m->nq); memcpy(out + (size_t)(t + 1) * nx + m->nq, d->qvel, sizeof(REAL) * m->nv); }
       }
     }
+    if (m->ls_stats_on) amxo_ls_stats_flush((amxo_model *)m, d);
     amxo_data_destroy(d);
   }
   return 0;

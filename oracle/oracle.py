@@ -42,6 +42,9 @@ def _lib(dtype):
         lib.amxo_model_int.argtypes = [C.c_void_p, C.c_char_p]
         lib.amxo_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         lib.amxo_max_threads.restype = C.c_int
+        lib.amxo_model_set_int.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        lib.amxo_ls_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.amxo_ls_stats_flush.argtypes = [C.c_void_p, C.c_void_p]
         _LIBS[key] = lib
     return _LIBS[key]
 
@@ -49,9 +52,13 @@ def _lib(dtype):
 class Oracle:
     """One model + one scratch data block in the chosen precision."""
 
-    def __init__(self, mj_model, dtype=np.float64, variant=None):
+    def __init__(self, mj_model, dtype=np.float64, variant=None, ls_rule=0, ls_stats=False):
         """variant: None (portable -O2 build), "native" (fp32, -O3 -march=native, `make -C oracle native` on this host) or
-        "count" (flop census build: fp64 arithmetic through a counting scalar)."""
+        "count" (flop census build: fp64 arithmetic through a counting scalar).
+        ls_rule: 0 = MJX's line-search formulation (the statement of record); 1 = the HIP kernel's acceptance rule (the step's
+        decrease with the constant terms differenced per row; that decrease is the solver's improvement); 3 = that rule with the
+        kernel's arithmetic around it (reciprocal trial points, multiplied-out stopping tests).  ls_stats: count, per line search,
+        what either acceptance rule decides (ls_stats())."""
         self.dtype = np.dtype(np.float32 if variant == "native" else (np.float64 if variant == "count" else dtype))
         self.lib = _lib(variant or dtype)
         self.variant = variant
@@ -63,6 +70,10 @@ class Oracle:
         self.d = self.lib.amxo_data_create(self.m)
         self.nq, self.nv, self.nu = mj_model.nq, mj_model.nv, mj_model.nu
         self.ncon = self.lib.amxo_model_int(self.m, b"ncon")
+        if ls_rule:
+            self.lib.amxo_model_set_int(self.m, b"ls_rule", int(ls_rule))
+        if ls_stats:
+            self.lib.amxo_model_set_int(self.m, b"ls_stats", 1)
         self.nefc_max = self.lib.amxo_model_int(self.m, b"nefc_max")
 
     def __del__(self):
@@ -106,6 +117,25 @@ class Oracle:
         xs = np.zeros((nenv, N + 1, self.nq + self.nv), dtype=self.dtype)
         self.lib.amxo_rollout(self.m, nenv, N, x0.ctypes.data, batched, us.ctypes.data, xs.ctypes.data, int(nthreads))
         return xs
+
+    def ls_stats(self):
+        """Counters since construction (ls_stats=True), both acceptance rules evaluated at the end of every line search:
+        line searches, steps accepted by MJX's rule, steps accepted by the kernel's rule, accept decisions that differ, Newton
+        iterations, solver calls (= env-steps + forwards), line searches where both accept but pick different bracket ends,
+        solver calls with at least one differing accept decision, stopping tests (`improvement < tolerance * scale`) that come
+        out differently for `prev_cost - cost` and for the line search's own decrease; end_gap_max: the largest relative gap between the two
+        ends' decreases among those differing picks (ties, when it is rounding-sized); accept_differ_decrease_max: the largest
+        step decrease relative to cost(0) among the differing accept decisions (what the full-cost comparison could not resolve)."""
+        self.lib.amxo_ls_stats_flush(self.m, self.d)
+        out = (C.c_longlong * 12)()
+        gap = (C.c_double * 3)()
+        self.lib.amxo_ls_stats(self.m, out, gap)
+        k = ("linesearches", "accept_mjx_rule", "accept_kernel_rule", "accept_differ", "newton_iterations", "solves", "end_pick_differ", "solves_affected", "stop_differ")
+        r = dict(zip(k, list(out)))
+        r["end_gap_max"] = gap[0]
+        r["stop_differ_gap_max"] = gap[2]  # largest |(prev_cost - cost) - decrease| / |cost| among the differing stopping tests
+        r["accept_differ_decrease_max"] = gap[1]  # largest |decrease| / |cost(0)| among the differing accept decisions
+        return r
 
     def max_threads(self):
         return self.lib.amxo_max_threads()

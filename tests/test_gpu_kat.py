@@ -208,6 +208,10 @@ def test_parity_per_horizon(dev):
             # the committed 256-env table (profiles/r02_parity_horizons.txt) is the record
             fm, ff = (2, 0.1) if h <= 10 else ((4, 0.15) if h <= 100 else (10, 0.15))
             assert r["gpu_fp32_median"] <= fm * r["cpu_fp32_median"] + 1e-6, (name, h, r)
+            # r04: the same against the fp32 CPU oracle that runs the KERNEL's line-search rule and arithmetic (ls_rule 3,
+            # tests/test_ls_rule.py) - the build of the checker that states the algorithm the HIP path runs
+            print(f"    cpu fp32 kernel-rule median {r['cpu_krule_median']:.2e} max {r['cpu_krule_max']:.2e} | gpu vs k-rule {r['gpu_vs_krule_median']:.2e} vs MJX-rule {r['gpu_vs_mjxrule_median']:.2e}")
+            assert r["gpu_fp32_median"] <= fm * r["cpu_krule_median"] + 1e-6, (name, h, r)
             assert abs(r["gpu_within_1e-5_frac"] - r["cpu_within_1e-5_frac"]) <= ff, (name, h, r)
             if h <= 10:
                 assert r["gpu_fp32_max"] <= 4 * r["cpu_fp32_max"] + 2e-6, (name, h, r)

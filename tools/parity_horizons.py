@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Parity per horizon: for C1 (pendulum), C2 (quadruped) and C3 (biped), the
 distance of the GPU fp32 rollout and of the CPU oracle's fp32 rollout to the CPU oracle's fp64 rollout, on the same
-seeded inputs, at N = 1, 10, 100, 1000 steps.
+seeded inputs, at N = 1, 10, 100, 1000 steps.  Since r04 the fp32 CPU oracle appears twice: with MJX's line-search
+formulation (ls_rule 0, the statement of record) and with the kernel's acceptance rule and arithmetic (ls_rule 3,
+oracle/amx_oracle.c; tests/test_ls_rule.py) - the column the GPU is expected to sit on.
 
     python tools/parity_horizons.py [--nenv 256] [--out profiles/r02_parity_horizons.txt]
 
@@ -52,6 +54,7 @@ def measure(path, nenv, horizons=HORIZONS, seed=7, gpu=True):
     x0, us = inputs(mj, nenv, N, seed)
     ref = Oracle(mj, np.float64).rollout(x0, us)
     o32 = Oracle(mj, np.float32).rollout(x0, us).astype(np.float64)
+    k32 = Oracle(mj, np.float32, ls_rule=3).rollout(x0, us).astype(np.float64)
     rows = {}
     xg = None
     if gpu:
@@ -61,11 +64,16 @@ def measure(path, nenv, horizons=HORIZONS, seed=7, gpu=True):
         xg = mjx.rollout(model, torch.tensor(x0), torch.tensor(us)).cpu().numpy()
     for h in horizons:
         f = env_err(o32, ref, h)
-        rows[h] = {"cpu_fp32_median": float(np.median(f)), "cpu_fp32_max": float(f.max())}
+        k = env_err(k32, ref, h)
+        rows[h] = {"cpu_fp32_median": float(np.median(f)), "cpu_fp32_max": float(f.max()), "cpu_within_1e-5_frac": float((f <= 1e-5).mean()),
+                   "cpu_krule_median": float(np.median(k)), "cpu_krule_max": float(k.max()), "cpu_krule_within_1e-5_frac": float((k <= 1e-5).mean())}
         if xg is not None:
             g = env_err(xg, ref, h)
             rows[h].update({"gpu_fp32_median": float(np.median(g)), "gpu_fp32_max": float(g.max()),
-                            "gpu_within_1e-5_frac": float((g <= 1e-5).mean()), "cpu_within_1e-5_frac": float((f <= 1e-5).mean())})
+                            "gpu_within_1e-5_frac": float((g <= 1e-5).mean()),
+                            # the GPU against the fp32 CPU oracle that runs the kernel's rule (not against fp64): how closely the two
+                            # fp32 implementations of the SAME algorithm track each other
+                            "gpu_vs_krule_median": float(np.median(env_err(xg, k32, h))), "gpu_vs_mjxrule_median": float(np.median(env_err(xg, o32, h)))})
     return rows
 
 
@@ -76,14 +84,19 @@ def main():
     args = ap.parse_args()
     lines = [f"# parity per horizon: {args.nenv} envs per config, relative error of the state (qpos, qvel) vs the fp64 CPU oracle",
              "# err_e = max_i |x_N - ref_N| / max(1, max_i |ref_N|); median / max over envs; `<=1e-5` = fraction of envs within north_star's tolerance",
-             f"{'config':<14}{'N':>6} | {'GPU fp32 median':>16}{'GPU fp32 max':>14}{'<=1e-5':>8} | {'CPU fp32 median':>16}{'CPU fp32 max':>14}{'<=1e-5':>8}"]
+             "# CPU fp32 = the oracle in single precision with MJX's line-search rule; CPU fp32 k-rule = the same with the kernel's acceptance rule and arithmetic (ls_rule 3)",
+             "# GPU-vs = median distance of the GPU rollout to either fp32 CPU rollout (not to fp64)",
+             f"{'config':<14}{'N':>6} | {'GPU fp32 median':>16}{'GPU fp32 max':>14}{'<=1e-5':>8} | {'CPU fp32 median':>16}{'CPU fp32 max':>14}{'<=1e-5':>8} | "
+             f"{'CPU k-rule median':>18}{'k-rule max':>14}{'<=1e-5':>8} | {'GPU-vs-k-rule':>14}{'GPU-vs-MJX-rule':>16}"]
     blob = {}
     for name, path in CONFIGS:
         rows = measure(path, args.nenv)
         blob[name] = rows
         for h, r in rows.items():
             lines.append(f"{name:<14}{h:>6} | {r['gpu_fp32_median']:>16.3e}{r['gpu_fp32_max']:>14.3e}{r['gpu_within_1e-5_frac']:>8.2f} | "
-                         f"{r['cpu_fp32_median']:>16.3e}{r['cpu_fp32_max']:>14.3e}{r['cpu_within_1e-5_frac']:>8.2f}")
+                         f"{r['cpu_fp32_median']:>16.3e}{r['cpu_fp32_max']:>14.3e}{r['cpu_within_1e-5_frac']:>8.2f} | "
+                         f"{r['cpu_krule_median']:>18.3e}{r['cpu_krule_max']:>14.3e}{r['cpu_krule_within_1e-5_frac']:>8.2f} | "
+                         f"{r['gpu_vs_krule_median']:>14.3e}{r['gpu_vs_mjxrule_median']:>16.3e}")
     text = "\n".join(lines)
     print(text)
     print(json.dumps(blob))
