@@ -258,6 +258,25 @@ def forward(m: Model, d: Data) -> Data:
                      qacc_warmstart=s(warm_out), qvel=s(qvel), ctrl=s(ctrl), time=time)
 
 
+def constraint_activity(m: Model, qpos: torch.Tensor, qvel: torch.Tensor, ctrl: torch.Tensor):
+    """What the constraint set of a batch of states looks like: one amx_forward launch, returning
+    (contact_dist [n, ncon] - the signed distance of every contact slot, >= 0 or the inactive marker when the slot holds no
+    contact - and nefc [n] - rows that entered the solve, i.e. D > 0: violated limits, equality rows, the pyramid rows of
+    contacts inside their margin).  bench.py reports these beside the throughput (the kernel skips the matrix-core work of rows
+    that are idle in both environments of a wave, so cost depends on them)."""
+    d = Data(qpos=qpos, qvel=qvel, ctrl=ctrl, qacc=None, qacc_warmstart=torch.zeros_like(qvel), time=None, qacc_smooth=None, qfrc_bias=None,
+             qfrc_constraint=None, xpos=None, xquat=None)
+    _, n, t = _prep(m, d, ("qpos", "qvel", "ctrl", "qacc_warmstart"))
+    dev = m.device
+    dist = torch.empty((n, max(1, m.ncon)), dtype=torch.float32, device=dev)
+    nefc = torch.empty((n,), dtype=torch.int32, device=dev)
+    out = _lib.AmxForwardOut(None, None, None, None, None, None, None, dist.data_ptr(), nefc.data_ptr())
+    with torch.cuda.device(dev):
+        _lib.check(m._h.L.amx_forward(m._h.ptr, n, t["qpos"].data_ptr(), t["qvel"].data_ptr(), t["ctrl"].data_ptr(), t["qacc_warmstart"].data_ptr(),
+                                          C.byref(out), _stream_ptr(dev)), m._h.L)
+    return dist[:, :m.ncon], nefc
+
+
 def step(m: Model, d: Data, nsub: int = 1) -> Data:
     """mjx.step, `nsub` times with ctrl held (reference ambersim/rl/base.py:88-96).  Functional: returns new Data."""
     b, n, t = _prep(m, d, ("qpos", "qvel", "ctrl", "qacc_warmstart"))

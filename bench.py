@@ -99,6 +99,31 @@ def make_inputs(mj, nenv, horizon, seed_state, seed_ctrl, device):
     return torch.tensor(x0, device=device), us
 
 
+def activity_stats(model, mj, xs, us, nenv_sample=512, every=25):
+    """What the workload physically did - outside any timed region.  From the returned trajectories: the lowest and the mean final
+    height of the floating base (qpos[2]) and the fraction of env-steps with the base below the floor; from one amx_forward launch
+    over a sample of the visited states (the first `nenv_sample` envs at every `every`-th step, with the control applied there): mean
+    contacts in touch (dist < 0) per env-step of the model's ncon slots, and mean rows in the constraint set (D > 0: violated
+    limits + pyramid rows of contacts inside the margin) of its nefc_max."""
+    import torch
+    from ambersim_amd import mjx
+    n, T = xs.shape[0], xs.shape[1] - 1
+    out = {}
+    if mj.nq >= 7 and mj.jnt_type[0] == 0:
+        z = xs[:, :, 2]
+        out.update({"base_z_min": float(z.min().item()), "base_z_final_mean": float(z[:, -1].mean().item()),
+                    "frac_env_steps_base_below_floor": float((z < 0).float().mean().item())})
+    ns = min(n, nenv_sample)
+    ts = torch.arange(0, T, every, device=xs.device)
+    st = xs[:ns][:, ts].reshape(-1, xs.shape[2])
+    ct = us[:ns][:, ts].reshape(-1, us.shape[2])
+    dist, nefc = mjx.constraint_activity(model, st[:, :mj.nq].contiguous(), st[:, mj.nq:].contiguous(), ct.contiguous())
+    out.update({"contacts_touching_mean": float((dist < 0).sum(dim=1).float().mean().item()), "contact_slots": int(mj.ncon),
+                "constraint_rows_mean": float(nefc.float().mean().item()), "constraint_rows_max": int(model.nefc_max),
+                "sampled_states": int(st.shape[0])})
+    return out
+
+
 def pmc_record(model_path, nenv, horizon):
     """Recorded (NOT measured by this run) rocprofv3 PMC figures of the rollout kernel for the default workloads, from the
     newest committed profiles/rNN_rocprofv3_pmc_<model>.csv (tools/pmc_collect.sh: one counter per pass).  gfx950

@@ -211,7 +211,13 @@ def test_parity_per_horizon(dev):
             # r04: the same against the fp32 CPU oracle that runs the KERNEL's line-search rule and arithmetic (ls_rule 3,
             # tests/test_ls_rule.py) - the build of the checker that states the algorithm the HIP path runs
             print(f"    cpu fp32 kernel-rule median {r['cpu_krule_median']:.2e} max {r['cpu_krule_max']:.2e} | gpu vs k-rule {r['gpu_vs_krule_median']:.2e} vs MJX-rule {r['gpu_vs_mjxrule_median']:.2e}")
-            assert r["gpu_fp32_median"] <= fm * r["cpu_krule_median"] + 1e-6, (name, h, r)
+            # (medians up to N = 10: at N = 100 the biped is at the onset of its contact chaos and a 64-env median moves by decades between
+            # any two fp32 runs; the committed 256-env table profiles/r04_parity_horizons.txt shows the GPU within 3.4e-5 of this oracle
+            # at N = 100 where it is 5.5e-2 from the MJX-rule one)
+            if h <= 10:
+                assert r["gpu_fp32_median"] <= fm * r["cpu_krule_median"] + 1e-6, (name, h, r)
+                assert r["gpu_vs_krule_median"] <= 2 * r["cpu_krule_median"] + 1e-6, (name, h, r)  # the two fp32 runs of one algorithm track each other
+            assert abs(r["gpu_within_1e-5_frac"] - r["cpu_krule_within_1e-5_frac"]) <= ff, (name, h, r)
             assert abs(r["gpu_within_1e-5_frac"] - r["cpu_within_1e-5_frac"]) <= ff, (name, h, r)
             if h <= 10:
                 assert r["gpu_fp32_max"] <= 4 * r["cpu_fp32_max"] + 2e-6, (name, h, r)
