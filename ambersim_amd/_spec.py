@@ -135,6 +135,12 @@ def _hipcc_id(hipcc: str) -> str:
     return _HIPCC_ID[hipcc]
 
 
+def _extra_flags():
+    """AMX_SPEC_FORCE_FALLBACK=1: build with the crash-fallback flags from the start (tests/test_gpu_parity.py runs that build
+    against the oracle, so the instruction mix a compiler crash would silently switch to is a tested one)."""
+    return list(CRASH_FALLBACK_FLAGS) if os.environ.get("AMX_SPEC_FORCE_FALLBACK", "0") not in ("", "0") else []
+
+
 def specialised_library_path(mj):
     """(path, header text) of the per-model build of `mj`: keyed by the record, the sources, the compile flags, the
     architecture and the compiler's version string."""
@@ -144,9 +150,16 @@ def specialised_library_path(mj):
     h = hashlib.sha256(header.encode())
     for f in srcs:
         h.update(f.read_bytes())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(FLAGS + _extra_flags()).encode())
     h.update(_hipcc_id(hipcc).encode())
     return cache_dir() / f"libamx_{h.hexdigest()[:16]}.so", header
+
+
+# What a per-model build is retried with when the compiler itself crashes (see build_specialised_library): the packed-fp32 forms
+# off.  tests/test_abi.py::test_compiler_crash_fallback_is_pinned holds the plan that needs it and checks that these two macros
+# gate nothing but the packed spellings of the same sums.
+CRASH_FALLBACK_FLAGS = ("-DAMX_PK_SV=0", "-DAMX_PK_DOT=0")
+_LAST_BUILD = {"path": None, "fallback": False}  # what the last compile in this process did (tests, logs)
 
 
 def build_specialised_library(mj, verbose: bool = False) -> Path:
@@ -167,13 +180,18 @@ def build_specialised_library(mj, verbose: bool = False) -> Path:
         os.replace(tmp_h, hdr)
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         tmp = _unique_tmp(out)
-        cmd = [hipcc] + FLAGS + [f'-DAMX_SPECS_HEADER="{hdr}"', "-DAMX_NO_GENERIC=1", "-no-hip-rt", "-shared", "-o", str(tmp), "-x", "hip", str(_CSRC / "amx_api.cpp")]
+        cmd = [hipcc] + _extra_flags() + FLAGS + [f'-DAMX_SPECS_HEADER="{hdr}"', "-DAMX_NO_GENERIC=1", "-no-hip-rt", "-shared", "-o", str(tmp), "-x", "hip", str(_CSRC / "amx_api.cpp")]
         r = subprocess.run(cmd, capture_output=True, text=True, cwd=str(_CSRC))
-        if r.returncode != 0 and "frontend command failed due to signal" in r.stderr:
+        _LAST_BUILD.update(path=str(out), fallback=False)
+        if r.returncode != 0 and "frontend command failed due to signal" in r.stderr and os.environ.get("AMX_SPEC_NO_RETRY", "0") in ("", "0"):
             # ROCm 7.2's register allocator has crashed on one plan's packed-fp32 spatial sums (r03: a 16-lane model with two free
             # bodies); the same kernels with those sums as scalar instructions compile.  Same arithmetic, the same HIP path.
             first = r.stderr
-            cmd = cmd[:1] + ["-DAMX_PK_SV=0", "-DAMX_PK_DOT=0"] + cmd[1:]
+            cmd = cmd[:1] + list(CRASH_FALLBACK_FLAGS) + cmd[1:]
+            _LAST_BUILD.update(fallback=True)
+            import logging
+            logging.getLogger("ambersim_amd").warning("hipcc crashed on this model's kernels (%s); rebuilding with %s", first.strip().splitlines()[-1][:120] if first.strip() else "",
+                                                      " ".join(CRASH_FALLBACK_FLAGS))
             r = subprocess.run(cmd, capture_output=True, text=True, cwd=str(_CSRC))
             if r.returncode != 0:
                 r.stderr = first[-1000:] + "\n--- retry without packed fp32 ---\n" + r.stderr

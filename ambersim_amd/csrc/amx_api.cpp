@@ -153,6 +153,33 @@ extern "C" int amx_model_destroy(amx_model *m) {
   return AMX_OK;
 }
 
+// "simd_pairing": do waves w and w + 4 of an 8-wave workgroup run on one SIMD on this device?  One probe launch per device (one
+// workgroup per CU, 512 threads), cached: 1 yes on every workgroup, 0 no (the rollout kernel then leaves the pair to the
+// hardware's arbitration: it re-checks per step), -1 the probe could not run.
+static int simd_pairing(int device, int ncu) {
+  static int cache[64];
+  static bool have[64];
+  if (device < 0 || device >= 64) return -1;
+  if (have[device]) return cache[device];
+  int verdict = -1;
+  const int nwg = ncu > 0 ? ncu : 256;
+  int *d = nullptr;
+  std::vector<int> h((size_t)nwg * 8, -1);
+  if (hipMalloc(&d, h.size() * sizeof(int)) == hipSuccess) {
+    hipLaunchKernelGGL(amx_simd_probe_kernel, dim3(nwg), dim3(512), 0, 0, d);
+    if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(h.data(), d, h.size() * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess) {
+      verdict = 1;
+      for (int b = 0; b < nwg; b++)
+        for (int w = 0; w < 4; w++)
+          if (h[(size_t)b * 8 + w] < 0 || h[(size_t)b * 8 + w] != h[(size_t)b * 8 + w + 4]) verdict = 0;
+    }
+    (void)hipFree(d);
+  }
+  cache[device] = verdict;
+  have[device] = true;
+  return verdict;
+}
+
 extern "C" int amx_model_query(const amx_model *m, const char *name, int *out) {
   if (!m || !name || !out) return fail(AMX_EINVAL, "null argument");
   std::string n(name);
@@ -168,6 +195,7 @@ extern "C" int amx_model_query(const amx_model *m, const char *name, int *out) {
   else if (n == "env_slab_bytes") *out = m->dev.env_floats * 4;
   else if (n == "const_bytes") *out = m->dev.nconst * 4;
   else if (n == "specialised") *out = m->spec >= 0 ? 1 : 0;
+  else if (n == "simd_pairing") { AMX_ON_DEVICE(m->device); *out = simd_pairing(m->device, m->ncu); }
   else return fail(AMX_EINVAL, "unknown query '%s'", name);
   return AMX_OK;
 }

@@ -797,7 +797,7 @@ template <int G> DEV RowPair row_pair(float c) {
   if constexpr (G == 16) {
     return RowPair{c, c};  // the first DPP reader (sym_pivot's v_max_f32_dpp) carries the wait states itself
   } else {
-    static_assert(G == 32, "row_pair: 16- or 32-lane groups");
+    static_assert(G == 32 || G == 64, "row_pair: 16-, 32- or 64-lane groups (the matrix rows of a 64-lane group sit in its first two DPP rows)");
     const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(c), __float_as_uint(c), false, false);
     return RowPair{__uint_as_float(sw[0]), __uint_as_float(sw[1])};
   }
@@ -951,7 +951,12 @@ template <class S, int G, bool TREE, bool BCOL> DEV void sym_eliminate(float (&a
   if constexpr (TREE) SymTree<S, G, 0, BCOL>::run(a, gl, diag, pm0, pm);
   else SymDense<S, G, 0, BCOL>::run(a, gl, diag, pm0, pm);
 }
-template <class S, int G> constexpr bool sym_elim_ok() { return S::is_static && G <= 32 && S::nv < G && !AMX_NO_SYM_ELIM; }
+// (64-lane groups, r04: one environment per wave with its matrix rows in lanes 0..nv-1 < 32 - the same two DPP rows as a 32-lane
+// group; lanes 32..63 hold all-zero rows and compute on them, their results are never stored)
+#ifndef AMX_SYM_ELIM_64
+#define AMX_SYM_ELIM_64 1  // 0: static 64-lane kernels keep the v_readlane eliminations (A/B switch)
+#endif
+template <class S, int G> constexpr bool sym_elim_ok() { return S::is_static && (G <= 32 ? S::nv < G : (AMX_SYM_ELIM_64 && S::nv < 32)) && !AMX_NO_SYM_ELIM; }
 
 template <class S, int G, bool TREE>
 AMX_STATIC_SOLVE_ATTR void spd_solve_static(int A_off, int rhs_off, int x_off, int gl, int rot, int bt_off) {
@@ -959,7 +964,7 @@ AMX_STATIC_SOLVE_ATTR void spd_solve_static(int A_off, int rhs_off, int x_off, i
   if constexpr (sym_elim_ok<S, G>()) {
     // bt_off: an idle vector of ld floats (the M*v staging vector) through which b reaches lane N as a row; < 0: none, b is
     // broadcast on its own (always so for 16-lane groups, where that costs nothing)
-    constexpr bool BCOL = G == 32;
+    constexpr bool BCOL = G >= 32;
     // the pivot-lane tests (gl == J) of one elimination are recomputed here (one v_cmp each): left loop-invariant, the thirty
     // masks were hoisted out of the step loop, held in scalar registers across it and spilled (two v_readlane per use)
     int gle = gl;
@@ -1037,7 +1042,7 @@ AMX_STATIC_SOLVE_ATTR bool newton_solve_fused(int M_off, int ld_, int n_, unsign
                                                 int rhs_off, int x_off, float dlim, int gl, int gb4, int rot, int bt_off, float flim = 0.0f, float ma_v = 0.0f,
                                                 float fs_v = 0.0f, int fcon_off = 0, bool store_ok = true, bool early_out = false, bool imp_done = false,
                                                 float scale = 1.0f, float tol = 0.0f, ProfCtx *pc = nullptr, bool *group_done = nullptr) {
-  if constexpr (sym_elim_ok<S, G>() && G == 32) {
+  if constexpr (sym_elim_ok<S, G>() && G >= 32) {
     // crossbar-free elimination (see sym_pivot): b reaches lane N as a row through the staging vector at bt_off
     constexpr int NS = S::nv, lds_ = S::ldm, nchs = lds_ / 4;
     int gle = gl;  // see spd_solve_static
@@ -3330,13 +3335,18 @@ amx_rollout_kernel(const DevModel m_in, int nenv, int nsteps, int x0_batched, co
   // contested issue slot: measured (r03, per-wave phase clocks) the older four waves of every workgroup ran a biped step in
   // 81 k cycles and the younger four in 99 k, and a launch ends with its slowest wave.  Each wave posts its step counter in
   // LDS; whichever of the pair is behind runs at raised priority for the step, so both advance at the same pace (~90 k).
+  // That waves w and w + 4 sit on one SIMD is how the hardware has dealt a workgroup's waves on every box measured, not a
+  // contract: each wave posts the SIMD it runs on (HW_ID bits 5:4, + 1) in the top byte of its counter word, and a wave whose
+  // presumed partner reports another SIMD never raises its priority - the pair falls back to the hardware's own arbitration
+  // (amx_model_query "simd_pairing" runs the same check as a probe launch and reports it).
   const bool paired = AMX_FAIR_SIMD && wpb == 8;
+  const int simd_tag = (int)((__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) + 1) << 24);  // hwreg(HW_REG_HW_ID, 4, 2) = SIMD_ID
   for (int t = -1; t < nsteps; ++t) {
     if (paired) {
       const int mine_ = t + 1;
-      if (lane == 0) lds[m.c_prog() + wave] = __int_as_float(mine_);
+      if (lane == 0) lds[m.c_prog() + wave] = __int_as_float(simd_tag | mine_);
       const int other_ = __builtin_amdgcn_readfirstlane(CI(m.c_prog() + (wave ^ 4)));
-      if (other_ > mine_) __builtin_amdgcn_s_setprio(3);
+      if (((other_ ^ simd_tag) >> 24) == 0 && (other_ & 0xFFFFFF) > mine_) __builtin_amdgcn_s_setprio(3);
       else __builtin_amdgcn_s_setprio(0);
     }
     if (t >= 0) {
@@ -3391,6 +3401,13 @@ amx_step_kernel(const DevModel m_in, int nenv, int nsub, const float *qpos, cons
     if (warm_out) warm_out[(size_t)e * nv + gl] = env.dof(Env<G, S>::D_WARM, gl);
   }
   if (time_out && gl == 0) time_out[e] = t0 + m.dt() * nsub;
+}
+
+// Which SIMD every wave of an 8-wave workgroup runs on (amx_model_query "simd_pairing": the fair-sharing logic of the rollout
+// kernel presumes waves w and w + 4 share one).  out[block * 8 + wave] = SIMD_ID.
+extern "C" __global__ void __launch_bounds__(512) amx_simd_probe_kernel(int *out) {
+  const int wave = threadIdx.x / AMX_WAVE;
+  if ((threadIdx.x & (AMX_WAVE - 1)) == 0) out[blockIdx.x * 8 + wave] = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);
 }
 
 struct ForwardOut { float *qacc, *qacc_smooth, *qfrc_bias, *qfrc_constraint, *qM, *xpos, *xquat, *cdist; int *nefc; };

@@ -112,13 +112,17 @@ class PeerCopyGather:
     a gloo group), and a gather is `world` asynchronous copies of the rank's block into slot `rank` of every peer's buffer on a
     side stream, ordered after the kernels already queued on the current stream.  `wait()` synchronises the side stream and meets
     the other ranks at a CPU (gloo) barrier: after it every rank's copies have landed, the buffer is complete.  Buffers rotate,
-    so at most `nbuf` gathers may be in flight.  Raises (at construction) if the IPC exchange or the probe transfer fails: the
-    caller falls back to the RCCL all-gather."""
+    so at most `nbuf` gathers may be in flight.  OWNERSHIP (r04): the tensor `wait()` returns is a view of one of the rotating
+    buffers, which the PEERS overwrite `nbuf` gathers later; it belongs to the caller until the handle's `release()` (or
+    `wait(copy=True)`, which returns a private copy and releases at once), and `start()` refuses - on every rank, through one gloo
+    reduction, so nobody hangs - to reuse a buffer that some rank still holds.  Raises (at construction) if the IPC exchange or the
+    probe transfer fails: the caller falls back to the RCCL all-gather."""
 
     def __init__(self, block_shape, dtype, device, nbuf: int = 2):
         from torch.multiprocessing.reductions import reduce_tensor
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self.device, self.nbuf, self.k = device, nbuf, 0
+        self.held = [False] * nbuf  # buffer b handed out by wait() and not yet released by this rank
         self.cpu_group = dist.new_group(backend="gloo")
         self.block_shape = tuple(block_shape)
 
@@ -176,6 +180,14 @@ class PeerCopyGather:
         """Starts the gather of `xs_local` (ordered after the current stream's queued work); returns the handle to wait on."""
         assert tuple(xs_local.shape) == self.block_shape, (tuple(xs_local.shape), self.block_shape)
         b = self.k % self.nbuf
+        if self.k >= self.nbuf:
+            # the peers are about to overwrite buffer b on EVERY rank: all of them must have let go of it.  One small CPU reduction
+            # (the ranks arrive here in step anyway: the previous wait() ended in a barrier); every rank sees the same verdict.
+            free = torch.tensor([0 if self.held[b] else 1], dtype=torch.int32)
+            dist.all_reduce(free, op=dist.ReduceOp.MIN, group=self.cpu_group)
+            if int(free.item()) == 0:
+                raise RuntimeError(f"peer-copy gather: buffer {b} is still held by a rank (a tensor returned by wait() {self.nbuf} gathers ago "
+                                   "was not released): call release() on that handle, or use wait(copy=True)")
         self.k += 1
         xs_local = xs_local.contiguous()
         ready = torch.cuda.Event()
@@ -204,13 +216,29 @@ class PendingPeerCopy:
     def __init__(self, owner, b, done):
         self.owner, self.b, self.done = owner, b, done
 
-    def wait(self) -> torch.Tensor:
-        """Blocks the host until every rank's block has landed in this rank's buffer; returns it as [world * nenv_local, ...]."""
+    def wait(self, copy: bool = False) -> torch.Tensor:
+        """Blocks the host until every rank's block has landed in this rank's buffer; returns it as [world * nenv_local, ...].
+        The result is a view of the rotating buffer and stays valid until `release()`; with copy=True it is a private copy and
+        the buffer is released here."""
         o = self.owner
         self.done.synchronize()             # my outgoing copies of THIS gather are done
         dist.barrier(group=o.cpu_group)     # ... and so are everybody else's (a CPU barrier: no kernel behind the rollout)
-        buf = o.bufs[self.b]
-        return buf.view((o.world * o.block_shape[0],) + o.block_shape[1:])
+        buf = o.bufs[self.b].view((o.world * o.block_shape[0],) + o.block_shape[1:])
+        if copy:
+            out = buf.clone()
+            torch.cuda.current_stream(o.device).synchronize()  # the copy has read the buffer before a peer may write it again
+            return out
+        o.held[self.b] = True
+        return buf
+
+    def release(self) -> None:
+        """The caller is done with the tensor wait() returned: its buffer may be overwritten by the peers' next gather into it.
+        Work the caller queued on that tensor must have finished (the peers write from other devices, unordered with this
+        device's streams): the current stream is synchronised here."""
+        o = self.owner
+        if o.held[self.b]:
+            torch.cuda.current_stream(o.device).synchronize()
+            o.held[self.b] = False
 
 
 def backend_report() -> dict:

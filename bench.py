@@ -4,18 +4,26 @@
 One "step" = one amx_rollout launch over one batch: NENV envs x HORIZON physics steps, inputs resident in HBM.
 
 The workload is the SAME at every N: north_star's target, BASELINE.md C3 per GPU / C5 sharded - the build-authored ~30-DoF
-biped (models/biped/biped.xml), 4096 envs per GPU, random ctrl, 1000-step fused rollout.
-  N = 1   the JSON line also carries `secondary`: C2 (the quadruped, 4096 x 1000, with its own roofline and CPU baseline),
-          C4 (1024 x 64 forward-difference gradient through amx_fd_grad), the biped at other solver options (MuJoCo's defaults
+biped on its two convex-mesh feet on flat ground, 4096 envs per GPU, ctrl ~ U(ctrlrange), 1000-step fused rollout.  Since r04 the
+headline model is models/biped/biped_stand.xml: biped.xml's bodies, feet and solver options with joint position servos (as C2's
+quadruped has) whose ctrlrange is the standing pose +- 0.02 rad - the robots stay on their feet for the whole horizon, which
+`config.activity` reports (base height, contacts in touch, constraint rows).  The two other readings of the same robot are
+`secondary` lines with the same statistics: biped_rest.xml (random torques; eight extra contact spheres, the fallen robot rests on the
+floor; 16 contact slots -> one environment per wavefront) and biped.xml (r01-r03's headline: random torques, feet-only contact -
+after ~150 steps the robots hang below the floor from their feet; kept for continuity).
+  N = 1   the JSON line also carries `secondary`: those two, C2 (the quadruped, 4096 x 1000, with its own roofline and CPU baseline),
+          C4 (1024 x 64 forward-difference gradient through amx_fd_grad), the headline at other solver options (MuJoCo's defaults
           100 / 50 with the tolerance exit; the reference pendulum's 5 / 10) so that the headline is not tied to the model
-          file's Newton 3 / 5, A8 (trajectory cost) and the FP32 figure (recorded flop census,
-          profiles/rNN_flop_census.json, / 157.3 TFLOP/s; VALU-busy from the committed PMC pass); `cpu_baseline`; the MJX-CPU probe.
+          file's Newton 3 / 5, the headline model on the generic (not per-model) kernels, A8 (trajectory cost) and the FP32 figure
+          (recorded flop census, profiles/rNN_flop_census.json, / 157.3 TFLOP/s; VALU-busy from the committed PMC pass);
+          `cpu_baseline`; the MJX-CPU probe.
   N > 1   every rank runs its own 4096 envs (weak scaling, no collective in the data path) and the returned trajectories
-          are all-gathered once per step, overlapped with the next rollout: by peer-to-peer copies on the copy engines
-          (ambersim_amd.dist.PeerCopyGather; `--gather auto`, the default, falls back to the RCCL collective if the IPC set-up
-          or its probe fails; `--gather traj` forces RCCL).  The rollout's workgroups fill every CU, so a collective's KERNELS
-          cannot run next to it (profiles/r03_coresidency.txt); copy-engine transfers can.  The line carries `scaling_report`:
-          rollout alone, both gather methods alone / serialised / overlapped, RCCL version, world size as the backend reports it.
+          are all-gathered once per step by ONE RCCL all-gather (north_star's exchange; `--gather traj`, the default), started
+          asynchronously behind each rollout.  The rollout's workgroups fill every CU, so a collective's KERNELS cannot run
+          next to it (profiles/r03_coresidency.txt); `--gather p2p` does the same exchange as peer-to-peer copies on the copy
+          engines (ambersim_amd.dist.PeerCopyGather), which can - a named alternative whose numbers sit beside the collective's in
+          `scaling_report` (rollout alone, both gather methods alone / serialised / overlapped, RCCL version, world size as the
+          backend reports it); it never carries the headline unless asked for.
 
 `python bench.py --gpus N` is self-contained: with WORLD_SIZE unset and N > 1 the parent - which has not imported torch
 or touched the GPU - starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process, relays
@@ -38,7 +46,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md); 6290 GB/s measured copy
 FP32_PEAK_TFLOPS = 157.3  # MI355X FP32 vector peak (same guide)
 QUADRUPED = "models/quadruped/quadruped.xml"
-BIPED = "models/biped/biped.xml"
+BIPED = "models/biped/biped.xml"              # legacy: random torques, feet-only contact (r01-r03 headline)
+BIPED_STAND = "models/biped/biped_stand.xml"  # headline since r04: the same robot held standing by joint position servos
+BIPED_REST = "models/biped/biped_rest.xml"    # random torques, eight extra contact spheres: falls and rests on the floor
+HEADLINE = BIPED_STAND
 
 
 def parse_args(argv=None):
@@ -48,11 +59,12 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--nenv", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--horizon", type=int, default=1000)
-    ap.add_argument("--model", default=None, help=f"default: {BIPED} (C3 / C5) at every N")
-    ap.add_argument("--gather", choices=["auto", "p2p", "traj", "none"], default="auto",
-                    help="N>1: how the returned trajectories are all-gathered: p2p = peer-to-peer copies on the copy engines (they run under "
-                         "the next rollout; ambersim_amd.dist.PeerCopyGather), traj = one RCCL all-gather (its kernels cannot be resident next "
-                         "to the rollout's), auto = p2p when its set-up and probe succeed, else traj; none = no gather")
+    ap.add_argument("--model", default=None, help=f"default: {HEADLINE} (C3 / C5) at every N")
+    ap.add_argument("--gather", choices=["traj", "p2p", "none"], default="traj",
+                    help="N>1: how the returned trajectories are all-gathered: traj (default) = one RCCL all-gather, north_star's exchange (its "
+                         "kernels cannot be resident next to the rollout's); p2p = the same exchange as peer-to-peer copies on the copy engines "
+                         "(they run under the next rollout; ambersim_amd.dist.PeerCopyGather) - reported beside the collective in "
+                         "scaling_report either way; none = no gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="N=1: skip the C2 / C4 / solver-option / FP32 secondary measurements")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: wait for each all-gather before the next rollout")
@@ -245,7 +257,7 @@ def worker(args):
         dev = torch.device("cuda", local)
     sync = (lambda: None) if dry else torch.cuda.synchronize
 
-    model_path = args.model or BIPED  # one workload at every N (north_star's target)
+    model_path = args.model or HEADLINE  # one workload at every N (north_star's target)
     mj = load_mj_model_from_file(model_path)
     nx = mj.nq + mj.nv
     if dry:
@@ -262,19 +274,21 @@ def worker(args):
     red_dev = "cpu" if (dry or share) else dev  # small host-side reductions: gloo takes CPU tensors
     # the gather method: peer-to-peer copies (copy engines) or the RCCL collective (kernels)
     p2p, p2p_note = None, None
-    if world > 1 and not dry and args.gather in ("auto", "p2p"):
+    want_p2p = args.gather == "p2p" or (args.gather == "traj" and not args.no_scaling_report)  # the alternative is measured beside the collective
+    if world > 1 and not dry and want_p2p:
         try:
             p2p = PeerCopyGather((args.nenv, args.horizon + 1, nx), torch.float32, dev, nbuf=2)
         except Exception as e:  # IPC not available, peer access refused, probe lost: the collective still works
             if args.gather == "p2p":
                 raise
-            p2p_note = f"peer-copy set-up failed ({type(e).__name__}: {str(e)[:160]}): RCCL all-gather instead"
+            p2p_note = f"peer-copy set-up failed ({type(e).__name__}: {str(e)[:160]}): not measured"
         # every rank must take the same path
         ok = torch.tensor([1 if p2p is not None else 0], device=red_dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
             p2p = None
-    method = "none" if (world == 1 or args.gather == "none") else ("p2p" if p2p is not None else "rccl")
+    # the headline's exchange is the one asked for: RCCL unless `--gather p2p` (ranks sharing one device have no RCCL: peer copies)
+    method = "none" if (world == 1 or args.gather == "none") else ("p2p" if (args.gather == "p2p" or share) and p2p is not None else "rccl")
 
     def run_steps(nsteps, mode, events=None, how=None):
         """`nsteps` rollouts.  mode "overlap": the gather of step k proceeds while rollout k+1 runs (at most two gathers in
@@ -292,11 +306,21 @@ def worker(args):
                 # (the pending handle holds xs until waited for: the name is rebound by the next rollout)
                 pending.append(p2p.start(xs) if how == "p2p" else gather_trajectories_async(xs))
                 if len(pending) > 1:
-                    pending.pop(0).wait()
+                    done_pg = pending.pop(0)
+                    done_pg.wait()
+                    if how == "p2p":
+                        done_pg.release()  # the gathered view belongs to us until released (PeerCopyGather: rotating buffers)
             elif world > 1 and mode == "serial":
-                xs = p2p.start(xs).wait() if how == "p2p" else gather_trajectories(xs, equal_blocks=True)
+                if how == "p2p":
+                    pg = p2p.start(xs)
+                    xs = pg.wait()
+                    pg.release()  # (the contents stay readable until the peers' next gather into this buffer, two gathers on)
+                else:
+                    xs = gather_trajectories(xs, equal_blocks=True)
         for pg in pending:
             xs = pg.wait()
+            if how == "p2p":
+                pg.release()
         return xs
 
     def timed(nsteps, mode, with_events=False, how=None):
@@ -322,18 +346,16 @@ def worker(args):
         return elapsed, kern_ms, xs
 
     mode = "none" if (world == 1 or args.gather == "none") else ("serial" if args.no_overlap else "overlap")
-    picked = None
-    if args.gather == "auto" and method == "p2p" and not share:
-        # both methods work: two steps of each, the faster one carries the headline (the copy engines' rate over xGMI is a property
-        # of the node; the collective is the known quantity)
-        run_steps(1, mode, how="p2p"); run_steps(1, mode, how="rccl")
-        tp, _, _ = timed(2, mode, how="p2p")
-        tr, _, _ = timed(2, mode, how="rccl")
-        method = "p2p" if tp <= tr else "rccl"
-        picked = {"peer_copy_ms_per_step": 1e3 * tp / 2, "rccl_ms_per_step": 1e3 * tr / 2, "picked": method}
     run_steps(args.warmup, mode)
     elapsed, kern_ms, xs = timed(args.steps, mode, with_events=True)
     finite = bool(torch.isfinite(xs).all().item())
+    activity = None
+    if rank == 0 and not dry:
+        # what the robots did (rank 0's own block; outside the timed region): base height, contacts in touch, constraint rows
+        try:
+            activity = activity_stats(model, mj, xs[:args.nenv], us)
+        except Exception as e:  # a diagnostic must never take the headline down
+            activity = {"error": f"{type(e).__name__}: {e}"}
     if dry:
         # gathered blocks are in rank order: block r is filled with r
         want = torch.arange(world, dtype=torch.float32).repeat_interleave(args.nenv) if mode != "none" else torch.full((args.nenv,), float(rank))
@@ -372,31 +394,32 @@ def worker(args):
         if p2p is not None:
             t_pser, _, _ = timed(k, "serial", how="p2p")
             t_pover, _, _ = timed(k, "overlap", how="p2p")
-            t_pg = alone(lambda x: p2p.start(x).wait())
+            t_pg = alone(lambda x: p2p.start(x).wait(copy=True))
             report.update({"with_peer_copy_serial_env_steps_per_s": es / t_pser, "with_peer_copy_overlapped_env_steps_per_s": es / t_pover,
                            "peer_copy_alone_ms": 1e3 * t_pg / k, "peer_copy_GBps_per_rank_received": gb * (world - 1) / world / (t_pg / k)})
         if p2p_note:
             report["peer_copy"] = p2p_note
-        if picked:
-            report["gather_method_calibration"] = picked
         report.update(backend_report())
 
     if rank == 0:
         env_steps = args.nenv * args.horizon * args.steps * world
-        tag = {QUADRUPED: "BASELINE.md C2", BIPED: "BASELINE.md C3 per GPU / C5 sharded"}.get(model_path, "custom")
+        tag = {QUADRUPED: "BASELINE.md C2", BIPED: "BASELINE.md C3 per GPU / C5 sharded; legacy: random torques, feet-only contact",
+               BIPED_STAND: "BASELINE.md C3 per GPU / C5 sharded; held standing on its convex-mesh feet by joint position servos",
+               BIPED_REST: "BASELINE.md C3 per GPU / C5 sharded; random torques, falls and rests on eight extra contact spheres"}.get(model_path, "custom")
         out = {
             "metric": "env-steps/sec, 4096 envs x 1000-step rollout",
             "value": env_steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic" + (" (dry run: no kernel, zero trajectories on the CPU)" if dry else ""),
             "config": {"workload": f"{os.path.basename(model_path)} (build-authored, {tag}), {args.nenv} envs/GPU x "
-                                   f"{args.horizon}-step fused rollout, random ctrl ~U(ctrlrange), Newton {mj.opt.iterations} it / "
+                                   f"{args.horizon}-step fused rollout, ctrl ~U(ctrlrange) i.i.d. per env per step, Newton {mj.opt.iterations} it / "
                                    f"{mj.opt.ls_iterations} ls, dt={mj.opt.timestep}",
                        "nenv_per_gpu": args.nenv, "horizon": args.horizon, "nq": mj.nq, "nv": mj.nv, "nu": mj.nu,
                        "gather": {"none": "none", "serial": "traj", "overlap": "traj+overlapped"}[mode] + ("" if method != "p2p" else " (peer-to-peer copies on the copy engines)"),
                        "outputs_finite": finite},
         }
         if not dry:
+            out["config"]["activity"] = activity
             out["roofline"] = roofline(mj, args.nenv, args.horizon, kern_ms, model_path)
         if report:
             out["scaling_report"] = report
@@ -512,7 +535,30 @@ def secondary(args, model, mj, model_path, x0_np, us_np, kern_ms, dev):
         except Exception as e:
             out.append({"name": "C2", "error": f"{type(e).__name__}: {e}"})
 
-    if model_path == BIPED:
+    if model_path == HEADLINE:
+        # the same robot, the two other workloads: what they cost and what the robots do in them
+        for name, path, what in (("C3 falls-and-rests", BIPED_REST, "random torques ~U(ctrlrange); two convex-mesh feet + eight contact spheres (pelvis, chest, shoulders, head, knees, "
+                                  "hands): the robot falls within ~150 steps and rests on the floor; 16 contact slots = 64 pyramid rows -> a 64-lane group, one environment per wavefront"),
+                                 ("C3 legacy feet-only", BIPED, "random torques ~U(ctrlrange); only the two convex-mesh feet collide (r01-r03 headline): after the fall the robot hangs "
+                                  "below the floor from its feet")):
+            try:
+                mjv = load_mj_model_from_file(path)
+                mdl = mjx.put_model(mjv, dev)
+                x0v, usv = make_inputs(mjv, args.nenv, args.horizon, 1, 2, dev)
+                k = 5
+                el, kms, fin = timed_rollouts(mdl, x0v, usv, k)
+                xsv = mjx.rollout(mdl, x0v, usv)
+                out.append({"name": name, "metric": "env-steps/sec, 4096 envs x 1000-step rollout", "value": args.nenv * args.horizon * k / el, "unit": "env-steps/s",
+                            "steps": k, "ms_per_step": 1e3 * el / k, "kernel_ms": kms,
+                            "config": {"workload": f"{os.path.basename(path)}: {what}; {args.nenv} envs x {args.horizon} steps, Newton {mjv.opt.iterations} it / {mjv.opt.ls_iterations} ls",
+                                       "lanes_per_env": int(mdl._h.query("lanes_per_env")), "specialised_build": bool(mdl._h.query("specialised")),
+                                       "activity": activity_stats(mdl, mjv, xsv, usv), "outputs_finite": fin},
+                            "roofline": roofline(mjv, args.nenv, args.horizon, kms, path),
+                            "fp32_valu": fp32(mjv, None, None, args.nenv * args.horizon / (kms * 1e-3), path)})
+                del mdl, xsv, usv
+            except Exception as e:
+                out.append({"name": name, "error": f"{type(e).__name__}: {e}"})
+
         # the headline's cost is set by the model file's solver options (Newton 3 iterations / 5 line-search iterations).  The same
         # workload at MuJoCo's defaults (100 / 50: the tolerance exit decides) and at the reference pendulum's 5 / 10
         # (reference ambersim/models/pendulum/pendulum.xml:3).  Each variant runs its own per-model build of the kernels
@@ -529,12 +575,29 @@ def secondary(args, model, mj, model_path, x0_np, us_np, kern_ms, dev):
                 el, kms, fin = timed_rollouts(mdl, x0_t, us_t, k)
                 out.append({"name": name, "metric": "env-steps/sec, 4096 envs x 1000-step rollout", "value": args.nenv * args.horizon * k / el, "unit": "env-steps/s",
                             "steps": k, "ms_per_step": 1e3 * el / k, "kernel_ms": kms,
-                            "config": {"workload": f"biped.xml with <option iterations={it} ls_iterations={ls}> (tolerance {mv.opt.tolerance:g}: the solver leaves its loop when the "
+                            "config": {"workload": f"{os.path.basename(model_path)} with <option iterations={it} ls_iterations={ls}> (tolerance {mv.opt.tolerance:g}: the solver leaves its loop when the "
                                                    f"scaled improvement or gradient falls below it), {args.nenv} envs x {args.horizon} steps, same x0 / ctrl as the headline",
                                        "specialised_build": bool(mdl._h.query("specialised")), "model_setup_s": t_build, "outputs_finite": fin}})
                 del mdl
             except Exception as e:
                 out.append({"name": name, "error": f"{type(e).__name__}: {e}"})
+        # the headline model on the GENERIC kernels (run-time descriptor): what a model that is neither shipped nor given a per-model
+        # build gets
+        try:
+            os.environ["AMX_NO_SPEC"] = "1"
+            try:
+                mdl = mjx.put_model(mj, dev, specialise=False)
+            finally:
+                del os.environ["AMX_NO_SPEC"]
+            k = 3
+            el, kms, fin = timed_rollouts(mdl, x0_t, us_t, k)
+            out.append({"name": "C3 generic kernels", "metric": "env-steps/sec, 4096 envs x 1000-step rollout", "value": args.nenv * args.horizon * k / el, "unit": "env-steps/s",
+                        "steps": k, "ms_per_step": 1e3 * el / k, "kernel_ms": kms,
+                        "config": {"workload": f"{os.path.basename(model_path)}, same inputs as the headline, on amx_rollout_kernel<G, DynSpec> (no per-model build)",
+                                   "specialised_build": bool(mdl._h.query("specialised")), "outputs_finite": fin}})
+            del mdl
+        except Exception as e:
+            out.append({"name": "C3 generic kernels", "error": f"{type(e).__name__}: {e}"})
         del x0_t, us_t
 
     if True:

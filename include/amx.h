@@ -121,7 +121,10 @@ const char *amx_last_error(void);
 int amx_model_create(const amx_model_desc *desc, int device, amx_model **out);
 int amx_model_destroy(amx_model *m);
 /* Static sizes of a created model: name in {"nq","nv","nu","nbody","ncon","nefc_max",
- * "lds_bytes","lanes_per_env","envs_per_block","env_slab_bytes","const_bytes"}. */
+ * "lds_bytes","lanes_per_env","envs_per_block","env_slab_bytes","const_bytes","specialised"}.
+ * "simd_pairing" is a property of the device, measured by one probe launch (cached): 1 when waves w and w + 4 of an 8-wave
+ * workgroup share a SIMD (what the rollout kernel's fair sharing of a SIMD presumes), 0 when they do not (the kernel then leaves
+ * the arbitration to the hardware; it re-checks on every step), -1 when the probe could not run. */
 int amx_model_query(const amx_model *m, const char *name, int *out);
 
 /* mjx.forward: derived quantities for the given state, no integration.  `qacc_warmstart_dev`

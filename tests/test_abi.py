@@ -164,6 +164,63 @@ def test_per_model_specialised_build():
     assert _spec.build_specialised_library(mj2).exists()
 
 
+def test_compiler_crash_fallback_is_pinned(tmp_path, monkeypatch):
+    """A per-model build whose compile dies inside the compiler ("frontend command failed due to signal", seen once on ROCm 7.2's
+    register allocator in r03; the source site that triggered it has since been rewritten, so no current plan reproduces it) is
+    retried with _spec.CRASH_FALLBACK_FLAGS.  Pinned here with a stand-in compiler that fails exactly that way unless the
+    fallback flags are present and otherwise IS hipcc: (a) the retry happens, once, and the two command lines differ by those
+    flags only; (b) the two macros gate nothing but the packed-fp32 spellings of sums (every use in the kernel source is an
+    `#if` around a `pk_` / f2v form with a scalar `#else`); (c) the resulting library is a complete ABI.  The GPU test
+    test_crash_fallback_build_matches_the_oracle runs that instruction mix against the oracle."""
+    import re
+    import stat
+    import sys
+    from ambersim_amd import _spec
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    log = tmp_path / "calls.log"
+    fake = tmp_path / "hipcc_that_crashes"
+    fake.write_text(f"""#!{sys.executable}
+import os, subprocess, sys
+args = sys.argv[1:]
+if "--version" in args:
+    sys.exit(subprocess.run([{hipcc!r}] + args).returncode)
+open({str(log)!r}, "a").write(" ".join(args) + chr(10))
+if not all(f in args for f in {list(_spec.CRASH_FALLBACK_FLAGS)!r}):
+    sys.stderr.write("clang++: error: clang frontend command failed due to signal (use -v to see invocation)" + chr(10))
+    sys.exit(1)
+sys.exit(subprocess.run([{hipcc!r}] + args).returncode)
+""")
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("HIPCC", str(fake))
+    monkeypatch.setenv("AMX_CACHE_DIR", str(tmp_path / "cache"))
+    monkeypatch.setattr(_spec, "_HIPCC_ID", {})
+    path = _spec.build_specialised_library(jit_test_model())
+    assert path.exists() and _spec._LAST_BUILD["fallback"] is True
+    calls = [c.split() for c in log.read_text().splitlines()]
+    assert len(calls) == 2
+    assert [a for a in calls[1] if a not in calls[0]] == list(_spec.CRASH_FALLBACK_FLAGS) and [a for a in calls[0] if a not in calls[1]] == []
+    assert _lib.load(path).amx_version() == 3
+    # AMX_SPEC_NO_RETRY=1: the crash is reported instead (how a new crashing plan would be found and reduced)
+    monkeypatch.setenv("AMX_SPEC_NO_RETRY", "1")
+    monkeypatch.setenv("AMX_CACHE_DIR", str(tmp_path / "cache2"))
+    with pytest.raises(RuntimeError, match="frontend command failed"):
+        _spec.build_specialised_library(jit_test_model())
+    # (b) what the two macros gate in the source
+    src = open(os.path.join(ROOT, "ambersim_amd", "csrc", "amx_kernels.hip")).read()
+    for macro in ("AMX_PK_SV", "AMX_PK_DOT"):
+        uses = [m.start() for m in re.finditer(rf"#if {macro}\b", src)]
+        other = [m.start() for m in re.finditer(rf"\b{macro}\b", src)]
+        assert len(uses) >= 2 and len(other) == len(uses) + 2, (macro, len(uses), len(other))  # + the #ifndef and #define of its definition: no other use
+        for u in uses:
+            block = src[u:src.index("#endif", u)]
+            packed_arm = block.split("#else")[0]
+            assert "f2v" in packed_arm, (macro, packed_arm[:200])  # the guarded arm is a packed spelling ...
+            if "#else" in block:
+                assert "f2v" not in block.split("#else")[1], (macro, "... and the other arm is scalar")
+
+
 def test_inline_assembly_dpp_reads_keep_their_wait_states():
     """The crossbar-free eliminations issue v_fmac_f32_dpp as inline assembly, which the compiler's hazard recogniser does not
     look into: tools/check_dpp_hazard.py re-checks on the emitted gfx950 code that no such instruction reads a register a

@@ -86,7 +86,7 @@ def test_bench_self_launch_dry_run(extra):
     assert len(lines) == 1, p.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak" and out["value"] > 0
-    assert "biped.xml" in out["config"]["workload"] and out["config"]["nenv_per_gpu"] == 6  # one workload at every N
+    assert "biped_stand.xml" in out["config"]["workload"] and out["config"]["nenv_per_gpu"] == 6  # one workload at every N
     assert out["scaling_report"]["backend"] == "gloo" and out["scaling_report"]["world_size_reported"] == 2
     want = {"": "traj+overlapped", "--no-overlap": "traj", "--gather": "none"}[extra[0] if extra else ""]
     assert out["config"]["gather"] == want
@@ -130,4 +130,4 @@ def test_bench_workload_is_the_same_at_every_n():
         out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
         assert out["n_gpus"] == n and out["config"]["nenv_per_gpu"] == 4096 and out["config"]["horizon"] == 1000
         loads.append(out["config"]["workload"])
-    assert loads[0] == loads[1] and "biped.xml" in loads[0]
+    assert loads[0] == loads[1] and "biped_stand.xml" in loads[0]

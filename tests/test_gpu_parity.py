@@ -238,6 +238,28 @@ def test_per_model_build_with_equality_rows(cases, dev):
     assert rel(a[:, 1], ref[:, 1]) < TOL and rel(b[:, 1], ref[:, 1]) < TOL and rel(a[:, 3], b[:, 3]) < 5e-5
 
 
+def test_crash_fallback_build_matches_the_oracle(cases, dev, monkeypatch):
+    """The per-model build a compiler crash would fall back to (_spec.CRASH_FALLBACK_FLAGS: packed-fp32 forms off; see
+    tests/test_abi.py::test_compiler_crash_fallback_is_pinned), forced with AMX_SPEC_FORCE_FALLBACK=1: the quadruped variant and
+    the biped on that instruction mix against the fp64 oracle (one step 1e-5) and against the regular per-model build."""
+    from test_abi import jit_test_model
+    from ambersim_amd import _spec, mjx
+    from oracle.oracle import Oracle
+    for mj, key in ((jit_test_model(), "quadruped"), (cases["biped"][0], "biped")):
+        _, _, x0, us = cases[key]
+        regular = mjx.put_model(mj, dev, specialise=True)
+        monkeypatch.setenv("AMX_SPEC_FORCE_FALLBACK", "1")
+        p_fb, _ = _spec.specialised_library_path(mj)
+        fallback = mjx.put_model(mj, dev, specialise=True)
+        monkeypatch.delenv("AMX_SPEC_FORCE_FALLBACK")
+        p_reg, _ = _spec.specialised_library_path(mj)
+        assert p_fb != p_reg and p_fb.exists() and fallback._h.query("specialised") == 1
+        a, b = gpu_rollout(regular, x0, us), gpu_rollout(fallback, x0, us)
+        ref = Oracle(mj, np.float64).rollout(x0.astype(np.float32), us.astype(np.float32))
+        print(f"{key}: fallback build 1-step {rel(b[:, 1], ref[:, 1]):.2e} (regular {rel(a[:, 1], ref[:, 1]):.2e}); 3-step fallback vs regular {rel(a[:, 3], b[:, 3]):.2e}")
+        assert rel(b[:, 1], ref[:, 1]) < TOL and rel(a[:, 3], b[:, 3]) < 5e-5
+
+
 def test_step_api_matches_rollout_bitwise(cases):
     """amx_step (state through HBM each call, warm start carried) and amx_rollout (state in LDS) run the same phases:
     identical bits after 20 steps."""
@@ -321,6 +343,54 @@ def test_full_size_properties_biped(dev):
     assert bool(((q > lim[:, 0] - 0.5) & (q < lim[:, 1] + 0.5)).all())  # soft limits: overshoot bounded under full random torques
     xf = mjx.rollout(model, x0[:64], us[:64], return_traj=False)
     assert torch.equal(xf, xs[:64, -1])  # the final-state-only output (C4's path) is the last trajectory row
+
+
+@pytest.mark.parametrize("path,what", [("models/biped/biped_stand.xml", "stands"), ("models/biped/biped_rest.xml", "rests")])
+def test_full_size_properties_physical_bipeds(dev, path, what):
+    """The r04 headline workload and its falls-and-rests sibling at full size (4096 x 1000): everything
+    test_full_size_properties_biped checks, plus what the robots physically do: the floating base never
+    goes below the floor (z > -0.05); the servo-held biped keeps its pelvis up (z > 0.9) with its feet in touch for the whole
+    horizon, the torque-driven one ends lying on its contact spheres (final z in [0.05, 0.4]); and one step of each against the
+    fp64 CPU oracle within north_star's 1e-5."""
+    from ambersim_amd import mjx
+    from ambersim_amd.utils.io_utils import load_mj_model_from_file
+    from bench import activity_stats, make_inputs
+    from oracle.oracle import Oracle
+    mj = load_mj_model_from_file(path)
+    model = mjx.put_model(mj, dev)
+    assert model._h.query("specialised") == 1 and model._h.query("lanes_per_env") == (32 if what == "stands" else 64)
+    x0, us = make_inputs(mj, 4096, 1000, 1, 2, dev)
+    xs = mjx.rollout(model, x0, us)
+    assert xs.shape == (4096, 1001, mj.nq + mj.nv) and bool(torch.isfinite(xs).all())
+    assert torch.equal(xs[:, 0], x0)
+    assert torch.equal(mjx.rollout(model, x0[:6], us[:6]), xs[:6])
+    assert torch.equal(mjx.rollout(model, x0[-3:], us[-3:]), xs[-3:])
+    assert float((xs[:, :, 3:7].norm(dim=-1) - 1).abs().max()) < 1e-4
+    z = xs[:, :, 2]
+    assert float(z.min()) > -0.05, float(z.min())
+    st = activity_stats(model, mj, xs, us)
+    print(what, st)
+    if what == "stands":
+        assert float(z.min()) > 0.9
+        assert st["contacts_touching_mean"] > 4.0  # of 8 slots: both feet on the ground throughout
+    else:
+        zf = z[:, -1]
+        assert float(zf.min()) > 0.05 and float(zf.max()) < 0.4, (float(zf.min()), float(zf.max()))
+        assert st["contacts_touching_mean"] > 1.0
+    # one step against the fp64 oracle
+    n = 64
+    ref = Oracle(mj, np.float64).rollout(x0[:n].cpu().numpy().astype(np.float64), us[:n, :1].cpu().numpy().astype(np.float64))
+    got = xs[:n, 1].cpu().numpy().astype(np.float64)
+    err = np.abs(got - ref[:, 1]).max(axis=1) / np.maximum(1.0, np.abs(ref[:, 1]).max(axis=1))
+    assert err.max() <= 1e-5, err.max()
+
+
+def test_simd_pairing_probe(cases, dev):
+    """The rollout kernel's fair sharing of a SIMD presumes waves w and w + 4 of a workgroup sit on one SIMD; the library measures it
+    (one probe launch, cached per device) and the kernel re-checks per step.  On every box measured so far the answer is yes; if
+    this fails the pairing logic has silently fallen back to the hardware's arbitration and the throughput tables need re-reading."""
+    model = cases[sorted(cases)[0]][1]
+    assert model._h.query("simd_pairing") == 1
 
 
 @pytest.mark.parametrize("flags,solver", [(0, 1), (16, 2), (64 | 16, 2), (16384, 2), (256, 2)])

@@ -29,10 +29,19 @@ for k in range(5):
         out = pg.wait()
         want = torch.cat([torch.full((64, 11, 7), float(10 * kk + r)) for r in range(world)]).to(dev)
         assert torch.equal(out, want), (rank, kk)
+        if kk == 1:  # holding on to a result: the gather that would overwrite its buffer is refused, on every rank
+            pend_k, pend_h = pend[0]
+            try:
+                g.start(xs)
+                raise SystemExit("start() reused a buffer that is still held")
+            except RuntimeError as e:
+                assert "still held" in str(e), e
+        pg.release()
 for kk, pg in pend:
     out = pg.wait()
     want = torch.cat([torch.full((64, 11, 7), float(10 * kk + r)) for r in range(world)]).to(dev)
     assert torch.equal(out, want), (rank, kk)
+    pg.release()
 g.close()
 dist.barrier()
 if rank == 0: print("peer-copy gather: 5 gathers, two in flight, contents and order correct on", world, "ranks")
