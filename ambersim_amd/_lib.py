@@ -22,7 +22,29 @@ class AmxForwardOut(C.Structure):
         "contact_dist_dev", "nefc_dev"]]
 
 
-EXPORTS = ["amx_version", "amx_last_error", "amx_model_create", "amx_model_destroy", "amx_model_query",
+TAIL_MAX_OBS, TAIL_MAX_REW = 16, 8
+
+
+class AmxEnvTailDesc(C.Structure):
+    """amx_env_tail_desc (include/amx.h): observation / reward terms and the episode length of a fused env.step."""
+    _fields_ = [("nobs", C.c_int), ("obs_kind", C.c_int * TAIL_MAX_OBS), ("obs_index", C.c_int * TAIL_MAX_OBS),
+                ("nrew", C.c_int), ("rew_kind", C.c_int * TAIL_MAX_REW), ("rew_index", C.c_int * TAIL_MAX_REW),
+                ("rew_target", C.c_float * TAIL_MAX_REW), ("rew_weight", C.c_float * TAIL_MAX_REW), ("episode_length", C.c_int)]
+
+
+TAIL_IO_FIELDS = ("first_qpos", "first_qvel", "first_ctrl", "first_warm", "first_time", "first_obs",
+                  "steps", "episode_return", "last_episode_return", "episodes", "step_counter_in",
+                  "qpos_out", "qvel_out", "ctrl_out", "warm_out", "time_out", "qacc_out",
+                  "obs_out", "terminal_obs_out", "reward_out", "done_out", "truncation_out",
+                  "steps_out", "episode_return_out", "last_episode_return_out", "episodes_out", "step_counter_out")
+
+
+class AmxEnvTailIO(C.Structure):
+    """amx_env_tail_io (include/amx.h): device pointers of a fused env.step, in the header's order."""
+    _fields_ = [(n, C.c_void_p) for n in TAIL_IO_FIELDS]
+
+
+EXPORTS = ["amx_env_step", "amx_version", "amx_last_error", "amx_model_create", "amx_model_destroy", "amx_model_query",
            "amx_forward", "amx_step", "amx_step_to", "amx_rollout", "amx_quadcost", "amx_fd_workspace_bytes", "amx_fd_grad"]
 
 
@@ -64,6 +86,7 @@ def load(path) -> C.CDLL:
     L.amx_forward.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.POINTER(AmxForwardOut), C.c_void_p]
     L.amx_step.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_void_p]
     L.amx_step_to.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 9 + [C.c_void_p]
+    L.amx_env_step.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.POINTER(AmxEnvTailDesc), C.POINTER(AmxEnvTailIO), C.c_void_p]
     L.amx_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.amx_quadcost.argtypes = [C.c_int] * 4 + [C.c_void_p] * 7 + [C.c_void_p]
     L.amx_fd_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t)]

@@ -292,6 +292,34 @@ extern "C" int amx_step(const amx_model *m, int nenv, int nsub, float *qpos, flo
   return amx_step_to(m, nenv, nsub, qpos, qvel, ctrl, warm, time, qpos, qvel, warm, time, stream);
 }
 
+extern "C" int amx_env_step(const amx_model *m, int nenv, int nsub, const float *qpos, const float *qvel, const float *action, const float *warm,
+                            const float *time, const amx_env_tail_desc *tail, const amx_env_tail_io *io, void *stream) {
+  if (!m || !tail || !io) return fail(AMX_EINVAL, "amx_env_step: null argument");
+  if (tail->nobs < 0 || tail->nobs > AMX_TAIL_MAX_OBS || tail->nrew < 0 || tail->nrew > AMX_TAIL_MAX_REW || tail->episode_length < 1)
+    return fail(AMX_EINVAL, "amx_env_step: descriptor out of range (nobs %d, nrew %d, episode_length %d)", tail->nobs, tail->nrew, tail->episode_length);
+  for (int k = 0; k < tail->nobs; k++) {
+    const int kind = tail->obs_kind[k], i = tail->obs_index[k];
+    if (kind < 0 || kind > 3 || i < 0 || i >= (kind == 3 ? m->dev.nv : m->dev.nq)) return fail(AMX_EINVAL, "amx_env_step: observation term %d (kind %d, index %d) is out of range", k, kind, i);
+  }
+  for (int k = 0; k < tail->nrew; k++) {
+    const int kind = tail->rew_kind[k], i = tail->rew_index[k];
+    if (kind < 0 || kind > 3 || i < 0 || i >= (kind == 2 ? m->dev.nv : (kind == 3 ? m->dev.nu : m->dev.nq))) return fail(AMX_EINVAL, "amx_env_step: reward term %d (kind %d, index %d) is out of range", k, kind, i);
+  }
+  const void *need[] = {io->first_qpos, io->first_qvel, io->first_warm, io->first_time, io->first_obs, io->steps, io->episode_return, io->last_episode_return, io->episodes,
+                        io->qpos_out, io->qvel_out, io->warm_out, io->time_out, io->qacc_out, io->obs_out, io->terminal_obs_out, io->reward_out, io->done_out,
+                        io->truncation_out, io->steps_out, io->episode_return_out, io->last_episode_return_out, io->episodes_out};
+  for (const void *p : need) if (!p) return fail(AMX_EINVAL, "amx_env_step: a required buffer of amx_env_tail_io is NULL");
+  if (m->dev.nu > 0 && (!io->first_ctrl || !io->ctrl_out || !action)) return fail(AMX_EINVAL, "amx_env_step: ctrl buffers are NULL");
+  if (!time) return fail(AMX_EINVAL, "amx_env_step: time_dev is NULL");
+  // the physics: state in -> qpos_out, qvel_out, time_out and the solver's result (the next warm start) in qacc_out
+  if (int rc = amx_step_to(m, nenv, nsub, qpos, qvel, action, warm, time, io->qpos_out, io->qvel_out, io->qacc_out, io->time_out, stream)) return rc;
+  if (nenv == 0) return AMX_OK;
+  AMX_ON_DEVICE(m->device);
+  hipLaunchKernelGGL(amx_env_tail_kernel, dim3((nenv + 255) / 256), dim3(256), 0, (hipStream_t)stream, nenv, m->dev.nq, m->dev.nv, m->dev.nu, action, *tail, *io);
+  HIP_TRY(hipGetLastError());
+  return AMX_OK;
+}
+
 #ifdef AMX_PROFILE
 static float *g_prof = nullptr;
 // Diagnostic build only (libamx_prof.so): where a rollout's cycles go.  Not part of include/amx.h.

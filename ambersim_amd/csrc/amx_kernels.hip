@@ -3403,6 +3403,62 @@ amx_step_kernel(const DevModel m_in, int nenv, int nsub, const float *qpos, cons
   if (time_out && gl == 0) time_out[e] = t0 + m.dt() * nsub;
 }
 
+// The tail of a wrapped env.step (amx_env_step, include/amx.h): one thread per environment, everything after the physics.
+// The physics kernel has written qpos / qvel / time and the solver's qacc (= the next warm start) into the *_out buffers; this
+// kernel reads them, forms observation and reward, advances the episode counters and overwrites the state of a finished
+// environment with its first state.
+extern "C" __global__ void __launch_bounds__(256) amx_env_tail_kernel(int nenv, int nq, int nv, int nu, const float *__restrict__ action,
+                                                                      const amx_env_tail_desc d, const amx_env_tail_io io) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e == 0 && io.step_counter_out) *io.step_counter_out = (io.step_counter_in ? *io.step_counter_in : 0.0f) + 1.0f;
+  if (e >= nenv) return;
+  float *qp = io.qpos_out + (size_t)e * nq, *qv = io.qvel_out + (size_t)e * nv;
+  const float *u = action + (size_t)e * nu;
+  float obs[AMX_TAIL_MAX_OBS];
+#pragma unroll
+  for (int k = 0; k < AMX_TAIL_MAX_OBS; ++k) {
+    if (k < d.nobs) {
+      const int kind = d.obs_kind[k], i = d.obs_index[k];
+      const float x = kind == 3 ? qv[i] : qp[i];
+      obs[k] = kind == 1 ? cosf(x) : (kind == 2 ? sinf(x) : x);
+    }
+  }
+  float reward = 0.0f;
+#pragma unroll
+  for (int k = 0; k < AMX_TAIL_MAX_REW; ++k) {
+    if (k < d.nrew) {
+      const int kind = d.rew_kind[k], i = d.rew_index[k];
+      float t = kind == 2 ? qv[i] : (kind == 3 ? u[i] : qp[i] - d.rew_target[k]);
+      if (kind == 0) t = atan2f(sinf(t), cosf(t));
+      reward -= d.rew_weight[k] * t * t;
+    }
+  }
+  const float env_done = 0.0f;  // (the reference env never terminates: swingup.py:115)
+  const float steps = io.steps[e] + 1.0f;
+  const float trunc = steps >= (float)d.episode_length ? 1.0f : 0.0f;
+  const float done = fmaxf(env_done, trunc);
+  const bool fin = done > 0.0f;
+  const float ret = io.episode_return[e] + reward;
+  io.last_episode_return_out[e] = fin ? ret : io.last_episode_return[e];
+  io.episodes_out[e] = io.episodes[e] + done;
+  io.episode_return_out[e] = fin ? 0.0f : ret;
+  io.truncation_out[e] = trunc * (1.0f - env_done);
+  io.steps_out[e] = fin ? 0.0f : steps;
+  io.reward_out[e] = reward;
+  io.done_out[e] = done;
+  for (int k = 0; k < d.nobs; ++k) {
+    io.terminal_obs_out[(size_t)e * d.nobs + k] = obs[k];
+    io.obs_out[(size_t)e * d.nobs + k] = fin ? io.first_obs[(size_t)e * d.nobs + k] : obs[k];
+  }
+  for (int i = 0; i < nu; ++i) io.ctrl_out[(size_t)e * nu + i] = fin ? io.first_ctrl[(size_t)e * nu + i] : u[i];
+  for (int i = 0; i < nv; ++i) io.warm_out[(size_t)e * nv + i] = fin ? io.first_warm[(size_t)e * nv + i] : io.qacc_out[(size_t)e * nv + i];
+  if (fin) {
+    for (int i = 0; i < nq; ++i) qp[i] = io.first_qpos[(size_t)e * nq + i];
+    for (int i = 0; i < nv; ++i) qv[i] = io.first_qvel[(size_t)e * nv + i];
+    io.time_out[e] = io.first_time[e];
+  }
+}
+
 // Which SIMD every wave of an 8-wave workgroup runs on (amx_model_query "simd_pairing": the fair-sharing logic of the rollout
 // kernel presumes waves w and w + 4 share one).  out[block * 8 + wave] = SIMD_ID.
 extern "C" __global__ void __launch_bounds__(512) amx_simd_probe_kernel(int *out) {

@@ -6,8 +6,8 @@ unbatched; every `Data` leaf is a float32 torch tensor that may carry one leadin
 [nenv, ...] (the layout `jax.vmap` gives the reference).  The arithmetic runs in the HIP library
 behind include/amx.h; there is no eager/CPU path here.
 """
-from ._src import (Data, DisableBit, Model, Option, SolverType, constraint_activity, device_put, forward, make_data, put_data,
+from ._src import (Data, DisableBit, Model, Option, SolverType, constraint_activity, device_put, env_step, forward, make_data, make_env_tail, put_data,
                    put_model, rollout, step)
 
-__all__ = ["Data", "DisableBit", "Model", "Option", "SolverType", "constraint_activity", "device_put", "forward", "make_data", "put_data",
+__all__ = ["Data", "DisableBit", "Model", "Option", "SolverType", "constraint_activity", "device_put", "env_step", "make_env_tail", "forward", "make_data", "put_data",
            "put_model", "rollout", "step"]

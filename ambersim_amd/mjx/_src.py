@@ -62,12 +62,29 @@ class _Handle:
         self.L = _lib.lib()
         _lib.check(self.L.amx_model_create(C.byref(self.desc), device_index, C.byref(self.ptr)), self.L)
         if specialise and not self.query("specialised"):
-            from .._spec import build_specialised_library
-            L2 = _lib.load(build_specialised_library(mj))
-            ptr2 = C.c_void_p()
-            _lib.check(L2.amx_model_create(C.byref(self.desc), device_index, C.byref(ptr2)), L2)
-            self.L.amx_model_destroy(self.ptr)
-            self.L, self.ptr = L2, ptr2
+            # specialise: True = the caller asked for a per-model build (errors propagate); "auto" = the default: build one when hipcc
+            # is on this machine, say so in one line, and run the generic kernels (about half the throughput) when it is not
+            import logging
+            from .._spec import build_specialised_library, specialised_library_path
+            log = logging.getLogger("ambersim_amd")
+            try:
+                if specialise == "auto":
+                    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+                    if not os.path.exists(hipcc):
+                        raise FileNotFoundError(f"{hipcc} not found")
+                    if not specialised_library_path(mj)[0].exists():
+                        log.warning("no kernels are compiled for this model's launch plan: building them with hipcc (about ten seconds, once; "
+                                    "cached under %s; AMX_SPECIALISE=0 keeps the generic kernels)", specialised_library_path(mj)[0].parent)
+                L2 = _lib.load(build_specialised_library(mj))
+                ptr2 = C.c_void_p()
+                _lib.check(L2.amx_model_create(C.byref(self.desc), device_index, C.byref(ptr2)), L2)
+                self.L.amx_model_destroy(self.ptr)
+                self.L, self.ptr = L2, ptr2
+            except Exception as e:
+                if specialise != "auto":
+                    raise
+                log.warning("per-model kernels unavailable (%s: %s): this model runs on the generic kernels, at about half the throughput of a "
+                            "per-model build", type(e).__name__, str(e).splitlines()[0][:160] if str(e) else "")
 
     def query(self, name: str) -> int:
         out = C.c_int()
@@ -150,7 +167,8 @@ class Data:
 def put_model(mj: MjModel, device=None, specialise: Optional[bool] = None) -> Model:
     """Host model -> device model.  `specialise=True`: if the library holds no kernels compiled for this model's launch plan
     (only the shipped models have them), compile csrc/ for it with hipcc - about ten seconds, cached by plan - and use that build:
-    static loop bounds, immediate LDS offsets, tree-sparse eliminations, as for the shipped models."""
+    static loop bounds, immediate LDS offsets, tree-sparse eliminations, as for the shipped models.  Default (None): do so whenever
+    hipcc is available, fall back to the generic kernels with one log line when it is not; False: always the library's own kernels."""
     if mj.opt.integrator != 0:
         raise NotImplementedError("only the Euler integrator is implemented")
     if getattr(mj, "nunsupported_pairs", 0):
@@ -158,8 +176,11 @@ def put_model(mj: MjModel, device=None, specialise: Optional[bool] = None) -> Mo
             f"{mj.nunsupported_pairs} collision pairs are outside the implemented pair functions (condim != 3, a capsule "
             "against a box or mesh, or a convex hull beyond 32 vertices / 32 faces / 64 edges); disable contact "
             "(DisableBit.CONTACT), restrict contype/conaffinity or simplify the meshes")
-    if specialise is None:  # the default follows AMX_SPECIALISE (unset / 0: the library's own kernels)
-        specialise = os.environ.get("AMX_SPECIALISE", "0") not in ("", "0")
+    if specialise is None:
+        # default (r04): "auto" - a model the library ships no kernels for gets a per-model build when hipcc is on this machine
+        # (the generic kernels run at about half the throughput: bench.py, "C3 generic kernels"); AMX_SPECIALISE=0 / 1 forces never / always
+        env = os.environ.get("AMX_SPECIALISE", "auto")
+        specialise = "auto" if env in ("", "auto") else env != "0"
     return Model(mj, _dev(device), specialise=specialise)
 
 
@@ -297,6 +318,71 @@ def step(m: Model, d: Data, nsub: int = 1) -> Data:
     s = (lambda t: t) if b else (lambda t: t[0])
     return d.replace(qpos=s(qpos), qvel=s(qvel), qacc_warmstart=s(warm), qacc=s(warm) if m.nefc_max > 0 else d.qacc, time=s(time),
                      ctrl=s(ctrl))
+
+
+def make_env_tail(obs_terms, reward_terms, episode_length: int) -> "_lib.AmxEnvTailDesc":
+    """The descriptor of a fused env.step (include/amx.h: amx_env_tail_desc).  obs_terms: [(kind, index)] with kind in
+    {"qpos", "cos", "sin", "qvel"}; reward_terms: [(kind, index, target, weight)] with kind in {"wrapped_angle", "qpos", "qvel",
+    "ctrl"}: reward = -sum weight * term^2."""
+    ok = {"qpos": 0, "cos": 1, "sin": 2, "qvel": 3}
+    rk = {"wrapped_angle": 0, "qpos": 1, "qvel": 2, "ctrl": 3}
+    if len(obs_terms) > _lib.TAIL_MAX_OBS or len(reward_terms) > _lib.TAIL_MAX_REW:
+        raise ValueError(f"a fused env tail holds at most {_lib.TAIL_MAX_OBS} observation and {_lib.TAIL_MAX_REW} reward terms")
+    d = _lib.AmxEnvTailDesc()
+    d.nobs, d.nrew, d.episode_length = len(obs_terms), len(reward_terms), int(episode_length)
+    for k, (kind, i) in enumerate(obs_terms):
+        d.obs_kind[k], d.obs_index[k] = ok[kind], int(i)
+    for k, (kind, i, target, weight) in enumerate(reward_terms):
+        d.rew_kind[k], d.rew_index[k], d.rew_target[k], d.rew_weight[k] = rk[kind], int(i), float(target), float(weight)
+    return d
+
+
+def env_step(m: Model, d: Data, action: torch.Tensor, nsub: int, tail, first: Data, first_obs: torch.Tensor, counters: dict):
+    """One wrapped env.step as ONE call of the C ABI (amx_env_step: the physics launch + one elementwise launch): the counterpart of
+    the reference's jitted env.step under brax's Episode / AutoReset wrappers.  `d`: batched state; `first` / `first_obs`: the
+    state and observation every env was first reset to; `counters`: {"steps", "episode_return", "last_episode_return", "episodes"}
+    [n] tensors and optionally "step" (the env's own 0-dim counter).  Returns (Data, out) with out = {obs, terminal_obs, reward,
+    done, truncation, steps, episode_return, last_episode_return, episodes[, step]} - all fresh tensors, inputs untouched."""
+    b, n, t = _prep(m, d, ("qpos", "qvel", "qacc_warmstart"))
+    if not b:
+        raise ValueError("env_step: the state must carry the batch axis")
+    dev = m.device
+    f32 = lambda x, shape: _c(x.to(device=dev, dtype=torch.float32).expand(shape))
+    act = f32(action, (n, m.nu))
+    time = f32(d.time if torch.is_tensor(d.time) else torch.tensor(float(d.time or 0.0)), (n,))
+    fq, fv, fw = f32(first.qpos, (n, m.nq)), f32(first.qvel, (n, m.nv)), f32(first.qacc_warmstart, (n, m.nv))
+    fc, ft = f32(first.ctrl, (n, m.nu)), f32(first.time if torch.is_tensor(first.time) else torch.tensor(0.0), (n,))
+    nobs = tail.nobs
+    fo = f32(first_obs, (n, nobs))
+    cin = {k: f32(counters[k], (n,)) for k in ("steps", "episode_return", "last_episode_return", "episodes")}
+    # one allocation for every output, carved into contiguous views: state fields [n, w], per-env scalars [n]
+    fields2d = (("qpos_out", m.nq), ("qvel_out", m.nv), ("ctrl_out", m.nu), ("warm_out", m.nv), ("qacc_out", m.nv), ("obs_out", nobs), ("terminal_obs_out", nobs))
+    scalars = ("time_out", "reward_out", "done_out", "truncation_out", "steps_out", "episode_return_out", "last_episode_return_out", "episodes_out")
+    buf = torch.empty(((sum(w for _, w in fields2d) + len(scalars)) * n + 1,), dtype=torch.float32, device=dev)
+    o, off = {}, 0
+    for name, w in fields2d:
+        o[name] = buf[off:off + n * w].view(n, w)
+        off += n * w
+    for name in scalars:
+        o[name] = buf[off:off + n]
+        off += n
+    step_in = counters.get("step")
+    step_out = buf[off:off + 1].view(()) if step_in is not None else None
+    io = _lib.AmxEnvTailIO()
+    vals = dict(first_qpos=fq, first_qvel=fv, first_ctrl=fc, first_warm=fw, first_time=ft, first_obs=fo, step_counter_in=step_in, step_counter_out=step_out, **cin, **o)
+    for name in _lib.TAIL_IO_FIELDS:
+        v = vals.get(name)
+        setattr(io, name, None if v is None else v.data_ptr())
+    with torch.cuda.device(dev):
+        _lib.check(m._h.L.amx_env_step(m._h.ptr, n, int(nsub), t["qpos"].data_ptr(), t["qvel"].data_ptr(), act.data_ptr(), t["qacc_warmstart"].data_ptr(),
+                                           time.data_ptr(), C.byref(tail), C.byref(io), _stream_ptr(dev)), m._h.L)
+    data = d.replace(qpos=o["qpos_out"], qvel=o["qvel_out"], ctrl=o["ctrl_out"], qacc_warmstart=o["warm_out"], time=o["time_out"],
+                     qacc=o["qacc_out"] if m.nefc_max > 0 else d.qacc)
+    out = {"obs": o["obs_out"], "terminal_obs": o["terminal_obs_out"], "reward": o["reward_out"], "done": o["done_out"], "truncation": o["truncation_out"],
+           "steps": o["steps_out"], "episode_return": o["episode_return_out"], "last_episode_return": o["last_episode_return_out"], "episodes": o["episodes_out"]}
+    if step_out is not None:
+        out["step"] = step_out
+    return data, out
 
 
 def rollout(m: Model, x0: torch.Tensor, us: torch.Tensor, return_traj: bool = True):

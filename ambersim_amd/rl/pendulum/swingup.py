@@ -39,6 +39,17 @@ class PendulumSwingupEnv(MjxEnv):
         """step() issues device work only (no draw from a host-side generator): it can be captured in a HIP graph."""
         return self.config.stdev_obs == 0.0
 
+    def fused_tail(self, episode_length: int):
+        """Observation and reward of this env as the descriptor of a fused env.step (mjx.env_step -> amx_env_step: the physics launch
+        and ONE elementwise launch for observation, reward, episode bookkeeping and auto reset), or None when a step draws
+        observation noise from a host-side generator.  The same formulas as compute_obs / compute_reward below."""
+        if self.config.stdev_obs != 0.0:
+            return None
+        c = self.config
+        return mjx.make_env_tail([("cos", 0), ("sin", 0), ("qvel", 0)],
+                                 [("wrapped_angle", 0, math.pi, c.theta_cost_weight), ("qvel", 0, 0.0, c.theta_dot_cost_weight),
+                                  ("ctrl", 0, 0.0, c.control_cost_weight)], episode_length)
+
     def compute_obs(self, data: mjx.Data, info: Dict[str, Any]) -> torch.Tensor:
         theta = data.qpos[..., 0]
         return torch.stack((torch.cos(theta), torch.sin(theta), data.qvel[..., 0]), dim=-1)

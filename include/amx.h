@@ -147,6 +147,41 @@ int amx_step_to(const amx_model *m, int nenv, int nsub, const float *qpos_dev, c
                 float *qpos_out_dev, float *qvel_out_dev, float *qacc_warmstart_out_dev, float *time_out_dev,
                 void *stream);
 
+/* A whole wrapped env.step in one call (two launches on `stream`: the physics of amx_step_to, then ONE elementwise kernel for
+ * everything the reference's env and its training wrappers do after it).  Replaces, for envs whose observation and reward fit
+ * the descriptor below, the body of PendulumSwingupEnv.step (reference ambersim/rl/pendulum/swingup.py:62-122: observation
+ * (cos q, sin q, qvel), reward -w_theta*wrap(q - pi)^2 - w_dtheta*qvel^2 - w_u*ctrl^2, done = 0) and what brax's EpisodeWrapper and
+ * AutoResetWrapper add around it inside ppo.train (reference examples/rl/pendulum/ex_swingup.py:25-43 passes episode_length):
+ * step counter, truncation at the episode length, done, episode returns, and the select that restarts a finished env from the
+ * state it was first reset to.  The reference's env.step is one jitted XLA program; torch would run these as dozens of small
+ * kernels per step.
+ *   observation term k: kind 0 qpos[i], 1 cos(qpos[i]), 2 sin(qpos[i]), 3 qvel[i]                        (i = obs_index[k])
+ *   reward = - sum_k rew_weight[k] * t_k^2, term kind 0 wrap_to_pi(qpos[i] - target), 1 qpos[i] - target, 2 qvel[i], 3 ctrl[i]
+ *   (wrap_to_pi(x) = atan2(sin x, cos x); ctrl is the action as given, not clamped: Data.ctrl of the reference) */
+#define AMX_TAIL_MAX_OBS 16
+#define AMX_TAIL_MAX_REW 8
+typedef struct amx_env_tail_desc {
+  int nobs, obs_kind[AMX_TAIL_MAX_OBS], obs_index[AMX_TAIL_MAX_OBS];
+  int nrew, rew_kind[AMX_TAIL_MAX_REW], rew_index[AMX_TAIL_MAX_REW];
+  float rew_target[AMX_TAIL_MAX_REW], rew_weight[AMX_TAIL_MAX_REW];
+  int episode_length; /* control steps after which an episode is truncated */
+} amx_env_tail_desc;
+/* Device pointers, fp32, env-major.  Inputs: the first (reset) state and observation of every env and the episode counters
+ * before the step.  Outputs (written by the call, must not alias the inputs of the same call): the state after the step with
+ * finished envs restarted (qpos, qvel, ctrl, qacc_warmstart, time), qacc (the solver's result before the restart select),
+ * obs (of the restarted state), terminal_obs (before the restart), reward, done, truncation and the counters after the step.
+ * step_counter_{in,out}: one float shared by all envs (the env's own step count), may be NULL. */
+typedef struct amx_env_tail_io {
+  const float *first_qpos, *first_qvel, *first_ctrl, *first_warm, *first_time, *first_obs;
+  const float *steps, *episode_return, *last_episode_return, *episodes, *step_counter_in;
+  float *qpos_out, *qvel_out, *ctrl_out, *warm_out, *time_out, *qacc_out;
+  float *obs_out, *terminal_obs_out, *reward_out, *done_out, *truncation_out;
+  float *steps_out, *episode_return_out, *last_episode_return_out, *episodes_out, *step_counter_out;
+} amx_env_tail_io;
+int amx_env_step(const amx_model *m, int nenv, int nsub, const float *qpos_dev, const float *qvel_dev, const float *action_dev,
+                 const float *qacc_warmstart_dev, const float *time_dev, const amx_env_tail_desc *tail, const amx_env_tail_io *io,
+                 void *stream);
+
 /* vmap(shoot): xs[e,0,:] = x0[e], xs[e,t+1,:] = concat(qpos,qvel) after step t under us[e,t,:].
  * x0 is [nenv,nq+nv] when x0_batched != 0, else one shared [nq+nv] row.  State stays on chip
  * for the whole horizon; HBM traffic is us in, xs out.  xs_dev may be NULL when only the final

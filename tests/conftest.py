@@ -9,6 +9,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The tests name the kernels they mean: put_model(mj, dev) = the library's own (generic unless the model is shipped),
+# put_model(..., specialise=True) = a per-model build.  The package's default ("auto": per-model builds whenever hipcc is there) would
+# compile every fuzz draw.
+os.environ.setdefault("AMX_SPECIALISE", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 

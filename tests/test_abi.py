@@ -22,7 +22,7 @@ def declared_functions():
 
 def test_library_exports_every_declared_symbol():
     names = declared_functions()
-    assert set(names) == set(_lib.EXPORTS) and len(names) == 12
+    assert set(names) == set(_lib.EXPORTS) and len(names) == 13
     lib = _lib.lib()
     for n in names:
         assert hasattr(lib, n), n
@@ -44,6 +44,26 @@ def test_desc_layout_matches_c(tmp_path):
     assert int(out["sizeof"]) == C.sizeof(AmxModelDesc)
     for f in fields:
         assert int(out[f]) == getattr(AmxModelDesc, f).offset, f
+
+
+def test_env_tail_layout_matches_c(tmp_path):
+    """amx_env_tail_desc / amx_env_tail_io (the fused env.step, amx_env_step) as gcc sees the header vs the ctypes mirrors."""
+    src = tmp_path / "layout2.c"
+    dfields = ["nobs", "obs_kind", "obs_index", "nrew", "rew_kind", "rew_index", "rew_target", "rew_weight", "episode_length"]
+    lines = "".join(f'  printf("d.{f} %zu\\n", offsetof(amx_env_tail_desc, {f}));\n' for f in dfields)
+    lines += "".join(f'  printf("io.{f} %zu\\n", offsetof(amx_env_tail_io, {f}));\n' for f in _lib.TAIL_IO_FIELDS)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "amx.h"\nint main(void){\n  printf("sizeof_d %zu\\n", sizeof(amx_env_tail_desc));\n'
+                   '  printf("sizeof_io %zu\\n", sizeof(amx_env_tail_io));\n' + lines + "  return 0;\n}\n")
+    exe = tmp_path / "layout2"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    assert int(out["sizeof_d"]) == C.sizeof(_lib.AmxEnvTailDesc) and int(out["sizeof_io"]) == C.sizeof(_lib.AmxEnvTailIO)
+    for f in dfields:
+        assert int(out["d." + f]) == getattr(_lib.AmxEnvTailDesc, f).offset, f
+    for f in _lib.TAIL_IO_FIELDS:
+        assert int(out["io." + f]) == getattr(_lib.AmxEnvTailIO, f).offset, f
+    lib = _lib.lib()
+    assert lib.amx_env_step(None, 0, 1, None, None, None, None, None, None, None, None) == _lib.AMX_EINVAL  # codes, not exceptions
 
 
 def test_error_reporting_without_gpu(mj_models):

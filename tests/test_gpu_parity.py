@@ -221,6 +221,23 @@ def test_per_model_specialised_build_runs(cases, dev):
     print(f"per-model build: 4096 x 50 rollout generic {1e3 * t['generic']:.2f} ms, specialised {1e3 * t['specialised']:.2f} ms")
 
 
+def test_put_model_default_builds_per_model_kernels_or_says_so(dev, monkeypatch, caplog):
+    """mjx.put_model's default (AMX_SPECIALISE unset = "auto", r04): a model without shipped kernels gets its per-model build when
+    hipcc is on the machine; without hipcc it runs on the generic kernels and ONE log line says so (bench.py's "C3 generic kernels"
+    line is what that costs).  The test suite itself pins AMX_SPECIALISE=0 (conftest.py)."""
+    import logging
+    from test_abi import jit_test_model
+    from ambersim_amd import mjx
+    mj = jit_test_model()
+    monkeypatch.setenv("AMX_SPECIALISE", "auto")
+    assert mjx.put_model(mj, dev)._h.query("specialised") == 1  # built by tests/test_abi.py on the build machine, found in csrc/jit/ here
+    monkeypatch.setenv("HIPCC", "/nonexistent/hipcc")
+    with caplog.at_level(logging.WARNING, logger="ambersim_amd"):
+        generic = mjx.put_model(mj, dev)
+    assert generic._h.query("specialised") == 0
+    assert sum("generic kernels" in r.getMessage() for r in caplog.records) == 1
+
+
 def test_per_model_build_with_equality_rows(cases, dev):
     """The static solves' remaining combination (32-lane group, stored Hessian, dense elimination, right-hand side broadcast on
     its own): the quadruped with its front knees coupled, compiled for its plan, against the generic kernels and the oracle."""
@@ -696,6 +713,46 @@ def test_unroll_as_hip_graph_matches_eager(dev):
             resets += int(a.done.sum().item())
         assert resets == 256  # every env was reset once inside the captured unrolls
         assert float(a.state.info["step"].item()) == 40.0  # the env's own counter lives on the device and advances in replays
+
+
+def test_fused_env_step_matches_the_torch_path(dev):
+    """amx_env_step (the physics launch + ONE elementwise launch for observation, reward, episode counters, done and the auto-reset
+    select: the body of reference ambersim/rl/pendulum/swingup.py:62-122 plus brax's Episode / AutoReset wrappers) against the same
+    transition written as torch code (the env's compute_obs / compute_reward and EpisodeAutoReset.step): 60 steps of 300 envs under
+    random actions across two episode boundaries - every field of the State within rounding of the trigonometric functions
+    (the physics is the same kernel: qpos / qvel bit-identical until an observation feeds nothing back), counters exact."""
+    from ambersim_amd.rl import ppo
+    from ambersim_amd.rl.pendulum.swingup import PendulumSwingupEnv
+    from ambersim_amd.rl.wrappers import EpisodeAutoReset
+    env = PendulumSwingupEnv(num_envs=300, device=dev)
+    fused, plain = EpisodeAutoReset(env, episode_length=25), EpisodeAutoReset(env, episode_length=25, fused=False)
+    assert fused._tail is not None and plain._tail is None
+    g = torch.Generator(device=dev).manual_seed(3)
+    with torch.no_grad():
+        sa = fused.reset(torch.Generator(device=dev).manual_seed(1))
+        sb = plain.reset(torch.Generator(device=dev).manual_seed(1))
+        ndone = 0
+        for t in range(60):
+            act = 4 * torch.rand((300, 1), generator=g, device=dev) - 2
+            before = [x.clone() for x in ppo._leaves(sa)]
+            na, nb = fused.step(sa, act), plain.step(sb, act)
+            for x, y in zip(ppo._leaves(sa), before):
+                assert torch.equal(x, y)  # functional: the input State is untouched
+            sa, sb = na, nb
+            assert torch.equal(sa.pipeline_state.qpos, sb.pipeline_state.qpos) and torch.equal(sa.pipeline_state.qvel, sb.pipeline_state.qvel)
+            assert torch.equal(sa.pipeline_state.time, sb.pipeline_state.time) and torch.equal(sa.pipeline_state.ctrl, sb.pipeline_state.ctrl)
+            assert torch.equal(sa.done, sb.done) and torch.equal(sa.info["truncation"], sb.info["truncation"])
+            for k in ("steps", "episodes"):
+                assert torch.equal(sa.info[k], sb.info[k]), k
+            assert float(sa.info["step"]) == float(sb.info["step"]) == t + 1
+            assert float((sa.obs - sb.obs).abs().max()) < 2e-6 and float((sa.info["terminal_obs"] - sb.info["terminal_obs"]).abs().max()) < 2e-6
+            assert float((sa.reward - sb.reward).abs().max()) < 1e-5 * max(1.0, float(sb.reward.abs().max()))
+            for k in ("episode_return", "last_episode_return"):
+                assert float((sa.info[k] - sb.info[k]).abs().max()) < 1e-4 * max(1.0, float(sb.info[k].abs().max())), k
+            ndone += int(sa.done.sum().item())
+        assert ndone == 600  # two episode boundaries per env
+    # the graph-captured collector runs on the fused step (same bit-identity between eager and replay as the torch path)
+    assert ppo.graphs_available(env, dev)
 
 
 def test_random_models_vs_oracle(dev):

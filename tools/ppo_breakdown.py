@@ -8,7 +8,7 @@ from ambersim_amd.rl.pendulum.swingup import PendulumSwingupEnv
 from ambersim_amd.rl.wrappers import EpisodeAutoReset
 dev = torch.device("cuda", 0)
 N = 1024
-env = PendulumSwingupEnv(num_envs=N, device=dev); w = EpisodeAutoReset(env, 200)
+env = PendulumSwingupEnv(num_envs=N, device=dev); w = EpisodeAutoReset(env, 200); w_plain = EpisodeAutoReset(env, 200, fused=False)
 nets = make_ppo_networks(3, 1, policy_hidden_layer_sizes=(64,) * 3)
 nets.policy_network.to(dev); nets.value_network.to(dev); nets.policy_network(torch.zeros(1, 3, device=dev)); nets.value_network(torch.zeros(1, 3, device=dev))
 norm = ppo.RunningStatistics(3, dev); norm.update(torch.randn(100, 3, device=dev))
@@ -30,7 +30,12 @@ with torch.no_grad():
     d = s0.pipeline_state
     t = timeit(lambda: mjx.step(env.sys, d.replace(ctrl=torch.zeros(N, 1, device=dev)), 1), 200); print(f"mjx.step eager (one amx_step_to + shim): {1e6*t:.1f} us")
     t = timeit(lambda: env.step(s0, torch.zeros(N, 1, device=dev)), 100); print(f"env.step eager: {1e6*t:.1f} us")
-    t = timeit(lambda: w.step(s0, torch.zeros(N, 1, device=dev)), 100); print(f"wrapped env.step eager: {1e6*t:.1f} us")
+    t = timeit(lambda: w_plain.step(s0, torch.zeros(N, 1, device=dev)), 100); print(f"wrapped env.step eager, torch path (env + wrapper as torch code): {1e6*t:.1f} us")
+    t = timeit(lambda: w.step(s0, torch.zeros(N, 1, device=dev)), 200); print(f"wrapped env.step eager, fused (amx_env_step: physics + one elementwise launch): {1e6*t:.1f} us")
+    for name, ww in (("torch path", w_plain), ("fused", w)):
+        c = ppo.Collector(ww, nets, norm, 10, 0.1, s0, use_graph=True)
+        t = timeit(lambda: c(gen), 50)
+        print(f"collector unroll of 10 steps x {N} envs as a graph, {name}: {1e3*t:.3f} ms -> {10*N/t/1e6:.2f} M env-steps/s")
 # ---- the update step
 import math
 obs_size, act_size, n, mb = 3, 1, 163840, 5120
