@@ -347,7 +347,10 @@ def env_step(m: Model, d: Data, action: torch.Tensor, nsub: int, tail, first: Da
     if not b:
         raise ValueError("env_step: the state must carry the batch axis")
     dev = m.device
-    f32 = lambda x, shape: _c(x.to(device=dev, dtype=torch.float32).expand(shape))
+    def f32(x, shape):  # the common case - already fp32, on the device, contiguous, full shape - costs three comparisons
+        if x.dtype is torch.float32 and x.device == dev and tuple(x.shape) == shape and x.is_contiguous():
+            return x
+        return _c(x.to(device=dev, dtype=torch.float32).expand(shape))
     act = f32(action, (n, m.nu))
     time = f32(d.time if torch.is_tensor(d.time) else torch.tensor(float(d.time or 0.0)), (n,))
     fq, fv, fw = f32(first.qpos, (n, m.nq)), f32(first.qvel, (n, m.nv)), f32(first.qacc_warmstart, (n, m.nv))
@@ -376,8 +379,9 @@ def env_step(m: Model, d: Data, action: torch.Tensor, nsub: int, tail, first: Da
     with torch.cuda.device(dev):
         _lib.check(m._h.L.amx_env_step(m._h.ptr, n, int(nsub), t["qpos"].data_ptr(), t["qvel"].data_ptr(), act.data_ptr(), t["qacc_warmstart"].data_ptr(),
                                            time.data_ptr(), C.byref(tail), C.byref(io), _stream_ptr(dev)), m._h.L)
-    data = d.replace(qpos=o["qpos_out"], qvel=o["qvel_out"], ctrl=o["ctrl_out"], qacc_warmstart=o["warm_out"], time=o["time_out"],
-                     qacc=o["qacc_out"] if m.nefc_max > 0 else d.qacc)
+    data = Data(qpos=o["qpos_out"], qvel=o["qvel_out"], ctrl=o["ctrl_out"], qacc_warmstart=o["warm_out"], time=o["time_out"],
+                qacc=o["qacc_out"] if m.nefc_max > 0 else d.qacc, qacc_smooth=d.qacc_smooth, qfrc_bias=d.qfrc_bias, qfrc_constraint=d.qfrc_constraint,
+                xpos=d.xpos, xquat=d.xquat)  # (the derived leaves are stale pass-throughs, as after mjx.step)
     out = {"obs": o["obs_out"], "terminal_obs": o["terminal_obs_out"], "reward": o["reward_out"], "done": o["done_out"], "truncation": o["truncation_out"],
            "steps": o["steps_out"], "episode_return": o["episode_return_out"], "last_episode_return": o["last_episode_return_out"], "episodes": o["episodes_out"]}
     if step_out is not None:

@@ -248,18 +248,24 @@ class Collector:
         self.done, self.trunc, self.nobs = f(self.T, N), f(self.T, N), f(self.T, N, O)
 
         def body():
+            # per step only what the next step needs (normalise, policy, sample, env.step); the trajectory buffers are filled once
+            # per unroll - one stack per field and ONE log-probability evaluation over [T, N] - instead of seven small copies and a
+            # dozen elementwise kernels per step (r04: 96 -> 7x us per step of the captured unroll, profiles/r04_ppo_breakdown.txt)
             s = self.state
+            obs_l, par_l, raw_l, rew_l, done_l, trunc_l, nobs_l = [], [], [], [], [], [], []
             for t in range(self.T):
                 obs = s.obs
                 x = norm.normalize(obs) if norm is not None else obs
                 params = nets.policy_network(x)
                 loc, scale = dist._split(params)
                 raw = loc + scale * self.noise[t]
-                self.obs[t].copy_(obs)  # before env.step: the wrapper may hand the same buffer back
-                s = env.step(s, dist.postprocess(raw))
-                self.raw[t].copy_(raw); self.logp[t].copy_(dist.log_prob(params, raw))
-                self.rew[t].copy_(s.reward * reward_scaling); self.done[t].copy_(s.done); self.trunc[t].copy_(s.info["truncation"])
-                self.nobs[t].copy_(s.info["terminal_obs"])
+                obs_l.append(obs); par_l.append(params); raw_l.append(raw)
+                s = env.step(s, dist.postprocess(raw))  # functional: fresh output tensors, the ones collected above stay as they are
+                rew_l.append(s.reward); done_l.append(s.done); trunc_l.append(s.info["truncation"]); nobs_l.append(s.info["terminal_obs"])
+            torch.stack(obs_l, out=self.obs); torch.stack(raw_l, out=self.raw)
+            self.logp.copy_(dist.log_prob(torch.stack(par_l), self.raw))
+            torch.stack(rew_l, out=self.rew); self.rew.mul_(reward_scaling)
+            torch.stack(done_l, out=self.done); torch.stack(trunc_l, out=self.trunc); torch.stack(nobs_l, out=self.nobs)
             _write_back(self.state, s)
         self._run = _Replayable(body, use_graph, dev, warmup=0)  # no warm-up run: it would advance the envs (capture does not execute)
 
