@@ -66,6 +66,7 @@ def render_record(name: str, p: dict) -> str:
     p = dict(p)
     parents = [int(x) for x in p.pop("dof_parent").split(",")]
     tree_h = int(p.pop("tree_H"))
+    p2_col = [int(x) for x in p.pop("p2_col").split(",")]
     pad = parents + [-1] * (32 - len(parents))
     return "\n".join([
         f"struct Spec_{name} {{",
@@ -74,6 +75,7 @@ def render_record(name: str, p: dict) -> str:
         "  " + " ".join(f"static constexpr int {k} = {v};" for k, v in p.items()),
         f"  static constexpr bool tree_H = {'true' if tree_h else 'false'};  // J'DJ keeps the dof tree's sparsity",
         f"  static constexpr int dof_parent[32] = {{{', '.join(str(x) for x in pad)}}};",
+        f"  static constexpr int p2_col[32] = {{{', '.join(str(x) for x in p2_col)}}};  // mfma2: column of register k of pair k / 16's block (dof, nv = gradient, -1 none)",
         "};"])
 
 

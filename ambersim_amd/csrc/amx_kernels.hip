@@ -89,6 +89,7 @@ struct DynSpec {
 #undef X
   static constexpr bool tree_H = false;
   static constexpr int dof_parent[32] = {};
+  static constexpr int p2_col[32] = {};
 };
 template <class S> struct MV {
   const DevModel &d;
@@ -611,35 +612,76 @@ DEV void jtdj_rows_mfma(unsigned long long crows, int row_base, int J_base, int 
     if constexpr (AUGN >= 0) C = *cinit;
     // the first active contact starts the accumulator from the instruction's constant 0 operand: clearing 32 registers
     // with v_mov costs as much VALU time as two more contacts' operand loads
-    auto contact = [&](auto first) {
+#ifndef AMX_MFMA_PREFETCH
+#define AMX_MFMA_PREFETCH 1  // 0: every contact's operands are loaded right in front of its own matrix instructions (r03), A/B switch
+#endif
+#ifdef AMX_EXPERIMENT_DOUBLE_MFMA
+    v32f C2 = {};
+#endif
+    // one contact's operands: D and J[j] of its four pyramid rows (+ the row's force / residual for COL31 / AUGN)
+    struct Ops { float d[4], jv[4], g[4]; bool has; unsigned rbits; };
+    auto load = [&]() {
+      Ops o;
       const int c = __builtin_ctzll(cm) >> 2;
       cm &= cm - 1ull;
       const int slot = CI(slot_base + 32 * c + j);
-      const bool has = slot >= 0;
-      const int Jr = J_base + 4 * c * ldc + (has ? slot : 0), Dr = row_base + 4 * c * ROW_E;
-      float d[4], jv[4], g[4];
+      o.has = slot >= 0;
+      const int Jr = J_base + 4 * c * ldc + (o.has ? slot : 0), Dr = row_base + 4 * c * ROW_E;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        d[r] = lds[Dr + r * ROW_E]; jv[r] = lds[Jr + r * ldc];
-        if (COL31) g[r] = lds[Dr + r * ROW_E + 1];
-        if (AUGN >= 0) g[r] = lds[Dr + r * ROW_E + 2];
+        o.d[r] = lds[Dr + r * ROW_E]; o.jv[r] = lds[Jr + r * ldc];
+        o.g[r] = 0.0f;
+        if (COL31) o.g[r] = lds[Dr + r * ROW_E + 1];
+        if (AUGN >= 0) o.g[r] = lds[Dr + r * ROW_E + 2];
       }
       // a pyramid row that is inactive in both environments has D = 0 and f = 0 everywhere: its instruction (64 cycles of the
       // matrix pipe, on the dependent chain) is skipped on a scalar test of its bit - except the one that starts the accumulator
-      const unsigned rbits = (unsigned)(crows >> (4 * c)) & 15u;
+      o.rbits = (unsigned)(crows >> (4 * c)) & 15u;
+      return o;
+    };
+    auto issue = [&](const Ops &o, auto first) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float v0 = has ? jv[r] : 0.0f;
-        const float v = (AUGN >= 0 && j == AUGN) ? g[r] : v0;
-        const float aop = (COL31 && j == 31) ? g[r] : d[r] * v;
+        const float v0 = o.has ? o.jv[r] : 0.0f;
+        const float v = (AUGN >= 0 && j == AUGN) ? o.g[r] : v0;
+        const float aop = (COL31 && j == 31) ? o.g[r] : o.d[r] * v;
         if (AUGN < 0 && decltype(first)::value && r == 0) { const v32f Z = {}; C = __builtin_amdgcn_mfma_f32_32x32x1f32(aop, v, Z, 0, 0, 0); }
-        else if (AMX_MFMA_ALL_ROWS || ((rbits >> r) & 1u)) C = __builtin_amdgcn_mfma_f32_32x32x1f32(aop, v, C, 0, 0, 0);
+        else if (AMX_MFMA_ALL_ROWS || ((o.rbits >> r) & 1u)) {
+          C = __builtin_amdgcn_mfma_f32_32x32x1f32(aop, v, C, 0, 0, 0);
+#ifdef AMX_EXPERIMENT_DOUBLE_MFMA  // timing experiment (same results): every row's instruction issued twice, the copy into a dead accumulator
+          C2 = __builtin_amdgcn_mfma_f32_32x32x1f32(aop, v, C2, 0, 0, 0);
+#endif
+        }
       }
     };
     if (cm != 0ull) {
-      contact(std::true_type{});
-      while (cm != 0ull) contact(std::false_type{});
+#if AMX_MFMA_PREFETCH
+      // software pipeline over the active contacts (r04): the loads of contact k + 1 are issued in front of the matrix instructions
+      // of contact k - with every contact of a standing robot active, a contact was an LDS round trip (~200 cycles) followed by
+      // its four 64-cycle instructions, eight times per Hessian (phase profile: 3.8 k cycles per Hessian for 2.0 k of matrix pipe)
+      Ops cur = load();
+      bool more = cm != 0ull;
+      if (more) {
+        Ops nxt = load();
+        issue(cur, std::true_type{});
+        cur = nxt;
+        while (cm != 0ull) {
+          nxt = load();
+          issue(cur, std::false_type{});
+          cur = nxt;
+        }
+        issue(cur, std::false_type{});
+      } else {
+        issue(cur, std::true_type{});
+      }
+#else
+      { const Ops o = load(); issue(o, std::true_type{}); }
+      while (cm != 0ull) { const Ops o = load(); issue(o, std::false_type{}); }
+#endif
     }
+#ifdef AMX_EXPERIMENT_DOUBLE_MFMA
+    asm volatile("" :: "v"(C2));
+#endif
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -1216,6 +1258,195 @@ AMX_STATIC_SOLVE_ATTR bool newton_solve_fused(int M_off, int ld_, int n_, unsign
   WSYNC();
   return false;
 }
+// ---- Newton direction of a two-pair model (planner: mfma2 - a biped's two feet; r04).  Same contract as the GRADCOL form of
+// newton_solve_fused; what differs is how J'DJ and J'f reach the elimination's registers.
+// The 32 x 32 two-block instruction spends 64 cycles of the matrix pipe per pyramid row on a product of which 12 x 12 entries per
+// environment are non-zero (a foot's rows touch the base and one leg), and the pipe's time is not hidden: with every contact of a
+// standing robot active, issuing each instruction twice cost 10.9 % of the step (profiles/r04_ab_mfma.txt).  Here the product is
+// formed chain-compressed: v_mfma_f32_16x16x1_4b_f32 has four 16 x 16 blocks = (environment, pair); lane 16 f + k of an environment
+// feeds block (env, f) - as B operand the Jacobian entry of the dof whose ROW it will hold, as A operand the entry of the dof
+// register k stands for (amx_plan.h: c_p2, Spec::p2_col; one A lane carries the row's residual, which makes column `nv` the gradient).
+// One instruction takes a row of EACH pair in both environments: 16 instructions of 32 cycles per Hessian instead of 32 of 64.
+// The accumulator gives lane (g, j) entries 4 g .. 4 g + 3 of column j of every block; four row exchanges per register quadruple
+// transpose that into "lane (b, j) holds column j = row j of ITS block", 16 entries.  The rows then go home: the planner has put a
+// pair's rows either in their dofs' own lanes (added in place) or in the other 16-lane row at (position + shift) - one
+// v_permlane16_swap and a DPP row shift on the add - and every other lane the adds' bank masks enable holds an all-zero row.
+// The mirrored right-hand-side row of lane nv is staged through LDS (the 32 x 32 form got it from the product's symmetry).
+#ifndef AMX_MFMA_PAIR2
+#define AMX_MFMA_PAIR2 1  // 0: two-pair models keep the 32 x 32 two-block product (A/B switch)
+#endif
+typedef float v16acc __attribute__((ext_vector_type(16)));
+template <int CTRL_SHL, int ROWS, int BANKS> DEV void p2_add(float &acc, float src) {
+  // acc += src read through DPP (row_shl:CTRL_SHL, or in place), on the lanes of the 16-lane rows ROWS (mask) and banks BANKS only
+  if constexpr (CTRL_SHL == 0)
+    asm("v_add_f32_dpp %0, %1, %0 quad_perm:[0,1,2,3] row_mask:%2 bank_mask:%3" : "+v"(acc) : "v"(src), "n"(ROWS), "n"(BANKS));
+  else
+    asm("v_add_f32_dpp %0, %1, %0 row_shl:%4 row_mask:%2 bank_mask:%3 bound_ctrl:1" : "+v"(acc) : "v"(src), "n"(ROWS), "n"(BANKS), "n"(CTRL_SHL));
+}
+// Two wait states between the lane swaps that wrote r[0..15] and the DPP reads (inline assembly: the hazard recogniser cannot pad them)
+// that follow: every register passes through this statement, so the compiler has to keep all their writers in front of it and all
+// their readers behind it.
+DEV void p2_fence(float (&r)[16]) {
+  asm volatile("s_nop 1" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]), "+v"(r[10]),
+               "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]));
+}
+template <class S, bool TREE>
+AMX_STATIC_SOLVE_ATTR bool newton_solve_pair2(int M_off, unsigned long long crows_, int row_base, int J_base, int rhs_off, int x_off, float dlim, int gl, int gb4, int rot,
+                                                int bt_off, float flim, float ma_v, float fs_v, int fcon_off, bool store_ok, bool early_out, bool imp_done, float scale,
+                                                float tol, ProfCtx *pc, bool *group_done) {
+  constexpr int G = 32, NS = S::nv, lds_ = S::ldm, nchs = lds_ / 4;
+  static_assert(S::mfma2 && NS <= 30 && lds_ >= NS + 1, "two-pair form: planner's mfma2");
+  int gle = gl;  // see spd_solve_static
+  asm volatile("" : "+v"(gle));
+  const unsigned crows_u = (unsigned)__builtin_amdgcn_readfirstlane((int)crows_);  // 32 contact rows: bits 0..15 pair 0, 16..31 pair 1
+  const bool owner = gl < NS, brow = gl == NS;
+  const int li = owner ? gl : 0;
+  // the limit row's diagonal term rides in M's stored diagonal for the duration of the row loads (as in newton_solve_fused)
+  int dpc = (gl >> 2) + (S::mrot ? rot : 0);
+  dpc -= dpc >= nchs ? nchs : 0;
+  const int dg = M_off + li * lds_ + 4 * dpc + (gl & 3);
+  float d0 = 0.0f;
+  if (owner) { d0 = lds[dg]; lds[dg] = d0 + dlim; }
+  PROF_CTX(pc, 24);
+  // the lane's row of M (lanes without one: the constants' all-zero row); entry NS starts as ma - fs - flim of the lane's dof
+  float a[NS + 1];
+  {
+    const float4 *rowp = reinterpret_cast<const float4 *>(lds + (owner ? M_off + li * lds_ : S::c_zero));
+    const int rot_l = owner ? rot : 0;
+#pragma unroll
+    for (int c = 0; c < (NS + 3) / 4; ++c) {
+      int pcc = c + (S::mrot ? rot_l : 0);
+      pcc -= pcc >= nchs ? nchs : 0;
+      const float4 v = rowp[pcc];
+      const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (4 * c + q < NS) a[4 * c + q] = e[q];
+    }
+  }
+  a[NS] = owner ? ma_v - fs_v - flim : 0.0f;
+  // ---- the product.  This lane: pair f = bit 4 of the lane, operand slots from the constants
+  const int f = (gl >> 4) & 1;
+  const int pk = CI(S::c_p2 + gl);
+  const int sA = pk & 255, sB = (pk >> 8) & 255;
+  const bool hasA = sA < 0xFE, augA = sA == 0xFE, hasB = sB < 0xFE;
+  const int JB = J_base + 16 * f * S::ldc + (hasB ? sB : 0), Dr = row_base + 16 * f * ROW_E;
+  // the A operand's address: entry sA of the row's Jacobian, or - the lane that carries the residual - field 2 of the row record
+  const int JA = augA ? Dr + 2 : J_base + 16 * f * S::ldc + (hasA ? sA : 0), strideA = augA ? ROW_E : S::ldc;
+  unsigned tm = (crows_u | (crows_u >> 16)) & 0xFFFFu;  // row t of either pair active in some environment of the wave
+  v16acc C = {};
+  struct Ops { float aop, bv; };
+  auto load = [&]() {
+    const int t = __builtin_ctz(tm);
+    tm &= tm - 1u;
+    const float d = lds[Dr + t * ROW_E], ja = lds[JA + t * strideA], jb = lds[JB + t * S::ldc];
+    return Ops{d * ((hasA | augA) ? ja : 0.0f), hasB ? jb : 0.0f};
+  };
+  if (tm != 0u) {  // software pipeline: the operands of the next row are in flight while this one's instruction runs
+    Ops cur = load();
+    while (tm != 0u) {
+      const Ops nxt = load();
+      C = __builtin_amdgcn_mfma_f32_16x16x1f32(cur.aop, cur.bv, C, 0, 0, 0);
+      cur = nxt;
+    }
+    C = __builtin_amdgcn_mfma_f32_16x16x1f32(cur.aop, cur.bv, C, 0, 0, 0);
+  }
+  PROF_CTX(pc, 25);
+  if (owner) lds[dg] = d0;  // M's own diagonal back (the row loads above are done: one wave's LDS operations execute in order)
+  // ---- transpose: register 4 b + r of lane (g, j) holds entry 4 g + r of column j of block b; wanted: lane (b, j) holds entries
+  // 4 g' + r, g' = 0..3, of column j of ITS block.  Per r a 4 x 4 transpose of 16-lane row pieces among four registers: two
+  // v_permlane16_swap (rows 0 <-> 1, 2 <-> 3 between register pairs) and two v_permlane32_swap (rows {2, 3} <-> {0, 1}).
+  float R[16];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    auto s01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(C[r]), __float_as_uint(C[4 + r]), false, false);
+    auto s23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(C[8 + r]), __float_as_uint(C[12 + r]), false, false);
+    auto t02 = __builtin_amdgcn_permlane32_swap(s01[0], s23[0], false, false);
+    auto t13 = __builtin_amdgcn_permlane32_swap(s01[1], s23[1], false, false);
+    R[r] = __uint_as_float(t02[0]); R[4 + r] = __uint_as_float(t13[0]); R[8 + r] = __uint_as_float(t02[1]); R[12 + r] = __uint_as_float(t13[1]);
+  }
+  // ---- the rows go home.  Lanes of the rows 0 / 2 of the wave (an environment's first 16 lanes) hold pair 0's block, rows 1 / 3 pair 1's.
+  constexpr int BH0 = S::p2_banks & 15, BH1 = (S::p2_banks >> 4) & 15, BC0 = (S::p2_banks >> 8) & 15, BC1 = (S::p2_banks >> 12) & 15;
+  p2_fence(R);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int c0 = S::p2_col[k], c1 = S::p2_col[16 + k];
+    if (c0 >= 0) p2_add<0, 0x5, BH0>(a[c0], R[k]);   // pair 0's rows in their own lanes
+    if (c1 >= 0) p2_add<0, 0xA, BH1>(a[c1], R[k]);   // pair 1's
+  }
+  // The other half of the rows sits one 16-lane row away: pair 1's rows of dofs that live in rows 0 / 2 and pair 0's rows of dofs
+  // that live in rows 1 / 3.  Registers are exchanged in PAIRS (k, k'), two v_permlane16_swap per pair and no copies (the home adds
+  // above were their last readers): the first swap leaves k's pair-1 entries in rows 0 / 2 of one register and k''s pair-0
+  // entries in rows 1 / 3 of the other; swapping the two results once more gives the other two combinations.
+  constexpr int NK = [] { int n = 0; for (int k = 0; k < 16; ++k) n += (S::p2_col[k] >= 0 || S::p2_col[16 + k] >= 0) ? 1 : 0; return n; }();
+  static_assert(NK >= 1 && NK <= 16, "two-pair form: columns");
+  // (the planner fills the registers from 0 upward: the used ones are 0 .. NK - 1)
+  // Two rounds, so that every swap works in place: all first swaps, their four adds per pair (the last readers of the results),
+  // then all second swaps on the same registers, and the remaining adds.
+  float P[16], Q[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { P[k] = 0.0f; Q[k] = 0.0f; }
+#pragma unroll
+  for (int k = 0; k < NK; k += 2) {
+    const int k2 = k + 1 < NK ? k + 1 : k;  // an odd register count: the last one pairs with itself (both results come out of one swap)
+    auto s1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(R[k]), __float_as_uint(R[k2]), false, false);  // (k.r0, k'.r0), (k.r1, k'.r1)
+    P[k] = __uint_as_float(s1[0]); Q[k] = __uint_as_float(s1[1]);
+  }
+  p2_fence(P);
+  p2_fence(Q);
+#pragma unroll
+  for (int k = 0; k < NK; k += 2) {
+    const int k2 = k + 1 < NK ? k + 1 : k;
+    // rows 0 / 2 read k.r1 = pair 1's entries of register k; rows 1 / 3 read k'.r0 = pair 0's entries of register k'
+    if (S::p2_col[16 + k] >= 0) p2_add<S::p2_shl1, 0x5, BC0>(a[S::p2_col[16 + k] >= 0 ? S::p2_col[16 + k] : 0], Q[k]);
+    if (S::p2_col[k2] >= 0) p2_add<S::p2_shl0, 0xA, BC1>(a[S::p2_col[k2] >= 0 ? S::p2_col[k2] : 0], P[k]);
+  }
+#pragma unroll
+  for (int k = 0; k + 1 < NK; k += 2) {
+    auto s2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(Q[k]), __float_as_uint(P[k]), false, false);  // (k.r1, k.r0), (k'.r1, k'.r0)
+    P[k] = __uint_as_float(s2[0]); Q[k] = __uint_as_float(s2[1]);
+  }
+  p2_fence(P);
+  p2_fence(Q);
+#pragma unroll
+  for (int k = 0; k + 1 < NK; k += 2) {
+    // rows 1 / 3 read k.r0 = pair 0's entries of register k; rows 0 / 2 read k'.r1 = pair 1's entries of register k'
+    if (S::p2_col[k] >= 0) p2_add<S::p2_shl0, 0xA, BC1>(a[S::p2_col[k] >= 0 ? S::p2_col[k] : 0], P[k]);
+    if (S::p2_col[16 + k + 1] >= 0) p2_add<S::p2_shl1, 0x5, BC0>(a[S::p2_col[16 + k + 1] >= 0 ? S::p2_col[16 + k + 1] : 0], Q[k]);
+  }
+  PROF_CTX(pc, 26);
+  const float b = owner ? a[NS] : 0.0f;  // the gradient ma - fs - flim - J'f
+  const float fcon = ma_v - fs_v - b;    // = flim + J'f of the contact rows
+  if (owner && store_ok) { lds[fcon_off + gl * DOF_E] = fcon; lds[rhs_off + gl * DOF_E] = b; }
+  // the mirrored right-hand-side row: lane NS holds b as a row - staged through LDS, the store in front of the stopping test so that
+  // its round trip runs under that test's group sum
+  if (gl < lds_) lds[bt_off + gl] = b;
+  if (early_out) {
+    const float gn = gsum<G>(b * b);
+    const float ts_ = scale * tol;
+    const bool done = imp_done | (gn < ts_ * ts_);
+    if (group_done) *group_done = done;
+    if (!wave_any(store_ok & !done)) { WSYNC(); return true; }
+  }
+  WSYNC();
+  if (brow) {
+    const float4 *rowp = reinterpret_cast<const float4 *>(lds + bt_off);
+#pragma unroll
+    for (int c = 0; c < (NS + 3) / 4; ++c) {
+      const float4 v = rowp[c];
+      const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (4 * c + q < NS) a[4 * c + q] = e[q];
+    }
+  }
+  a[NS] = b;
+  float d = 1.0f;
+  sym_eliminate<S, G, TREE, true>(a, gle, d);
+  PROF_CTX(pc, 27);
+  if (owner) lds[x_off + gl * DOF_E] = fdiv(a[NS], AMX_PIVOT_CLAMP ? d : fmaxf(d, MINVAL));
+  WSYNC();
+  return false;
+}
+
 template <int G>
 __device__ __noinline__ void newton_fused_dyn(int nchol, int M_off, int ld, int n, unsigned long long crows, int row_base, int J_base, int ldc, int slot_base,
                                               int rhs_off, int x_off, float dlim, int gl, int gb4, int rot) {
@@ -2860,7 +3091,10 @@ struct Env {
 #else
         ProfCtx *pc = nullptr;
 #endif
-        if constexpr (grad_in_solve())
+        if constexpr (grad_in_solve() && S::mfma2 && AMX_MFMA_PAIR2)
+          stop = newton_solve_pair2<S, S::tree_H>(Mo, rows, eb + m.e_row() + row0 * ROW_E, Jo, dofoff(D_GRAD), dofoff(D_MGRAD), dlim, gl, gb4, m_rot, eb + m.e_H(), pend_flim,
+                                                  r_ma, r_fs, dofoff(D_FCON), alive, early_out, imp_done, m.scale(), m.tolerance(), pc, group_done);
+        else if constexpr (grad_in_solve())
           stop = newton_solve_fused<S, S::nv, G, S::tree_H, true>(Mo, ldm, nv, rows, eb + m.e_row() + row0 * ROW_E, Jo, ldc, m.c_slot(), dofoff(D_GRAD), dofoff(D_MGRAD), dlim, gl, gb4, m_rot,
                                                                  eb + m.e_H(), pend_flim, r_ma, r_fs, dofoff(D_FCON), alive, early_out, imp_done, m.scale(),
                                                                  m.tolerance(), pc, group_done);
@@ -3073,6 +3307,140 @@ struct Env {
     return improved ? -fminf(lo_delta, hi_delta) : 0.0f;
   }
 
+  // ---- the same search, second form (r04; static kernels whose rows are all one-sided: no equality, friction-loss, connect or weld
+  // rows).  Identical trial points and decisions; what changes is the instruction count of a bracketing iteration (101 -> ~80 vector
+  // instructions; fifteen iterations a step):
+  //  * the Gauss terms ride in the group sums: every lane adds its dof's share (alpha-independent) to its rows' coefficients, so the
+  //    reduced values are the whole q1, q2 and the per-point "+ g1", "+ g2" additions are gone;
+  //  * coefficients as packed pairs: (q1/2, q2) of a row slot is one register pair and "add the row if it is active at alpha" is one
+  //    v_pk_fma_f32 with the activity as a 0 / 1 factor - a compare, a select and one packed multiply-add per row slot and trial
+  //    point instead of a compare, two selects and two additions;
+  //  * derivatives carried HALVED (hd = d0 / 2 = q1/2 + alpha q2, h = d1 / 2 = max(q2, MINVAL/2)): every comparison of the search is
+  //    invariant under the factor (a power of two: exact), d0 / d1 = hd / h bit for bit, and "2 alpha", "2 q2" are never formed;
+  //  * the bracket logic on lane MASKS: every comparison is a v_cmp into a scalar register pair, and / or / not run on the scalar
+  //    unit, selects take the mask directly (the `bool` form kept `swap` as a 0 / 1 vector register across the unrolled iterations).
+  static constexpr bool ls_v2_ok() {
+#ifdef AMX_NO_LS_V2
+    return false;
+#else
+    return S::is_static && S::nfri == 0 && S::neq == 0 && S::npair == S::npc + S::nbl && S::ls_iterations <= 10;
+#endif
+  }
+  typedef unsigned long long lmask;
+  static DEV lmask LT(float a, float b) { return __builtin_amdgcn_ballot_w64(a < b); }
+  static DEV float SEL(lmask mk, float yes, float no) { return __builtin_amdgcn_inverse_ballot_w64(mk) ? yes : no; }
+  template <int K> static DEV void fmac_rowb(float &acc, float x, float y) {  // acc += (lane K of the lane's 16-lane row of x) * y
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x), "v"(y), "n"(K));
+  }
+  template <int K> static DEV float max_rowb(float x, float y) {  // max(lane K of the lane's 16-lane row of x, y) - one instruction (fmaxf adds a canonicalising v_max)
+    float o;
+    asm("v_max_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(o) : "v"(x), "v"(y), "n"(K));
+    return o;
+  }
+  struct LSH { float alpha, hd, h; };
+  DEV float linesearch_v2(bool alive) {
+    const int nv = m.nv();
+    const float mv = mul_M_row(D_SEARCH);
+    aJv = row_dot_A(D_SEARCH);
+    cJv = row_dot_B(D_SEARCH);
+    const bool validA = gl < nA(), validB = gl < nB();
+    // (q1 / 2, q2) of the lane's two row slots, zero for a slot without a row; the lane's share of the Gauss terms
+    const float tA = validA ? aJv * aD : 0.0f, tB = validB ? cJv * cD : 0.0f;
+    const f2v pA = {0.5f * tA * aJaref, 0.5f * tA * aJv}, pB = {0.5f * tB * cJaref, 0.5f * tB * cJv};
+    f2v gsh;
+    float sn_;
+    {
+      const int li = gl < nv ? gl : 0;
+      const float si = dof(D_SEARCH, li);
+      const float g1h = 0.5f * (si * r_ma - si * r_fs), g2_ = 0.5f * si * mv;
+      gsh = f2v{gl < nv ? g1h : 0.0f, gl < nv ? g2_ : 0.0f};
+      sn_ = gl < nv ? si * si : 0.0f;
+    }
+    // q0 of the lane's rows at alpha = 0 (the acceptance test's constant terms)
+    const float a0A = validA ? 0.5f * aD * aJaref * aJaref : 0.0f, a0B = validB ? 0.5f * cD * cJaref * cJaref : 0.0f;
+    auto terms = [&](float alpha) {  // the lane's (q1 / 2, q2) at alpha, Gauss share included
+      const float xA = __builtin_fmaf(alpha, aJv, aJaref), xB = __builtin_fmaf(alpha, cJv, cJaref);
+      const float mA = xA < 0.0f ? 1.0f : 0.0f, mB = xB < 0.0f ? 1.0f : 0.0f;
+      return pk_fma(pA, f2v{mA, mA}, pk_fma(pB, f2v{mB, mB}, gsh));
+    };
+    auto q0at = [&](float alpha) {
+      const float xA = __builtin_fmaf(alpha, aJv, aJaref), xB = __builtin_fmaf(alpha, cJv, cJaref);
+      return (xA < 0.0f ? a0A : 0.0f) + (xB < 0.0f ? a0B : 0.0f);
+    };
+    const float hmin = 0.5f * MINVAL;
+    // hmin with a (fake) data dependence on `dep`: the assembly DPP reads that take it are ordered behind the compiler-padded read that made `dep`
+    auto hmin_v = [&](float dep) { float o = hmin; asm("" : "+v"(o) : "v"(dep)); return o; };
+    const float q0_start = q0at(0.0f);
+    LSH p0;
+    float sn;
+    {
+      const f2v t = terms(0.0f);
+      const float u = gsum_pack4<G>(t.x, t.y, sn_, 0.0f);
+      sn = quad_value<3>(u);
+      const float hd0 = quad_value<0>(u);  // (compiler-visible DPP read of u first: it carries the wait states the assembly reads below rely on)
+      p0 = LSH{0.0f, hd0, max_rowb<4>(u, hmin_v(hd0))};
+    }
+    PROF(21);
+    const float hgtol = 0.5f * (m.tolerance() * m.ls_tolerance() * __builtin_amdgcn_sqrtf(sn) * m.scale());
+    LSH p1;
+    {
+      const float a1 = __builtin_fmaf(-p0.hd, __builtin_amdgcn_rcpf(p0.h), p0.alpha);
+      const f2v t = terms(a1);
+      const float r = gsum_pack2<G>(t.x, t.y);
+      float hd = quad_value<0>(r);
+      fmac_rowb<4>(hd, r, a1);
+      p1 = LSH{a1, hd, max_rowb<4>(r, hmin_v(hd))};
+    }
+    const lmask first = LT(p1.hd, p0.hd);
+    LSH lo = {SEL(first, p1.alpha, p0.alpha), SEL(first, p1.hd, p0.hd), SEL(first, p1.h, p0.h)};
+    LSH hi = {SEL(first, p0.alpha, p1.alpha), SEL(first, p0.hd, p1.hd), SEL(first, p0.h, p1.h)};
+    const lmask alivem = __builtin_amdgcn_ballot_w64(alive);
+    lmask swapm = ~0ull;
+    auto bracket_step = [&]() {
+      const lmask dm = ~swapm | (LT(lo.hd, 0.0f) & LT(-hgtol, lo.hd)) | (LT(0.0f, hi.hd) & LT(hi.hd, hgtol));
+      const lmask nd = ~dm;
+      if ((nd & alivem) == 0ull) return false;
+      const float a_lo = __builtin_fmaf(-lo.hd, __builtin_amdgcn_rcpf(lo.h), lo.alpha), a_hi = __builtin_fmaf(-hi.hd, __builtin_amdgcn_rcpf(hi.h), hi.alpha);
+      const float a_mid = 0.5f * (lo.alpha + hi.alpha);
+      const f2v t_lo = terms(a_lo), t_hi = terms(a_hi), t_mid = terms(a_mid);
+      float u, w;
+      gsum_pack6<G>(t_lo.x, t_lo.y, t_hi.x, t_hi.y, t_mid.x, t_mid.y, u, w);  // u: quads 0..3 = lo q1/2, lo q2, hi q2, hi q1/2; w: quads 0, 1 = mid q1/2, mid q2
+      float hd_lo = quad_value<0>(u), hd_hi = quad_value<3>(u), hd_mid = quad_value<0>(w);
+      fmac_rowb<4>(hd_lo, u, a_lo);
+      fmac_rowb<8>(hd_hi, u, a_hi);
+      fmac_rowb<4>(hd_mid, w, a_mid);
+      // (ordered behind the compiler-visible DPP reads of u and w through their results: the two wait states after the lane swaps)
+      const float h_lo = max_rowb<4>(u, hmin_v(hd_lo)), h_hi = max_rowb<8>(u, hmin_v(hd_hi)), h_mid = max_rowb<4>(w, hmin_v(hd_mid));
+      const lmask s_lo_next = nd & (LT(0.0f, lo.hd) | LT(lo.hd, hd_lo));
+      LSH nlo = {SEL(s_lo_next, a_lo, lo.alpha), SEL(s_lo_next, hd_lo, lo.hd), SEL(s_lo_next, h_lo, lo.h)};
+      const lmask s_lo_mid = nd & LT(hd_mid, 0.0f) & LT(nlo.hd, hd_mid);
+      nlo = LSH{SEL(s_lo_mid, a_mid, nlo.alpha), SEL(s_lo_mid, hd_mid, nlo.hd), SEL(s_lo_mid, h_mid, nlo.h)};
+      const lmask s_hi_next = nd & (LT(hi.hd, 0.0f) | LT(hd_hi, hi.hd));
+      LSH nhi = {SEL(s_hi_next, a_hi, hi.alpha), SEL(s_hi_next, hd_hi, hi.hd), SEL(s_hi_next, h_hi, hi.h)};
+      const lmask s_hi_mid = nd & LT(0.0f, hd_mid) & LT(hd_mid, nhi.hd);
+      nhi = LSH{SEL(s_hi_mid, a_mid, nhi.alpha), SEL(s_hi_mid, hd_mid, nhi.hd), SEL(s_hi_mid, h_mid, nhi.h)};
+      lo = nlo; hi = nhi;
+      swapm = s_lo_next | s_lo_mid | s_hi_next | s_hi_mid;
+      return true;
+    };
+#pragma unroll
+    for (int it = 0; it < S::ls_iterations; ++it) if (!bracket_step()) break;
+    PROF(22);
+    // costs of the two bracket ends relative to the starting point (see linesearch): 2 alpha (hd - alpha h / 2) is alpha d0 - alpha^2 d1 / 2
+    const float r = gsum_pack2<G>(q0at(lo.alpha) - q0_start, q0at(hi.alpha) - q0_start);
+    const float lo_delta = 2.0f * lo.alpha * (lo.hd - 0.5f * lo.alpha * lo.h) + quad_value<0>(r);
+    const float hi_delta = 2.0f * hi.alpha * (hi.hd - 0.5f * hi.alpha * hi.h) + quad_value<1>(r);
+    const bool improved = alive & ((lo_delta < 0.0f) | (hi_delta < 0.0f));
+    const float alpha = lo_delta < hi_delta ? lo.alpha : hi.alpha;
+    if (improved) {
+      if (gl < nv) { r_ma += alpha * mv; dof(D_QACC, gl) += alpha * dof(D_SEARCH, gl); dof(D_MA, gl) = r_ma; }
+      aJaref += alpha * aJv;
+      cJaref += alpha * cJv;
+    }
+    WSYNC();
+    return improved ? -fminf(lo_delta, hi_delta) : 0.0f;
+  }
+
   DEV void solve() {
     const int nv = m.nv();
     float gauss, cost;
@@ -3136,7 +3504,9 @@ struct Env {
       }
       if (!wave_any(alive)) break;
       PROF(12);
-      const float dec = linesearch(alive);
+      float dec;
+      if constexpr (ls_v2_ok()) dec = linesearch_v2(alive);
+      else dec = linesearch(alive);
       improvement = alive ? dec : improvement;
       PROF(13);
       float pg = 0;  // CG: keep grad.Mgrad of the previous iterate

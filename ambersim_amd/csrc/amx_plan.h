@@ -78,6 +78,10 @@ static bool plan_tree_H(const amx_model_desc *d, const DevModel &m, const Image 
 
 // Host-only part of amx_model_create: validates the descriptor and builds the constant image and the launch plan.
 // No HIP call in here (tools/gen_specs.py runs it without a GPU through amx_model_plan_describe).
+// column of the elimination's register row that register k of a pair's block stands for (mfma2; dof, nv = the gradient, -1 none): compile-time
+// data of a specialisation record (amx_model_plan_describe prints it), not part of the device model
+static thread_local std::vector<int> p2_col;
+
 static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
   if (!d) return fail(AMX_EINVAL, "null argument");
   if (d->version != AMX_VERSION) return fail(AMX_EINVAL, "amx_model_desc version %d, library %d", d->version, AMX_VERSION);
@@ -553,6 +557,92 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
       for (int j = i; j >= 0; j = d->dof_parentid[j]) Mlist.push_back((int)((unsigned)moff(i, j) | ((unsigned)moff(j, i) << 11) | ((unsigned)i << 22) | ((unsigned)j << 27)));
     m.nM = (int)Mlist.size(); m.c_M = add_ints(Mlist);
   }
+  // ---- two-pair models on the 4-block matrix instruction (amx_kernels.hip, newton_solve_pair2).  v_mfma_f32_16x16x1_4b has four
+  // 16 x 16 blocks: (environment, pair) for a 32-lane group whose contacts all belong to two pairs of four contacts with dof lists
+  // of at most 13 entries - a biped's two feet.  Lane 16 f + k of an environment feeds block (env, f): as B operand the Jacobian
+  // entry of the dof whose ROW of the block it will hold, as A operand the entry of the dof whose COLUMN register k stands for
+  // (k = 15 - ... see p2_col; one more A lane carries the row's residual, which makes the gradient).  Rows are placed so that
+  //   * pair 0's dofs below 16 and pair 1's dofs from 16 up sit in their own lanes (home: added in place),
+  //   * pair 0's dofs from 16 up / pair 1's dofs below 16 sit in the OTHER 16-lane row at (position + shift): one row exchange
+  //     (v_permlane16_swap) and a DPP row shift on the add bring them home;
+  // and so that every other lane the adds' bank masks enable holds an all-zero row.  No placement: mfma2 = 0 (32 x 32 path).
+  m.mfma2 = 0; m.p2_shl0 = m.p2_shl1 = 0; m.p2_banks = 0;
+  p2_col.assign(32, -1);
+  {
+    std::vector<int> pk(32, 0xFFFF);
+    const bool shape = m.G == 32 && m.fusedH && np == 2 && npc == 2 && nbl == 0 && ncon == 8 && nv <= 30 && d->solver == 2 && m.neq == 0 && m.nfri == 0;
+    bool ok = shape;
+    int dl[2] = {0, 0}, d0s[2] = {0, 0};
+    if (ok) for (int f = 0; f < 2 && ok; f++) {
+      const int o = m.c_pair + f * PAIR_S;
+      d0s[f] = im.geti(o + 9); dl[f] = im.geti(o + 10);
+      ok = dl[f] <= 13 && im.geti(o + 3) == 4 * f && im.geti(o + 4) == 4;  // contacts 4 f .. 4 f + 3
+    }
+    if (ok) {
+      // B placement: rowlane[f][pos] = slot of the pair's list whose row lane 16 f + pos holds, -1 none
+      int rowlane[2][16], shl[2] = {-1, -1};
+      for (int f = 0; f < 2; f++) for (int k = 0; k < 16; k++) rowlane[f][k] = -1;
+      for (int f = 0; f < 2 && ok; f++)
+        for (int t = 0; t < dl[f]; t++) {  // home rows
+          const int dof = pairdof[d0s[f] + t] & 255;
+          if ((dof >= 16) == (f == 1)) rowlane[f][dof & 15] = t;
+        }
+      auto banks_of = [&](int f, bool home, int sh) {  // bank mask of the destination lanes of pair f's home / cross adds
+        int b = 0;
+        for (int t = 0; t < dl[f]; t++) {
+          const int dof = pairdof[d0s[f] + t] & 255;
+          if (((dof >= 16) == (f == 1)) == home) b |= 1 << ((dof & 15) >> 2);
+        }
+        (void)sh;
+        return b;
+      };
+      for (int f = 0; f < 2 && ok; f++) {
+        // cross rows of pair f: dest position p = dof & 15 (in the other row), source position p + s in block f
+        for (int s_ = 0; s_ < 16 && shl[f] < 0; s_++) {
+          int trial[16];
+          for (int k = 0; k < 16; k++) trial[k] = rowlane[f][k];
+          bool fits = true;
+          for (int t = 0; t < dl[f] && fits; t++) {
+            const int dof = pairdof[d0s[f] + t] & 255;
+            if ((dof >= 16) == (f == 1)) continue;
+            const int src = (dof & 15) + s_;
+            if (src > 15 || trial[src] >= 0) fits = false; else trial[src] = t;
+          }
+          if (!fits) continue;
+          // junk check: every enabled destination lane (bank granularity) that is not a destination reads an unused or out-of-row lane
+          const int cb = banks_of(f, false, s_), hb = banks_of(f, true, 0);
+          for (int p = 0; p < 16 && fits; p++) {
+            if ((cb >> (p >> 2)) & 1) {
+              bool is_dest = false;
+              for (int t = 0; t < dl[f]; t++) { const int dof = pairdof[d0s[f] + t] & 255; if ((dof >= 16) != (f == 1) && (dof & 15) == p) is_dest = true; }
+              const int src = p + s_;
+              if (!is_dest && src <= 15 && trial[src] >= 0) fits = false;
+            }
+            if ((hb >> (p >> 2)) & 1) {  // home adds read the lane itself: it must hold its own dof's row or nothing
+              bool is_home = false;
+              for (int t = 0; t < dl[f]; t++) { const int dof = pairdof[d0s[f] + t] & 255; if ((dof >= 16) == (f == 1) && (dof & 15) == p) is_home = true; }
+              if (!is_home && trial[p] >= 0) fits = false;
+            }
+          }
+          if (fits) { shl[f] = s_; for (int k = 0; k < 16; k++) rowlane[f][k] = trial[k]; }
+        }
+        if (shl[f] < 0) ok = false;
+      }
+      if (ok) {
+        m.mfma2 = 1; m.p2_shl0 = shl[0]; m.p2_shl1 = shl[1];
+        m.p2_banks = banks_of(0, true, 0) | (banks_of(1, true, 0) << 4) | (banks_of(1, false, 0) << 8) | (banks_of(0, false, 0) << 12);
+        for (int f = 0; f < 2; f++)
+          for (int k = 0; k < 16; k++) {
+            // A operand / column register k of block f: slot k of the list, then the residual (the gradient column)
+            const int sa = k < dl[f] ? k : (k == dl[f] ? 0xFE : 0xFF);
+            p2_col[16 * f + k] = k < dl[f] ? (pairdof[d0s[f] + k] & 255) : (k == dl[f] ? nv : -1);
+            const int sb = rowlane[f][k] >= 0 ? rowlane[f][k] : 0xFF;
+            pk[16 * f + k] = sa | (sb << 8);
+          }
+      }
+    }
+    m.c_p2 = add_ints(pk);
+  }
   m.c_qpos0 = im.reserve(nq);
   for (int k = 0; k < nq; k++) im.setf(m.c_qpos0 + k, d->qpos0[k]);
   m.c_vert = im.reserve(3 * d->nconvexvert);
@@ -633,6 +723,9 @@ extern "C" int amx_model_plan_describe(const amx_model_desc *d, char *out, size_
   t += "\n";
   snprintf(line, sizeof(line), "tree_H=%d\n", plan_tree_H(d, m, im) ? 1 : 0);
   t += line;
+  t += "p2_col=";
+  for (int k = 0; k < 32; k++) { snprintf(line, sizeof(line), "%d%s", p2_col[k], k + 1 < 32 ? "," : ""); t += line; }
+  t += "\n";
   if (t.size() + 1 > cap) return fail(AMX_EINVAL, "amx_model_plan_describe: buffer of %zu bytes, %zu needed", cap, t.size() + 1);
   memcpy(out, t.c_str(), t.size() + 1);
   return AMX_OK;

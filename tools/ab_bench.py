@@ -10,7 +10,12 @@ from ambersim_amd.utils.io_utils import load_mj_model_from_file
 from bench import make_inputs
 dev = torch.device("cuda", 0)
 out = []
-for path, nenv, hor in (("models/quadruped/quadruped.xml", 4096, 1000), ("models/biped/biped.xml", 4096, 1000), ("models/biped/biped.xml", 1024, 64), ("models/quadruped/quadruped.xml", 32768, 200), ("models/biped/biped.xml", 32768, 100)):
+import os
+CASES = (("models/quadruped/quadruped.xml", 4096, 1000), ("models/biped/biped_stand.xml", 4096, 1000), ("models/biped/biped.xml", 4096, 1000), ("models/biped/biped.xml", 1024, 64),
+         ("models/quadruped/quadruped.xml", 32768, 200), ("models/biped/biped_stand.xml", 32768, 100))
+if os.environ.get("AB_CASES"):  # e.g. AB_CASES=biped_stand,biped: only those models (a library built with SPECS=... holds no others)
+    CASES = tuple(c for c in CASES if c[0].split("/")[-1][:-4] in os.environ["AB_CASES"].split(","))
+for path, nenv, hor in CASES:
     mj = load_mj_model_from_file(path); model = mjx.put_model(mj, dev)
     x0, us = make_inputs(mj, nenv, hor, 1, 2, dev)
     mjx.rollout(model, x0, us); torch.cuda.synchronize()
