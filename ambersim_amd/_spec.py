@@ -51,13 +51,20 @@ def _plan_library():
     return L
 
 
-def plan(mj) -> dict:
-    """The launch plan of a host model as {name: text}, from the planner built alone (csrc/libamx_plan.so: host C++, no HIP)."""
+def plan(mj, force_lanes: int = 0) -> dict:
+    """The launch plan of a host model as {name: text}, from the planner built alone (csrc/libamx_plan.so: host C++, no HIP).
+    force_lanes = 64: the model's WIDE plan (one environment per wavefront), which amx_model_create keeps beside the regular one
+    of a 32-lane model for batches too small to fill the SIMDs."""
     from ._desc import build_desc
     L = _plan_library()
     d = build_desc(mj)
     buf = C.create_string_buffer(1 << 16)
-    if L.amx_model_plan_describe(C.byref(d), buf, len(buf)) != 0:
+    L.amx_plan_force_lanes(int(force_lanes))
+    try:
+        rc = L.amx_model_plan_describe(C.byref(d), buf, len(buf))
+    finally:
+        L.amx_plan_force_lanes(0)
+    if rc != 0:
         raise RuntimeError(L.amx_plan_last_error().decode())
     return dict(line.split("=") for line in buf.value.decode().splitlines())
 
@@ -83,8 +90,9 @@ def render_header(models, banner: str) -> str:
     lines = [banner, "// One record per model: every integer of its launch plan (AMX_MODEL_INTS) and its dof tree, as compile-time constants.",
              "#pragma once", ""]
     names = []
-    for name, mj in models:
-        lines.append(render_record(name, plan(mj)))
+    for entry in models:  # (name, model) or (name, model, forced lane-group width)
+        name, mj = entry[0], entry[1]
+        lines.append(render_record(name, plan(mj, entry[2] if len(entry) > 2 else 0)))
         names.append(name)
     lines += ["", "#define AMX_SPECS(X) " + " ".join(f"X(Spec_{n})" for n in names)]
     return "\n".join(lines) + "\n"

@@ -48,6 +48,7 @@ struct DeviceGuard {
   if (!guard_.ok()) return fail(AMX_EHIP, "hipSetDevice(%d) failed", (int)(dev))
 
 struct amx_model {
+  amx_model *wide = nullptr;  // the same model planned on a 64-lane group (static kernels only), for batches of at most 4 * ncu environments
   DevModel dev;
   int spec;  // index into AMX_SPECS of the compile-time specialisation whose plan equals this model's, -1 = generic kernels
   int device, ncu;
@@ -109,12 +110,13 @@ static int find_spec(const DevModel &m, const amx_model_desc *d, const Image &im
   return found;
 }
 
-extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model **out) {
+static int model_create_impl(const amx_model_desc *d, int device, amx_model **out, bool wide_plan) {
   if (!d || !out) return fail(AMX_EINVAL, "null argument");
   DevModel m;
   Image im;
   if (int rc = plan_model(d, m, im)) return rc;
   const int spec = find_spec(m, d, im);
+  if (wide_plan && (spec < 0 || m.G != 64)) return AMX_EUNSUPPORTED;  // only kept when the library holds static kernels for it
   if (AMX_NO_GENERIC && spec < 0) return fail(AMX_EUNSUPPORTED, "this build of the library holds only the kernels of the model it was compiled for");
   const int lds_bytes = (m.nconst + m.wpb * (AMX_WAVE / m.G) * m.env_floats) * (int)sizeof(float);
   // The dynamic-LDS limit is an attribute of the KERNEL, shared by every model handle of the process (the generic kernels
@@ -143,8 +145,34 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
   return AMX_OK;
 }
 
+extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model **out) {
+  if (int rc = model_create_impl(d, device, out, false)) return rc;
+  // A 32-lane model with static kernels gets a second plan on a 64-lane group when the library holds static kernels for that too
+  // (tools/gen_specs.py: the *_w64 records): one environment per wavefront.  A two-environment wave-step takes about as long as a
+  // one-environment one (both are bound by their dependent chains), so a batch that cannot give every SIMD a wave at two
+  // environments per wave finishes sooner spread over twice as many waves (C4: 1024 rollouts = 512 waves on 1024 SIMDs).
+  // Used by amx_fd_grad; amx_rollout keeps one kernel for every batch size (results bit-identical across launch sizes) unless
+  // AMX_WIDE_SMALL_BATCH=1.
+  amx_model *h = *out;
+  if (h->dev.G == 32 && h->spec >= 0 && !getenv("AMX_NO_WIDE")) {
+    amx_plan_force_lanes(64);
+    amx_model *w = nullptr;
+    const int rc = model_create_impl(d, device, &w, true);
+    amx_plan_force_lanes(0);
+    if (rc == AMX_OK) h->wide = w;
+  }
+  return AMX_OK;
+}
+
+// the handle a batch of `nenv` environments runs on: the wide plan when there is one and every environment can have a wave of its own
+static const amx_model *pick_plan(const amx_model *m, int nenv) {
+  const int ncu = m->ncu > 0 ? m->ncu : 256;
+  return (m->wide && nenv <= 4 * ncu) ? m->wide : m;
+}
+
 extern "C" int amx_model_destroy(amx_model *m) {
   if (!m) return AMX_OK;
+  if (m->wide) { amx_model_destroy(m->wide); m->wide = nullptr; }
   {
     DeviceGuard guard(m->device);
     (void)hipFree(m->d_image);
@@ -195,6 +223,7 @@ extern "C" int amx_model_query(const amx_model *m, const char *name, int *out) {
   else if (n == "env_slab_bytes") *out = m->dev.env_floats * 4;
   else if (n == "const_bytes") *out = m->dev.nconst * 4;
   else if (n == "specialised") *out = m->spec >= 0 ? 1 : 0;
+  else if (n == "wide_plan") *out = m->wide ? 1 : 0;
   else if (n == "simd_pairing") { AMX_ON_DEVICE(m->device); *out = simd_pairing(m->device, m->ncu); }
   else return fail(AMX_EINVAL, "unknown query '%s'", name);
   return AMX_OK;
@@ -330,6 +359,10 @@ extern "C" int amx_rollout(const amx_model *m, int nenv, int nsteps, const float
                            float *xfinal, void *stream) {
   if (!m || !x0 || nenv < 0 || nsteps < 0 || (nsteps > 0 && m->dev.nu > 0 && !us)) return fail(AMX_EINVAL, "amx_rollout: bad argument");
   if (nenv == 0) return AMX_OK;
+  if (m->wide) {  // opt-in: small batches of a plain rollout on the wide plan too (gives up bit-identity between small and large launches)
+    static const bool wide_rollouts = [] { const char *e = getenv("AMX_WIDE_SMALL_BATCH"); return e && atoi(e) != 0; }();
+    if (wide_rollouts && pick_plan(m, nenv) != m) return amx_rollout(m->wide, nenv, nsteps, x0, x0_batched, us, xs, xfinal, stream);
+  }
   AMX_ON_DEVICE(m->device);
   dim3 grid;
   int wpb, lds_bytes;
@@ -419,7 +452,7 @@ extern "C" int amx_fd_grad(const amx_model *m, int nsamples, int nsteps, const f
     hipLaunchKernelGGL(amx_fd_perturb_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, nsamples, nsteps, nu, coord0, us_nominal, eps, us);
     HIP_TRY(hipGetLastError());
   }
-  if (int rc = amx_rollout(m, nsamples, nsteps, x0, /*x0_batched=*/0, us, /*xs=*/nullptr, xf, stream)) return rc;
+  if (int rc = amx_rollout(pick_plan(m, nsamples), nsamples, nsteps, x0, /*x0_batched=*/0, us, /*xs=*/nullptr, xf, stream)) return rc;
   hipLaunchKernelGGL(amx_fd_cost_kernel, dim3(nsamples), dim3(AMX_WAVE), 0, (hipStream_t)stream, nsamples, nsteps, nx, nu, coord0, xf, Qf, xg, eps, J, grad);
   HIP_TRY(hipGetLastError());
   if (xfinal) HIP_TRY(hipMemcpyAsync(xfinal, xf, (size_t)nsamples * nx * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));

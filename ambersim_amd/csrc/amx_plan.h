@@ -81,6 +81,10 @@ static bool plan_tree_H(const amx_model_desc *d, const DevModel &m, const Image 
 // column of the elimination's register row that register k of a pair's block stands for (mfma2; dof, nv = the gradient, -1 none): compile-time
 // data of a specialisation record (amx_model_plan_describe prints it), not part of the device model
 static thread_local std::vector<int> p2_col;
+// > 0: plan the model on a lane group at least this wide (amx_plan_force_lanes; amx_model_create plans a 32-lane model a second time
+// at 64 lanes - one environment per wavefront - for batches too small to fill the SIMDs with two-environment waves)
+static thread_local int plan_force_lanes = 0;
+extern "C" void amx_plan_force_lanes(int g) { plan_force_lanes = g; }
 
 static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
   if (!d) return fail(AMX_EINVAL, "null argument");
@@ -472,6 +476,7 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
     const int need = std::max({nb, nj, nv, np, m.ngc, con_off ? 0 : m.neq + m.nfri + m.nlim, con_off ? 0 : 4 * m.ncon, 1});
     m.G = need <= 16 ? 16 : (need <= 32 ? 32 : 64);
     if (const char *force = getenv("AMX_FORCE_G")) { int g = atoi(force); if ((g == 16 || g == 32 || g == 64) && g >= m.G) m.G = g; }
+    if (plan_force_lanes >= m.G && (plan_force_lanes == 32 || plan_force_lanes == 64)) m.G = plan_force_lanes;  // the wide plan of a model (amx_model_create)
   }
   // lists
   auto add_ints = [&](const std::vector<int> &v) { int o = im.reserve((int)v.size()); for (size_t k = 0; k < v.size(); k++) im.seti(o + (int)k, v[k]); return o; };

@@ -143,6 +143,33 @@ def test_c4_fd_gradient_vs_oracle(name, tolJ):
 
 
 @pytest.mark.gpu
+def test_c4_runs_on_the_wide_plan():
+    """A batch too small to give every SIMD a wave at two environments per wave (C4: 1024 rollouts = 512 waves on 1024 SIMDs) runs
+    on the model's WIDE plan: the same biped planned on a 64-lane group, one environment per wavefront, static kernels
+    (Spec_biped_w64; amx_model_create keeps it beside the regular plan, amx_fd_grad picks it for nsamples <= 4 x CUs).  The same
+    algorithm on another lane layout: final states agree with the regular kernels' rollout of the same controls to rounding
+    (1e-5 relative after 64 steps in flight), and the launch is deterministic."""
+    from ambersim_amd import mjx
+    from ambersim_amd.trajopt.fd import fd_grad_terminal_cost
+    mj, x0, us, Qf, xg, eps = c4_case("biped_flight")
+    dev = torch.device("cuda", 0)
+    model = mjx.put_model(mj, dev)
+    assert model._h.query("wide_plan") == 1 and model._h.query("lanes_per_env") == 32
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
+    S = 1024
+    r = fd_grad_terminal_cost(model, t(x0), t(us), t(Qf), t(xg), t(eps), nsamples=S)
+    r2 = fd_grad_terminal_cost(model, t(x0), t(us), t(Qf), t(xg), t(eps), nsamples=S)
+    assert torch.equal(r.xfinal, r2.xfinal) and torch.equal(r.grad, r2.grad)
+    usp = t(us).unsqueeze(0).repeat(S, 1, 1)
+    flat = usp.view(S, -1)
+    for k in range(1, S):
+        flat[k, k - 1] += t(eps)[(k - 1) % mj.nu]
+    xs = mjx.rollout(model, t(x0), usp)  # the regular (32-lane) kernels
+    err = (xs[:, -1] - r.xfinal).abs().max(dim=1).values / xs[:, -1].abs().max(dim=1).values.clamp(min=1.0)
+    assert float(err.max()) < 1e-5, float(err.max())
+    assert not torch.equal(xs[:, -1], r.xfinal)  # (it IS another kernel: if this ever holds bitwise the wide plan was not used)
+
+
 def test_c4_api_consistency():
     """amx_fd_grad is exactly perturb -> rollout -> terminal cost: its J equals amx_quadcost on trajectories of the
     explicitly perturbed controls bit for bit; coord0 windows tile the full gradient; bad shapes raise ValueError."""
