@@ -148,11 +148,9 @@ static int model_create_impl(const amx_model_desc *d, int device, amx_model **ou
 extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model **out) {
   if (int rc = model_create_impl(d, device, out, false)) return rc;
   // A 32-lane model with static kernels gets a second plan on a 64-lane group when the library holds static kernels for that too
-  // (tools/gen_specs.py: the *_w64 records): one environment per wavefront.  A two-environment wave-step takes about as long as a
-  // one-environment one (both are bound by their dependent chains), so a batch that cannot give every SIMD a wave at two
-  // environments per wave finishes sooner spread over twice as many waves (C4: 1024 rollouts = 512 waves on 1024 SIMDs).
-  // Used by amx_fd_grad; amx_rollout keeps one kernel for every batch size (results bit-identical across launch sizes) unless
-  // AMX_WIDE_SMALL_BATCH=1.
+  // (tools/gen_specs.py: the *_w64 records): one environment per wavefront, for batches that cannot give every SIMD a wave at two
+  // environments per wave (C4: 1024 rollouts = 512 waves on 1024 SIMDs).  Opt-in (AMX_WIDE_SMALL_BATCH=1, see pick_plan): it
+  // measured slower than the regular plan, and by default every batch size runs one kernel (results bit-identical across launch sizes).
   amx_model *h = *out;
   if (h->dev.G == 32 && h->spec >= 0 && !getenv("AMX_NO_WIDE")) {
     amx_plan_force_lanes(64);
@@ -164,10 +162,16 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
   return AMX_OK;
 }
 
-// the handle a batch of `nenv` environments runs on: the wide plan when there is one and every environment can have a wave of its own
+// the handle a batch of `nenv` environments runs on: the wide plan when the caller has asked for it (AMX_WIDE_SMALL_BATCH=1, read
+// per call), there is one, and every environment can have a wave of its own.  OFF by default - measured (profiles/r04_c4_fd_grad.txt):
+// C4 on the wide plan 36.5 M env-steps/s against 38.7 M on the regular one.  The premise did not hold: a one-environment 64-lane
+// wave-step is not shorter than a two-environment 32-lane one (it loses the two-pair matrix-core form and the gradient out of the
+// product, both tied to 32-lane groups), so twice as many waves of the same length gain nothing once every SIMD has one.
 static const amx_model *pick_plan(const amx_model *m, int nenv) {
   const int ncu = m->ncu > 0 ? m->ncu : 256;
-  return (m->wide && nenv <= 4 * ncu) ? m->wide : m;
+  if (!m->wide || nenv > 4 * ncu) return m;
+  const char *e = getenv("AMX_WIDE_SMALL_BATCH");
+  return (e && atoi(e) != 0) ? m->wide : m;
 }
 
 extern "C" int amx_model_destroy(amx_model *m) {
@@ -359,10 +363,7 @@ extern "C" int amx_rollout(const amx_model *m, int nenv, int nsteps, const float
                            float *xfinal, void *stream) {
   if (!m || !x0 || nenv < 0 || nsteps < 0 || (nsteps > 0 && m->dev.nu > 0 && !us)) return fail(AMX_EINVAL, "amx_rollout: bad argument");
   if (nenv == 0) return AMX_OK;
-  if (m->wide) {  // opt-in: small batches of a plain rollout on the wide plan too (gives up bit-identity between small and large launches)
-    static const bool wide_rollouts = [] { const char *e = getenv("AMX_WIDE_SMALL_BATCH"); return e && atoi(e) != 0; }();
-    if (wide_rollouts && pick_plan(m, nenv) != m) return amx_rollout(m->wide, nenv, nsteps, x0, x0_batched, us, xs, xfinal, stream);
-  }
+  if (m->wide && pick_plan(m, nenv) != m) return amx_rollout(m->wide, nenv, nsteps, x0, x0_batched, us, xs, xfinal, stream);
   AMX_ON_DEVICE(m->device);
   dim3 grid;
   int wpb, lds_bytes;

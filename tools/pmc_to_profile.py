@@ -4,16 +4,16 @@ means plus the derived figures bench.py and DESIGN.md quote.  python tools/pmc_t
 import os, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r04"
 G, waves, passes = 32, 2048, 1001  # 4096 envs x 1000 steps, two environments per wave
-model_arg = "" if tag == "biped" else f" --model models/{tag}/{tag}.xml"  # the biped is bench.py's default workload since r03
+model_arg = "" if tag == "biped_stand" else f" --model models/{tag.split('_')[0]}/{tag}.xml"  # biped_stand is bench.py's default workload since r04
 v = {}
 for line in open(os.path.join(root, "gpurun_out", f"pmc_{tag}_summary.csv")):
     p = line.strip().split(",")
     try: v[p[0]] = float(p[1])
     except (ValueError, IndexError): pass
 out = [f"# rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary{model_arg}; one pass per group (tools/pmc_collect.sh {tag})",
-       f"# per dispatch of amx_rollout_kernel<{G}, Spec_{tag}> ({tag}, 4096 envs x 1000 steps, {waves} waves x {passes} forward passes); FETCH_SIZE/WRITE_SIZE in KiB;",
+       f"# per dispatch of amx_rollout_kernel<{G}, Spec_{'biped' if tag.startswith('biped') else tag}> ({tag}, 4096 envs x 1000 steps, {waves} waves x {passes} forward passes); FETCH_SIZE/WRITE_SIZE in KiB;",
        "# SQ_ACTIVE_* / SQ_WAIT_* / SQ_WAVE_CYCLES count quad-cycles summed over waves; GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_INSTS_* are wave instructions",
        "# derived: valu_busy_frac = 4*SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE/8); lds_busy_frac = SQ_LDS_IDX_ACTIVE / (256 CUs * GRBM_GUI_ACTIVE/8);",
        f"#          executed_fp32_flops = 64 lanes * (2 FMA + ADD + MUL + TRANS) (idle lanes count as work); *_per_wave_step = SQ_INSTS_* / ({waves} * {passes})",

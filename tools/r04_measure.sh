@@ -18,3 +18,13 @@ phase) AMX_LIBRARY=ambersim_amd/csrc/libamx_prof.so timeout -k 10 300 python too
        grep "cycles per env-step" $OUT/phase_*.txt ;;
 esac
 done
+# extras: bash tools/r04_measure.sh extras
+for s in $STEPS; do
+case $s in
+extras) timeout -k 10 400 python tools/parity_horizons.py --out $OUT/parity_horizons.txt > $OUT/parity.log 2>&1; tail -14 $OUT/parity_horizons.txt
+        timeout -k 10 300 python tools/variants_check.py --out $OUT/biped_variants.txt > $OUT/variants.log 2>&1; cat $OUT/biped_variants.txt
+        timeout -k 10 200 python tools/c4_bench.py > $OUT/c4_fd_grad.txt 2>&1; AMX_NO_WIDE=1 timeout -k 10 200 python tools/c4_bench.py >> $OUT/c4_fd_grad.txt 2>&1; cat $OUT/c4_fd_grad.txt
+        timeout -k 10 300 python tools/ppo_breakdown.py > $OUT/ppo_breakdown.txt 2>&1; tail -14 $OUT/ppo_breakdown.txt
+        timeout -k 10 400 python examples/rl/pendulum/ex_swingup.py 8028160 > $OUT/ppo_pendulum_swingup.log 2>&1; tail -3 $OUT/ppo_pendulum_swingup.log ;;
+esac
+done
