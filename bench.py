@@ -521,11 +521,16 @@ def secondary(args, model, mj, model_path, x0_np, us_np, kern_ms, dev):
             x0q, usq = make_inputs(mjq, args.nenv, args.horizon, 1, 2, dev)
             k = 5
             el, kms, fin = timed_rollouts(mq, x0q, usq, k)
+            try:
+                act_q = activity_stats(mq, mjq, mjx.rollout(mq, x0q, usq), usq)
+            except Exception as e:
+                act_q = {"error": f"{type(e).__name__}: {e}"}
             x0qn, usqn = x0q.cpu().numpy(), usq.cpu().numpy()
             entry = {"name": "C2", "metric": "env-steps/sec, 4096 envs x 1000-step rollout", "value": args.nenv * args.horizon * k / el, "unit": "env-steps/s",
                      "steps": k, "ms_per_step": 1e3 * el / k,
                      "config": {"workload": f"quadruped.xml (build-authored, BASELINE.md C2: free base + 12 hinges, sphere feet), {args.nenv} envs x {args.horizon}-step fused rollout, "
-                                            f"random ctrl, Newton {mjq.opt.iterations} it / {mjq.opt.ls_iterations} ls", "nq": mjq.nq, "nv": mjq.nv, "nu": mjq.nu, "outputs_finite": fin},
+                                            f"random ctrl, Newton {mjq.opt.iterations} it / {mjq.opt.ls_iterations} ls; only the feet collide: under random servo targets the base ends below the floor "
+                                            "(activity)", "nq": mjq.nq, "nv": mjq.nv, "nu": mjq.nu, "outputs_finite": fin, "activity": act_q},
                      "roofline": roofline(mjq, args.nenv, args.horizon, kms, QUADRUPED),
                      "fp32_valu": fp32(mjq, x0qn, usqn, args.nenv * args.horizon / (kms * 1e-3), QUADRUPED)}
             if not args.no_cpu_baseline:

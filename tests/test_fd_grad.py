@@ -167,6 +167,7 @@ def test_wide_plan_is_opt_in_and_agrees(monkeypatch):
     assert float(err.max()) < 1e-5, float(err.max())
 
 
+@pytest.mark.gpu
 def test_c4_api_consistency():
     """amx_fd_grad is exactly perturb -> rollout -> terminal cost: its J equals amx_quadcost on trajectories of the
     explicitly perturbed controls bit for bit; coord0 windows tile the full gradient; bad shapes raise ValueError."""
