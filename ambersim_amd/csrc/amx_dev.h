@@ -25,7 +25,9 @@
 enum { BODY_E = 29, JNT_E = 7, DOF_E = 17, ROW_E = 3, CON_E = 5, GEO_E = 13 };
 enum { BODY_S = 25, JNT_S = 13, DOF_S = 13, ACT_S = 13, GEOM_S = 13, PAIR_S = 33, LIM_S = 15, EQ_S = 21, HULL_S = 7, FRI_S = 5 };
 // convex-convex scratch per environment (floats): world vertices of both hulls [2][32][3], two clip polygons [2][16][3]
-enum { CX_MAXV = 32, CX_MAXP = 16, CX_VA = 0, CX_VB = 96, CX_POLY = 192, CX_SCRATCH = 289 };
+// convex-convex limits and scratch: world vertices of both hulls [2][cx_maxv][3] (cx_maxv = the model's largest hull in such a pair), two clip
+// polygons [2][CX_MAXP][3], one spare word
+enum { CX_MAXV = 64, CX_MAXF = 128, CX_MAXE = 192, CX_MAXP = 16, CX_TAIL = 6 * CX_MAXP + 1 };
 // BodyRec: 0 parent 1 level 2 rootslot 3 jntadr 4 jntnum 5 childadr 6 childnum 7-9 pos 10-13 quat 14-16 ipos 17-20 iquat 21 mass 22-24 inertia
 // JntRec : 0 type 1 qadr 2 dadr 3 body 4-6 pos 7-9 axis 10 qpos0 11 stiffness 12 springref
 // DofRec : 0 body 1 jnt 2 kind(0 free-trans,1 free/ball-rot,2 hinge,3 slide) 3 axis 4 armature 5 damping 6 actadr 7 actnum 8 rootslot
@@ -54,7 +56,7 @@ enum { CX_MAXV = 32, CX_MAXP = 16, CX_VA = 0, CX_VB = 96, CX_POLY = 192, CX_SCRA
   X(fusedH) /* 1: Newton eliminates H in registers, no H buffer (G >= 32, no equality rows) */                            \
   X(mfma2) /* 1: the contacts belong to exactly two pairs (two feet): J'DJ runs chain-compressed on the 4-block 16x16 matrix instruction, one block per (environment, pair) - amx_kernels.hip, newton_solve_pair2 */ X(p2_shl0) X(p2_shl1) /* row shift that takes a pair's rows from their lanes in the other 16-lane row to their dofs' lanes */ X(p2_banks) /* four 4-bit DPP bank masks: home adds of pair 0 | of pair 1 << 4 | cross adds into pair 1's row-0 dofs << 8 | into pair 0's row-1 dofs << 12 */ \
   X(nchol) X(njac) X(nhent) X(subtree_contig) /* 1: every body's descendants are the bodies right after it (field 6 of the body record carries the end) */ X(sub_iter) /* largest subtree (bodies, itself included) below the tree roots */ X(deep_free) /* 1: a free joint below the first tree level (the chain-walking velocity pass assumes none) */ X(max_dofmem) /* most contacts any one dof takes part in */ X(max_jntnum) /* most joints on one body */ X(max_bgrp) /* most dof groups on one body (c_bgrp) */ X(jac_one_sided) /* 1: every contact Jacobian entry belongs to the chain of geom2's body alone (geom1 on a body without dofs: the ground) */                                                                                               \
-  X(cx_first) X(ncx) /* run of convex-convex pairs (fn 6), processed one after the other by the whole lane group */         \
+  X(cx_first) X(ncx) X(cx_maxv) /* run of convex-convex pairs (fn 6), processed one after the other by the whole lane group */         \
   X(pcx_first) X(npcx) /* run of plane - convex pairs (<= 32 hull vertices) handled one lane per vertex; npcx = 0: none */ X(pcx_unit) /* lanes per pair in that routine: 16 when every hull of the run has at most 16 vertices, else 32 */   \
   X(iterations) X(ls_iterations) X(solver) X(disableflags)                                                                 \
   X(G)   /* lanes per environment: 16, 32 or 64 */                                                                         \
@@ -77,7 +79,7 @@ enum { CX_MAXV = 32, CX_MAXP = 16, CX_VA = 0, CX_VB = 96, CX_POLY = 192, CX_SCRA
   X(e_J) /* contact rows only, chain-compressed: [4*ncon][ldc] */ X(e_vch) /* [npair][ldc]: the vector of the current J*v products gathered in the order of each pair's dof list (0 past its end) */                                                          \
   X(e_con) /* records [ncon][CON_E]: dist 0 pos 1-3 */ X(e_frame) /* [npair][9] */                                         \
   X(e_geom) /* records [ngc][GEO_E]: pos 0-2 mat 3-11 */                                                                   \
-  X(e_cx) /* convex-convex scratch [CX_SCRATCH], only when ncx > 0 */                                                                   \
+  X(e_cx) /* convex-convex scratch [6 cx_maxv + CX_TAIL], only when ncx > 0 */                                                                   \
   X(e_prof)                                                                                                                \
   X(env_floats) /* floats per environment slab */
 #define AMX_MODEL_FLOATS(X) X(dt) X(gx) X(gy) X(gz) X(tolerance) X(ls_tolerance) X(impratio) X(scale) /* scale = meaninertia*max(1,nv) */

@@ -1446,7 +1446,10 @@ AMX_STATIC_SOLVE_ATTR bool newton_solve_pair2(int M_off, unsigned long long crow
   float d = 1.0f;
   sym_eliminate<S, G, TREE, true>(a, gle, d);
   PROF_CTX(pc, 27);
-  if (owner) lds[x_off + gl * DOF_E] = fdiv(a[NS], AMX_PIVOT_CLAMP ? d : fmaxf(d, MINVAL));
+  // the direction and, in the adjacent field of the dof record, the search vector -direction: the caller's copy pass (a load, a
+  // store and a wave sync between the solve and the line search) is not needed
+  // (Env::D_SEARCH == Env::D_MGRAD + 1: asserted there)
+  if (owner) { const float xv = fdiv(a[NS], AMX_PIVOT_CLAMP ? d : fmaxf(d, MINVAL)); lds[x_off + gl * DOF_E] = xv; lds[x_off + gl * DOF_E + 1] = -xv; }
   WSYNC();
   return false;
 }
@@ -1642,10 +1645,10 @@ template <int G> DEV f3 gfetch3(f3 v, int lane_in_group, int gb4) {  // v of lan
 // reference / incident choice, over polygon edges for the clipping (ballot prefix counts compact the output in order) and
 // over polygon points for the manifold picks.  Scratch (world vertices, two clip polygons) lives in the slab (e_cx).
 template <int G>
-__device__ __noinline__ void convex_convex_pairs(int cx_first, int ncx, int c_pair, int geom_off, int con_off, int frame_off, int scr, int gl, int gb4) {
+__device__ __noinline__ void convex_convex_pairs(int cx_first, int ncx, int cx_maxv, int c_pair, int geom_off, int con_off, int frame_off, int scr, int gl, int gb4) {
 #define GEO(f, g) lds[geom_off + (g) * GEO_E + (f)]
 #define HV(base, i) mk3(lds[(base) + 3 * (i)], lds[(base) + 3 * (i) + 1], lds[(base) + 3 * (i) + 2])
-  const int VA = scr + CX_VA, VB = scr + CX_VB;
+  const int VA = scr, VB = scr + 3 * cx_maxv, POLY = scr + 6 * cx_maxv;
   for (int pp = 0; pp < ncx; ++pp) {
     const int pr = cx_first + pp, rec = c_pair + pr * PAIR_S;
     const int g1 = CI(rec), g2 = CI(rec + 1), c0 = CI(rec + 3), hA = CI(rec + 25), hB = CI(rec + 26);
@@ -1754,7 +1757,7 @@ __device__ __noinline__ void convex_convex_pairs(int cx_first, int ncx, int c_pa
       const int polyI = (refA ? pB : pA) + 9 * fi, polyR = (refA ? pA : pB) + 9 * rf, VI = refA ? VB : VA, VR = refA ? VA : VB;
       int np_ = CI(polyI);
       const int nr_ = CI(polyR);
-      int cur = scr + CX_POLY, oth = scr + CX_POLY + 3 * CX_MAXP;
+      int cur = POLY, oth = POLY + 3 * CX_MAXP;
       if (gl < np_) { const f3 w = HV(VI, CI(polyI + 1 + gl)); lds[cur + 3 * gl] = w.x; lds[cur + 3 * gl + 1] = w.y; lds[cur + 3 * gl + 2] = w.z; }
       WSYNC();
       for (int k = 0; k < 8; ++k) {  // Sutherland-Hodgman against the side plane through reference edge k (lane = polygon edge)
@@ -1968,6 +1971,7 @@ struct Env {
   // crb*cdof (6) is dead once M is built; the six solver vectors reuse its space
   enum { D_CDOF = 0, D_FCRB = 6, D_MA = 6, D_GRAD = 7, D_MGRAD = 8, D_SEARCH = 9, D_MV = 10, D_FCON = 11,
          D_FSMOOTH = 12, D_ASMOOTH = 13, D_QACC = 14, D_WARM = 15, D_FBIAS = 16 };
+  static_assert(D_SEARCH == D_MGRAD + 1, "newton_solve_pair2 writes the search vector into the field behind Mgrad");
   DEV int dofoff(int f) const { return ebD + f; }  // element i of dof field f lives at dofoff(f) + i*DOF_E
 
   // ------------------------------------------------------------------ A9.1 kinematics
@@ -2510,7 +2514,7 @@ struct Env {
       else plane_convex_parallel<G, 32>(cx_first, cx_num, m.c_pair(), m.c_vert(), eb + m.e_geom(), eb + m.e_con(), eb + m.e_frame(), gl, gb4);
     }
     if (m.ncx() > 0 && contacts_on)  // uniform: a property of the model
-      convex_convex_pairs<G>(m.cx_first(), m.ncx(), m.c_pair(), eb + m.e_geom(), eb + m.e_con(), eb + m.e_frame(), eb + m.e_cx(), gl, gb4);
+      convex_convex_pairs<G>(m.cx_first(), m.ncx(), m.cx_maxv(), m.c_pair(), eb + m.e_geom(), eb + m.e_con(), eb + m.e_frame(), eb + m.e_cx(), gl, gb4);
     if (m.nbl() > 0 && gl >= np - m.nbl() && gl < np) {
       // A ball joint's limit (MJX constraint._instantiate_limit_ball; oracle: make_constraint): the joint
       // quaternion (normalised by kinematics) as axis * angle, the angle wrapped to (-pi, pi] and made positive by turning the
@@ -2660,6 +2664,79 @@ struct Env {
         const float d = (below ? -dn : dn) - r;
         const f3 posl = (pt + c + nl * r) * 0.5f;
         st_contact(c0, d, pos2 + mulv(R2, posl));
+        make_frame(mulv(R2, nl), fr);
+      } else if (fn == 11) {
+        // capsule - convex hull (oracle: capsule_convex; r04): in the hull's frame, the face of largest support of the capsule's
+        // axis; the axis clipped to that face's side planes -> two contacts, or - an axis that misses the polygon - the closest
+        // polygon edge -> one contact, the second slot inactive
+        const int hB = CI(rec + 26), nfB = CI(hB + 2), vB = CI(hB + 1), nB_ = CI(hB + 3), pB = CI(hB + 4);
+#define HV(base, i) mk3(CF((base) + 3 * (i)), CF((base) + 3 * (i) + 1), CF((base) + 3 * (i) + 2))
+        const float r = CF(s1), half = CF(s1 + 1);
+        const f3 c = mulTv(R2, pos1 - pos2), ax = mulTv(R2, mk3(R1.a[2], R1.a[5], R1.a[8]));
+        const f3 a = c + ax * half, b = c - ax * half;
+        int bf = 0;
+        float bs = -1e30f;
+        for (int f = 0; f < nfB; ++f) {
+          const f3 n = HV(nB_, f), v0 = HV(vB, CI(pB + 9 * f + 1));
+          const float sup = fminf(dot(a - v0, n), dot(b - v0, n)) - r;
+          if (sup > bs) { bs = sup; bf = f; }
+        }
+        const f3 n = HV(nB_, bf);
+        const int poly = pB + 9 * bf, nvf = CI(poly);
+        const f3 v0 = HV(vB, CI(poly + 1));
+        float t0 = 0.0f, t1 = 1.0f;
+        bool empty = false;
+        for (int k = 0; k < nvf; ++k) {
+          const f3 p0 = HV(vB, CI(poly + 1 + (k == 0 ? nvf - 1 : k - 1))), p1 = HV(vB, CI(poly + 1 + k));
+          const f3 en = cross(p1 - p0, n);
+          const float da = dot(a - p0, en), db = dot(b - p0, en);
+          if (da > 0 && db > 0) { empty = true; continue; }
+          if (da > 0) t0 = fmaxf(t0, da / (da - db));
+          else if (db > 0) t1 = fminf(t1, da / (da - db));
+        }
+        if (t0 > t1) empty = true;
+        f3 nl, pl0, pl1;
+        float dist0, dist1;
+        if (!empty) {
+          const f3 q0 = a + (b - a) * t0, q1 = a + (b - a) * t1;
+          dist0 = dot(q0 - v0, n) - r; dist1 = dot(q1 - v0, n) - r;
+          pl0 = q0 - n * (r + 0.5f * dist0); pl1 = q1 - n * (r + 0.5f * dist1);
+          nl = n * -1.0f;
+        } else {
+          float best = 1e30f;
+          f3 pa = c, pe = v0;
+          for (int k = 0; k < nvf; ++k) {
+            const f3 p0 = HV(vB, CI(poly + 1 + (k == 0 ? nvf - 1 : k - 1))), p1 = HV(vB, CI(poly + 1 + k));
+            // closest points of the segments [a, b] and [p0, p1] (clamped; the oracle's seg_seg_closest)
+            const f3 d1 = b - a, d2 = p1 - p0, rr = a - p0;
+            const float aa = dot(d1, d1), ee = dot(d2, d2), ff = dot(d2, rr);
+            float sg, tg;
+            if (aa <= MINVAL && ee <= MINVAL) { sg = 0; tg = 0; }
+            else if (aa <= MINVAL) { sg = 0; tg = fminf(fmaxf(ff / ee, 0.0f), 1.0f); }
+            else {
+              const float cc = dot(d1, rr);
+              if (ee <= MINVAL) { tg = 0; sg = fminf(fmaxf(-cc / aa, 0.0f), 1.0f); }
+              else {
+                const float bb = dot(d1, d2), denom = aa * ee - bb * bb;
+                sg = denom > MINVAL ? fminf(fmaxf((bb * ff - cc * ee) / denom, 0.0f), 1.0f) : 0.0f;
+                tg = (bb * sg + ff) / ee;
+                if (tg < 0) { tg = 0; sg = fminf(fmaxf(-cc / aa, 0.0f), 1.0f); }
+                else if (tg > 1) { tg = 1; sg = fminf(fmaxf((bb - cc) / aa, 0.0f), 1.0f); }
+              }
+            }
+            const f3 c1 = a + d1 * sg, c2 = p0 + d2 * tg, dd = c2 - c1;
+            const float d2n = dot(dd, dd);
+            if (d2n < best) { best = d2n; pa = c1; pe = c2; }
+          }
+          float dn;
+          nl = normalize3(pe - pa, &dn);
+          if (dn == 0) nl = n * -1.0f;
+          dist0 = dn - r; dist1 = 1.0f;
+          pl0 = (pa + nl * r + pe) * 0.5f; pl1 = pl0;
+        }
+#undef HV
+        st_contact(c0, dist0, pos2 + mulv(R2, pl0));
+        st_contact(c0 + 1, dist1, pos2 + mulv(R2, pl1));
         make_frame(mulv(R2, nl), fr);
       } else {
         f3 p1 = pos1, p2 = pos2;
@@ -2989,6 +3066,8 @@ struct Env {
   // grad_in_solve(): the specialised fused Newton path takes J'f of the contact rows from the matrix cores (newton_solve_fused
   // GRADCOL), so a call that is followed by newton_direction() only publishes the row records and the limit-row force
   static constexpr bool grad_in_solve() { return S::is_static && G == 32 && S::fusedH && S::solver == 2 && S::nv <= 31 && sym_elim_ok<S, G>() && !AMX_NO_GRADCOL; }
+  // the two-pair Newton solve (newton_solve_pair2) also writes the search vector
+  static constexpr bool search_from_solve() { return grad_in_solve() && S::mfma2 && AMX_MFMA_PAIR2; }
   float pend_flim;  // limit-row force on this lane's dof, handed from a deferring constraint_force_and_grad to newton_direction
   // x of the single-entry rows on this lane's dof, summed: its limit row and (models with friction loss) its friction-loss row, each
   // fetched from the row's lane through the crossbar; 0 on lanes without a dof or without such rows
@@ -3485,8 +3564,10 @@ struct Env {
     PROF(10);
     if (m.solver() == 2) newton_direction();
     else chol_solve<G>(m.nchol(), eb + m.e_M(), m.ldm(), nv, eb + m.e_Lb(), dofoff(D_GRAD), dofoff(D_MGRAD), false, gl, gb4);
-    if (gl < nv) dof(D_SEARCH, gl) = -dof(D_MGRAD, gl);
-    WSYNC();
+    if constexpr (!search_from_solve()) {
+      if (gl < nv) dof(D_SEARCH, gl) = -dof(D_MGRAD, gl);
+      WSYNC();
+    }
     PROF(11);
     bool alive = true;  // per group: still iterating
     bool stop = false;  // wave-uniform: the stopping test evaluated inside newton_direction ended the solve
@@ -3530,7 +3611,7 @@ struct Env {
           stop = newton_direction(alive, m.iterations() != 1, imp_done, &next_done);
           have_next = m.iterations() != 1;
           PROF(11);
-          if (gl < nv) dof(D_SEARCH, gl) = -dof(D_MGRAD, gl);
+          if constexpr (!search_from_solve()) { if (gl < nv) dof(D_SEARCH, gl) = -dof(D_MGRAD, gl); }
         }
       } else {
         chol_solve<G>(m.nchol(), eb + m.e_M(), m.ldm(), nv, eb + m.e_Lb(), dofoff(D_GRAD), dofoff(D_MGRAD), false, gl, gb4);

@@ -35,7 +35,7 @@ struct Image {
   int geti(int off) const { int x; memcpy(&x, &v[off], 4); return x; }
   void setf(int off, double x) { v[off] = (float)x; }
 };
-const int PAIR_NCON[11] = {1, 2, 4, 1, 1, 1, 4, 1, 1, 1, 1};  // 8, 9: one row group each (connect / weld-translation, weld-rotation); 10: a ball joint's limit row
+const int PAIR_NCON[12] = {1, 2, 4, 1, 1, 1, 4, 1, 1, 1, 1, 2};  // 8, 9: one row group each (connect / weld-translation, weld-rotation); 10: a ball joint's limit row; 11: capsule - convex
 
 // {k, b, dmin, dmax, width, mid, power, ca, cb}: the position-independent part of MuJoCo's solref/solimp
 // mapping (reference physics: constraint._kbi), evaluated once on the host in double precision.
@@ -266,9 +266,9 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
   for (int h = 0; h < d->nhull; h++) {
     const int nvh = d->hull_vertnum[h], nfh = d->hull_facenum[h], neh = d->hull_edgenum[h];
     const int va = d->hull_vertadr[h], fa = d->hull_faceadr[h], ea = d->hull_edgeadr[h];
-    if (nvh < 1 || nvh > CX_MAXV || nfh < 1 || nfh > 32 || neh < 0 || neh > 64 || va < 0 || va + nvh > d->nhullvert || fa < 0 || fa + nfh > d->nhullface ||
+    if (nvh < 1 || nvh > CX_MAXV || nfh < 1 || nfh > CX_MAXF || neh < 0 || neh > CX_MAXE || va < 0 || va + nvh > d->nhullvert || fa < 0 || fa + nfh > d->nhullface ||
         ea < 0 || ea + neh > d->nhulledge)
-      return fail(AMX_ECAPACITY, "hull %d: %d vertices, %d faces, %d edges (limits 32 / 32 / 64)", h, nvh, nfh, neh);
+      return fail(AMX_ECAPACITY, "hull %d: %d vertices, %d faces, %d edges (limits %d / %d / %d)", h, nvh, nfh, neh, (int)CX_MAXV, (int)CX_MAXF, (int)CX_MAXE);
     const int o = im.reserve(HULL_S);
     hull_rec[h] = o;
     im.seti(o, nvh); im.seti(o + 2, nfh); im.seti(o + 5, neh);
@@ -338,8 +338,8 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
       for (int k = 0; k < 4; k++) im.setf(o + 29 + k, weld ? dat[6 + k] : (k == 0 ? 1.0 : 0.0));
     } else {
     g1 = d->pair_geom1[p]; g2 = d->pair_geom2[p]; fn = d->pair_fn[p];
-    if (fn < 0 || fn > 7) return fail(AMX_EUNSUPPORTED, "pair %d: unknown collision function %d", p, fn);
-    if (fn == 7 && (d->pair_hull2[p] < 0 || d->pair_hull2[p] >= d->nhull)) return fail(AMX_EINVAL, "pair %d: sphere-convex pair without a hull", p);
+    if (fn < 0 || (fn > 7 && fn != 11)) return fail(AMX_EUNSUPPORTED, "pair %d: unknown collision function %d", p, fn);
+    if ((fn == 7 || fn == 11) && (d->pair_hull2[p] < 0 || d->pair_hull2[p] >= d->nhull)) return fail(AMX_EINVAL, "pair %d: sphere / capsule - convex pair without a hull", p);
     if (fn == 6 && (d->pair_hull1[p] < 0 || d->pair_hull1[p] >= d->nhull || d->pair_hull2[p] < 0 || d->pair_hull2[p] >= d->nhull))
       return fail(AMX_EINVAL, "pair %d: convex-convex pair without hulls", p);
     if (fn == 2 && (d->pair_vertnum[p] < 1 || d->pair_vertadr[p] < 0 || d->pair_vertadr[p] + d->pair_vertnum[p] > d->nconvexvert))
@@ -349,7 +349,7 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
     im.seti(o + 5, fn == 2 ? d->pair_vertadr[p] : 0); im.seti(o + 6, fn == 2 ? d->pair_vertnum[p] : 0);
     im.seti(o + 7, root_slot[b1]); im.seti(o + 8, root_slot[b2]);
     if (fn == 6) { im.seti(o + 25, hull_rec[d->pair_hull1[p]]); im.seti(o + 26, hull_rec[d->pair_hull2[p]]); }
-    if (fn == 7) im.seti(o + 26, hull_rec[d->pair_hull2[p]]);
+    if (fn == 7 || fn == 11) im.seti(o + 26, hull_rec[d->pair_hull2[p]]);
     im.setf(o + 11, d->pair_friction[3 * p]);
     write_kbi(im, o + 12, d->pair_solref + 2 * p, d->pair_solimp + 5 * p, d->timestep, refsafe);
     im.setf(o + 21, d->pair_margin[p]);
@@ -400,6 +400,11 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
     for (int p = 0; p < npc; p++) if (d->pair_fn[p] == 6) { if (first < 0) first = p; last = p; cnt++; }
     if (cnt > 0 && last - first + 1 != cnt) return fail(AMX_EINVAL, "convex-convex pairs must be contiguous in the pair list (pairs are sorted by function)");
     if (cnt > 0) { m.cx_first = first; m.ncx = cnt; }
+    m.cx_maxv = 0;
+    for (int p = 0; p < npc; p++)
+      if (d->pair_fn[p] == 6)
+        for (int h : {d->pair_hull1[p], d->pair_hull2[p]})
+          if (h >= 0 && h < d->nhull && d->hull_vertnum[h] > m.cx_maxv) m.cx_maxv = d->hull_vertnum[h];
   }
   // plane - convex pairs with at most 32 hull vertices go to the vertex-parallel routine when they form one contiguous run of
   // pair indices (pairs come grouped by function, so they do unless a larger hull sits among them)
@@ -672,7 +677,7 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
   m.e_com = take(3 * m.nroot); m.e_actf = take(nu);
   m.e_con = take(CON_E * m.ncon); m.e_frame = take(9 * np);
   m.e_geom = take(GEO_E * m.ngc);
-  m.e_cx = m.ncx > 0 ? take(CX_SCRATCH) : 0;
+  m.e_cx = m.ncx > 0 ? take(6 * m.cx_maxv + CX_TAIL) : 0;
   const int ntri = nv * (nv + 1) / 2;
   off = (off + 3) & ~3;
   m.e_M = take(nv * m.ldm);

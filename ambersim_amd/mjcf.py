@@ -1065,9 +1065,10 @@ PAIR_PLANE_SPHERE, PAIR_PLANE_CAPSULE, PAIR_PLANE_CONVEX = 0, 1, 2
 PAIR_SPHERE_SPHERE, PAIR_SPHERE_CAPSULE, PAIR_CAPSULE_CAPSULE = 3, 4, 5
 PAIR_CONVEX_CONVEX = 6  # box / mesh hull against box / mesh hull: SAT + face clipping
 PAIR_SPHERE_CONVEX = 7  # sphere against a box / mesh hull: closest point of the best-supported face
-PAIR_UNSUPPORTED = -1  # condim != 3, hulls beyond the size limits, capsule against a hull
-_PAIR_NCON = {0: 1, 1: 2, 2: 4, 3: 1, 4: 1, 5: 1, 6: 4, 7: 1, -1: 0}
-HULL_MAX_VERT, HULL_MAX_FACE, HULL_MAX_FACEVERT, HULL_MAX_EDGE = 32, 32, 8, 64
+PAIR_CAPSULE_CONVEX = 11  # capsule against a box / mesh hull (r04): the axis clipped to the best-supported face (two contacts), or the closest edge (8 - 10 are the planner's row groups)
+PAIR_UNSUPPORTED = -1  # condim != 3, hulls beyond the size limits
+_PAIR_NCON = {0: 1, 1: 2, 2: 4, 3: 1, 4: 1, 5: 1, 6: 4, 7: 1, 11: 2, -1: 0}
+HULL_MAX_VERT, HULL_MAX_FACE, HULL_MAX_FACEVERT, HULL_MAX_EDGE = 64, 128, 8, 192  # a triangulated 64-vertex hull has 124 faces and 186 edges
 _BOX_CORNERS = np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], dtype=float)
 
 
@@ -1183,6 +1184,8 @@ def _make_collision_pairs(m: MjModel):
                 fn = PAIR_CONVEX_CONVEX
             elif ta == GEOM_SPHERE and tb in convex and hull_id(b) >= 0:
                 fn = PAIR_SPHERE_CONVEX
+            elif ta == GEOM_CAPSULE and tb in convex and hull_id(b) >= 0:
+                fn = PAIR_CAPSULE_CONVEX
             else:
                 # the host model still loads (as MuJoCo's compiler would); putting it on the device raises
                 # NotImplementedError, like mjx.device_put does for unsupported collisions (reference io_utils.py:228-241)
@@ -1220,7 +1223,7 @@ def _make_collision_pairs(m: MjModel):
                         box_vert_adr[b] = nvert0 + 8 * len(extra)
                         extra.append(_BOX_CORNERS * m.geom_size[b])
                     vadr, vnum = box_vert_adr[b], 8
-            h1, h2 = (hull_id(a), hull_id(b)) if fn == PAIR_CONVEX_CONVEX else ((-1, hull_id(b)) if fn == PAIR_SPHERE_CONVEX else (-1, -1))
+            h1, h2 = (hull_id(a), hull_id(b)) if fn == PAIR_CONVEX_CONVEX else ((-1, hull_id(b)) if fn in (PAIR_SPHERE_CONVEX, PAIR_CAPSULE_CONVEX) else (-1, -1))
             pairs.append(dict(g1=a, g2=b, fn=fn, ncon=_PAIR_NCON[fn], friction=fri[:3].copy(), solref=np.array(solref),
                               solimp=np.array(solimp), includemargin=margin - gap, vadr=vadr, vnum=vnum, h1=h1, h2=h2))
     # contacts are grouped by pair function (as the reference physics groups them), stable in geom order

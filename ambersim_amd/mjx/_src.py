@@ -173,8 +173,8 @@ def put_model(mj: MjModel, device=None, specialise: Optional[bool] = None) -> Mo
         raise NotImplementedError("only the Euler integrator is implemented")
     if getattr(mj, "nunsupported_pairs", 0):
         raise NotImplementedError(
-            f"{mj.nunsupported_pairs} collision pairs are outside the implemented pair functions (condim != 3, a capsule "
-            "against a box or mesh, or a convex hull beyond 32 vertices / 32 faces / 64 edges); disable contact "
+            f"{mj.nunsupported_pairs} collision pairs are outside the implemented pair functions (condim != 3, a cylinder or "
+            "ellipsoid, or a convex hull beyond 32 vertices / 32 faces / 64 edges); disable contact "
             "(DisableBit.CONTACT), restrict contype/conaffinity or simplify the meshes")
     if specialise is None:
         # default (r04): "auto" - a model the library ships no kernels for gets a per-model build when hipcc is on this machine

@@ -66,7 +66,7 @@ typedef struct amx_model_desc {
   const double *geom_pos, *geom_quat, *geom_size /*[ngeom,3]*/;
   /* static collision pairs [npair] (contype/conaffinity/parent filters already applied) */
   const int *pair_geom1, *pair_geom2, *pair_fn /*0 plane-sphere 1 plane-capsule 2 plane-convex
-      3 sphere-sphere 4 sphere-capsule 5 capsule-capsule 6 convex-convex (box / mesh hulls) 7 sphere-convex*/, *pair_vertadr, *pair_vertnum;
+      3 sphere-sphere 4 sphere-capsule 5 capsule-capsule 6 convex-convex (box / mesh hulls) 7 sphere-convex 11 capsule-convex*/, *pair_vertadr, *pair_vertnum;
   const double *pair_friction /*[npair,3]*/, *pair_solref /*[npair,2]*/, *pair_solimp /*[npair,5]*/,
       *pair_margin /*[npair] margin-gap*/, *convex_vert /*[nconvexvert,3] geom-local hull vertices*/;
   /* convex hulls of the box / mesh geoms in convex-convex pairs (pair_fn 6): polygon faces (coplanar triangles merged,

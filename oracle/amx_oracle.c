@@ -115,7 +115,7 @@ static REAL *dup_r(const double *src, size_t n) {
   return p;
 }
 
-static const int PAIR_NCON[8] = {1, 2, 4, 1, 1, 1, 4, 1};
+static const int PAIR_NCON[12] = {1, 2, 4, 1, 1, 1, 4, 1, 1, 1, 1, 2}; /* 11: capsule - convex (8 - 10 are the planner's row groups, never in pair_fn) */
 
 amxo_model *amxo_model_create(const amx_model_desc *d) {
   amxo_model *m = (amxo_model *)calloc(1, sizeof(amxo_model));
@@ -540,7 +540,7 @@ static int argmax_r(const REAL *v, int n) { int k = 0; for (int i = 1; i < n; i+
  * edges; an edge pair is a candidate only if both edges are supporting edges along its axis).  Ties go to the lowest axis
  * index (faces of hull 1, faces of hull 2, edge pairs edge1-major).  Four contact
  * slots per pair; unused ones report dist = 1.  Contact normal points from geom1 to geom2. */
-#define CX_MAXV 32
+#define CX_MAXV 64
 #define CX_MAXP 16
 #ifdef __cplusplus
 #define AMXO_TLS thread_local
@@ -771,6 +771,102 @@ static void sphere_convex(const amxo_model *m, amxo_data *d, int p) {
   make_frame(d->con_frame + 9 * c0, nw);
 }
 
+/* closest points of the segments [p1, q1] and [p2, q2] (clamped; Ericson, Real-Time Collision Detection 5.1.9): s, t in [0, 1] */
+static void seg_seg_closest(const REAL *p1, const REAL *q1, const REAL *p2, const REAL *q2, REAL *c1, REAL *c2) {
+  REAL d1[3], d2[3], r[3];
+  for (int i = 0; i < 3; i++) { d1[i] = q1[i] - p1[i]; d2[i] = q2[i] - p2[i]; r[i] = p1[i] - p2[i]; }
+  REAL a = dot3(d1, d1), e = dot3(d2, d2), f = dot3(d2, r), s, t;
+  if (a <= MINVAL && e <= MINVAL) { s = 0; t = 0; }
+  else if (a <= MINVAL) { s = 0; t = r_clip(f / e, 0, 1); }
+  else {
+    REAL c = dot3(d1, r);
+    if (e <= MINVAL) { t = 0; s = r_clip(-c / a, 0, 1); }
+    else {
+      REAL b = dot3(d1, d2), denom = a * e - b * b;
+      s = denom > MINVAL ? r_clip((b * f - c * e) / denom, 0, 1) : 0;
+      t = (b * s + f) / e;
+      if (t < 0) { t = 0; s = r_clip(-c / a, 0, 1); }
+      else if (t > 1) { t = 1; s = r_clip((b - c) / a, 0, 1); }
+    }
+  }
+  for (int i = 0; i < 3; i++) { c1[i] = p1[i] + d1[i] * s; c2[i] = p2[i] + d2[i] * t; }
+}
+
+/* ------------------------------------------------------------------ A9.5 capsule - convex hull (pair function 11, r04)
+ * The published routine (mjx collision_convex.capsule_convex) is restated from its description, like sphere_convex: in the hull's
+ * frame, the face of largest support of the capsule's axis (the height of its LOWER end over the face plane, minus the radius);
+ * the axis clipped to that face's side planes gives two contacts (the clipped end points: depth = height - radius, normal = minus the
+ * face normal); an axis that misses the polygon altogether touches the hull at the polygon edge closest to it: one contact
+ * (closest points of the two segments), the second slot inactive.  Pinned by closed forms (tests/test_convex.py: flat on a box,
+ * overhanging, end-on, against an edge; a capsule at rest on a box carries its weight). */
+static void capsule_convex(const amxo_model *m, amxo_data *d, int p) {
+  int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p], c0 = m->pair_conadr[p];
+  const REAL *pos1 = d->geom_xpos + 3 * g1, *mat1 = d->geom_xmat + 9 * g1, *pos2 = d->geom_xpos + 3 * g2, *mat2 = d->geom_xmat + 9 * g2;
+  REAL r = m->geom_size[3 * g1], half = m->geom_size[3 * g1 + 1];
+  hull_view H;
+  hull_get(m, m->pair_hull2[p], &H);
+  REAL rel[3] = {pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2]}, axw[3] = {mat1[2], mat1[5], mat1[8]}, c[3], ax[3], a[3], b[3];
+  matT_mul_vec3(c, mat2, rel); matT_mul_vec3(ax, mat2, axw);
+  for (int i = 0; i < 3; i++) { a[i] = c[i] + ax[i] * half; b[i] = c[i] - ax[i] * half; }
+  int bf = 0; REAL bs = (REAL)-1e30;
+  for (int f = 0; f < H.nf; f++) {
+    const REAL *n = H.normal + 3 * f, *v0 = H.vert + 3 * H.fvert[H.fvadr[f]];
+    REAL qa[3] = {a[0] - v0[0], a[1] - v0[1], a[2] - v0[2]}, qb[3] = {b[0] - v0[0], b[1] - v0[1], b[2] - v0[2]};
+    REAL sup = r_min(dot3(qa, n), dot3(qb, n)) - r;
+    if (sup > bs) { bs = sup; bf = f; }
+  }
+  const REAL *n = H.normal + 3 * bf;
+  int nvf = H.fvnum[bf];
+  const int *fv = H.fvert + H.fvadr[bf];
+  const REAL *v0 = H.vert + 3 * fv[0];
+  REAL t0 = 0, t1 = 1; int empty = 0;
+  for (int k = 0; k < nvf; k++) { /* side plane of edge k (vertex k-1 -> k): outside where (x - p0) . (e x n) > 0 */
+    const REAL *p0 = H.vert + 3 * fv[(k + nvf - 1) % nvf], *p1 = H.vert + 3 * fv[k];
+    REAL e[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]}, en[3], wa[3] = {a[0] - p0[0], a[1] - p0[1], a[2] - p0[2]}, wb[3] = {b[0] - p0[0], b[1] - p0[1], b[2] - p0[2]};
+    cross3(en, e, n);
+    REAL da = dot3(wa, en), db = dot3(wb, en);
+    if (da > 0 && db > 0) { empty = 1; continue; }
+    if (da > 0) t0 = r_max(t0, da / (da - db));
+    else if (db > 0) t1 = r_min(t1, da / (da - db));
+  }
+  if (t0 > t1) empty = 1;
+  REAL nl[3], posl[2][3], dist[2];
+  if (!empty) {
+    REAL tt[2] = {t0, t1};
+    for (int k = 0; k < 2; k++) {
+      REAL pt[3], w[3];
+      for (int i = 0; i < 3; i++) { pt[i] = a[i] + (b[i] - a[i]) * tt[k]; w[i] = pt[i] - v0[i]; }
+      REAL h = dot3(w, n);
+      dist[k] = h - r;
+      for (int i = 0; i < 3; i++) posl[k][i] = pt[i] - n[i] * (r + (REAL)0.5 * dist[k]);
+    }
+    for (int i = 0; i < 3; i++) nl[i] = -n[i];
+  } else {
+    REAL best = (REAL)1e30, pa[3] = {c[0], c[1], c[2]}, pe[3] = {v0[0], v0[1], v0[2]};
+    for (int k = 0; k < nvf; k++) {
+      const REAL *p0 = H.vert + 3 * fv[(k + nvf - 1) % nvf], *p1 = H.vert + 3 * fv[k];
+      REAL c1[3], c2[3];
+      seg_seg_closest(a, b, p0, p1, c1, c2);
+      REAL dd[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]}, d2 = dot3(dd, dd);
+      if (d2 < best) { best = d2; memcpy(pa, c1, sizeof(pa)); memcpy(pe, c2, sizeof(pe)); }
+    }
+    for (int i = 0; i < 3; i++) nl[i] = pe[i] - pa[i];
+    REAL dn = normalize_n(nl, 3);
+    if (dn == 0) { nl[0] = -n[0]; nl[1] = -n[1]; nl[2] = -n[2]; }
+    dist[0] = dn - r; dist[1] = 1;
+    for (int i = 0; i < 3; i++) { posl[0][i] = (REAL)0.5 * (pa[i] + nl[i] * r + pe[i]); posl[1][i] = posl[0][i]; }
+  }
+  REAL nw[3];
+  mat_mul_vec3(nw, mat2, nl);
+  for (int k = 0; k < 2; k++) {
+    REAL pw[3];
+    mat_mul_vec3(pw, mat2, posl[k]);
+    d->con_dist[c0 + k] = dist[k];
+    for (int i = 0; i < 3; i++) d->con_pos[3 * (c0 + k) + i] = pw[i] + pos2[i];
+    make_frame(d->con_frame + 9 * (c0 + k), nw);
+  }
+}
+
 static void collision(const amxo_model *m, amxo_data *d) {
   for (int p = 0; p < m->npair; p++) {
     int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p], c0 = m->pair_conadr[p], fn = m->pair_fn[p];
@@ -780,6 +876,7 @@ static void collision(const amxo_model *m, amxo_data *d) {
     for (int k = 0; k < PAIR_NCON[fn]; k++) d->con_pair[c0 + k] = p;
     if (fn == 6) { convex_convex(m, d, p); continue; }
     if (fn == 7) { sphere_convex(m, d, p); continue; }
+    if (fn == 11) { capsule_convex(m, d, p); continue; }
     if (fn == 0) { /* plane-sphere */
       REAL n[3] = {mat1[2], mat1[5], mat1[8]};
       plane_sphere_core(n, pos1, pos2, size2[0], d->con_dist + c0, d->con_pos + 3 * c0);

@@ -442,3 +442,233 @@ def test_sphere_convex_gpu_vs_oracle():
         # (one env of the sphere-mesh draw sits at 1.8e-5 with the CPU restatement in fp32 at 4.5e-5: the loss is in the arithmetic
         # of the closest-feature computation, which neither the inputs' conditioning nor the precision of one side explains away)
         assert (e1_env < np.maximum(1e-5, np.maximum(10 * sens, e1_cpu32))).all() and e1 < 2e-5 and e5 < 2e-5, (name, e1, e5)
+
+
+CAPSULE_BOX = """
+<mujoco><compiler angle="degree"/><option timestep="0.002" iterations="{it}" ls_iterations="{it}" gravity="0 0 {g}"/><worldbody>
+  <body name="table" pos="0 0 0">{ja}<geom type="box" size="0.2 0.1 0.1" mass="5"/></body>
+  <body name="cap" pos="{pb}" euler="{eb}"><freejoint/><geom type="capsule" size="0.05 {half}" mass="0.5"/></body>
+</worldbody></mujoco>
+"""
+
+
+def test_capsule_convex_closed_forms():
+    """Capsule (r = 0.05) against a box (half sizes 0.2, 0.1, 0.1), pair function 11, two contact slots.  Lying over a face: the axis
+    clipped to the face polygon gives two contacts, each at height - r, midway between the surfaces; hanging over the rim the
+    contact points stop at the rim; standing on end the upper end's slot is far and inactive; beside an edge, parallel to it, one
+    contact at the axis-to-edge distance - r and the second slot switched off (dist = 1); normals point from the capsule to the box."""
+    def one(pb, eb, half=0.15):
+        mj = MjModel.from_xml_string(CAPSULE_BOX.format(pb=pb, eb=eb, half=half, ja="", g=0, it=10))
+        assert mj.pair_fn.tolist() == [11] and mj.ncon == 2 and mj.pair_hull2.tolist() == [0]
+        return contacts(mj)
+    d, p, f = one("0 0 0.14", "0 90 0")                 # axis along x, 0.04 above the top face
+    assert np.allclose(d, [-0.01, -0.01], atol=1e-12) and np.allclose(f[:, 0], [[0, 0, -1]] * 2)
+    assert np.allclose(p[np.argsort(p[:, 0])], [[-0.15, 0, 0.095], [0.15, 0, 0.095]], atol=1e-12)
+    d, p, f = one("0 0 0.14", "0 90 0", half=0.3)       # longer than the box: clipped at x = +-0.2
+    assert np.allclose(d, [-0.01, -0.01], atol=1e-12) and np.allclose(p[np.argsort(p[:, 0])], [[-0.2, 0, 0.095], [0.2, 0, 0.095]], atol=1e-12)
+    d, p, f = one("0.05 0.02 0.29", "0 0 0")            # standing on end: lower end 0.04 above the face, upper end 0.34 above
+    k = np.argsort(d)
+    assert np.allclose(d[k], [-0.01, 0.29], atol=1e-12) and np.allclose(p[k], [[0.05, 0.02, 0.095], [0.05, 0.02, 0.245]], atol=1e-12)
+    assert np.allclose(f[:, 0], [[0, 0, -1]] * 2)
+    d, p, f = one("0.23 0 0.13", "90 0 0")              # along y beside the top +x edge, axis 0.03 out and 0.03 up from it
+    s = np.sqrt(0.5)
+    assert np.isclose(d[0], 0.03 / s - 0.05, atol=1e-12) and d[1] == 1.0 and np.allclose(f[0, 0], [-s, 0, -s], atol=1e-12)
+    assert np.allclose(p[0, [0, 2]], [0.2 + (0.03 - 0.5 * (0.05 + 0.03 / s) * s), 0.1 + (0.03 - 0.5 * (0.05 + 0.03 / s) * s)], atol=1e-12)
+
+
+def test_capsule_resting_on_box():
+    """A capsule lying on a fixed box settles on its two contacts and the constraint force on its vertical translation is its weight."""
+    mj = MjModel.from_xml_string(CAPSULE_BOX.format(pb="0.02 0.01 0.151", eb="0 90 0", half=0.15, ja="", g=-9.81, it=50))
+    o = Oracle(mj)
+    xs = o.rollout(np.concatenate([mj.qpos0, np.zeros(6)]), np.zeros((1, 1000, 0)))[0]
+    assert np.abs(xs[-1, 7:]).max() < 1e-3 and 0.149 < xs[-1, 2] < 0.1505
+    o.set_state(xs[-1, :7], xs[-1, 7:], np.zeros(0)); o.forward()
+    assert (o.get("con_dist") < 0).all()
+    assert abs(o.get("qfrc_constraint")[2] - 0.5 * 9.81) < 0.01 * 0.5 * 9.81
+
+
+@pytest.mark.gpu
+def test_capsule_convex_gpu_vs_oracle():
+    """The HIP path on seeded random capsule-box and capsule-mesh poses (lying across faces, over rims, end-on, along edges,
+    separated): both contact distances within 1e-5 of the oracle's wherever the oracle's own fp32 run agrees on the manifold, one step
+    within 1e-5 per env (or the env's one-ulp input sensitivity / the fp32 oracle's error) and five within 2e-5 (relative to the state scale)."""
+    import ctypes as C
+    import torch
+    from ambersim_amd import _lib, mjx
+    dev = torch.device("cuda", 0)
+    octa = "0.3 0 0  -0.3 0 0  0 0.3 0  0 -0.3 0  0 0 0.35  0 0 -0.25"
+    for name, geom in (("capsule-box", 'type="box" size="0.2 0.1 0.1"'), ("capsule-mesh", 'type="mesh" mesh="o"')):
+        xml = CAPSULE_BOX.format(pb="0 0 0.5", eb="0 0 0", half=0.15, ja="<freejoint/>", g=-9.81, it=3).replace('type="box" size="0.2 0.1 0.1"', geom)
+        if "mesh" in geom:
+            xml = xml.replace("<worldbody>", f'<asset><mesh name="o" vertex="{octa}"/></asset><worldbody>')
+        mj = MjModel.from_xml_string(xml)
+        assert mj.pair_fn.tolist() == [11] and mj.ncon == 2, name
+        model = mjx.put_model(mj, dev)
+        rng = np.random.default_rng(41 if name == "capsule-box" else 42)
+        nenv = 96
+        q = np.tile(mj.qpos0, (nenv, 1))
+        for k in range(nenv):
+            quat = np.array([1.0, 0, 0, 0]) + 0.6 * rng.uniform(-1, 1, 4)
+            q[k, 3:7] = quat / np.linalg.norm(quat)
+            quat = rng.standard_normal(4)
+            q[k, 10:14] = quat / np.linalg.norm(quat)
+            u = rng.standard_normal(3)
+            q[k, 7:10] = u / np.linalg.norm(u) * (rng.uniform(0.1, 0.4) if name == "capsule-box" else rng.uniform(0.1, 0.5))
+        v = 0.3 * rng.standard_normal((nenv, mj.nv))
+        x0 = np.concatenate([q, v], axis=1).astype(np.float32)
+        tq, tv = torch.tensor(x0[:, :mj.nq], device=dev), torch.tensor(x0[:, mj.nq:], device=dev)
+        cd = torch.zeros((nenv, 2), device=dev)
+        out = _lib.AmxForwardOut(None, None, None, None, None, None, None, cd.data_ptr(), None)
+        _lib.check(_lib.lib().amx_forward(model._h.ptr, nenv, tq.data_ptr(), tv.data_ptr(), torch.zeros((nenv, 1), device=dev).data_ptr(), None, C.byref(out), None))
+        torch.cuda.synchronize()
+        o, o32 = Oracle(mj, np.float64), Oracle(mj, np.float32)
+        ref_d, ref_d32 = np.zeros((nenv, 2)), np.zeros((nenv, 2))
+        for k in range(nenv):
+            o.set_state(x0[k, :mj.nq], x0[k, mj.nq:], np.zeros(0)); o.forward()
+            o32.set_state(x0[k, :mj.nq], x0[k, mj.nq:], np.zeros(0)); o32.forward()
+            ref_d[k], ref_d32[k] = o.get("con_dist"), o32.get("con_dist")
+        two_c = ((ref_d < 0).sum(axis=1) == 2).sum()
+        assert (ref_d.min(axis=1) < 0).sum() >= 12 and (ref_d.min(axis=1) > 0).sum() >= 12 and two_c >= 3, (name, two_c)
+        # an env where fp32 arithmetic picks another face or flips face/edge is a tie of the fp64 answer, not a kernel error
+        same = np.abs(ref_d32 - ref_d).max(axis=1) < 1e-5
+        got = cd.cpu().numpy()
+        assert same.sum() >= nenv - 4 and np.abs(got - ref_d)[same].max() < 1e-5, (name, same.sum(), np.abs(got - ref_d)[same].max())
+        us = np.zeros((nenv, 5, 0), dtype=np.float32)
+        xs = mjx.rollout(model, torch.tensor(x0), torch.tensor(us)).cpu().numpy().astype(np.float64)
+        ref = Oracle(mj, np.float64).rollout(x0, us)
+        scale = lambda t: np.maximum(1.0, np.abs(ref[:, t]).max(axis=1))
+        e1_env = np.abs(xs[:, 1] - ref[:, 1]).max(axis=1) / scale(1)
+        e5_env = np.abs(xs[:, 5] - ref[:, 5]).max(axis=1) / scale(5)
+        sens = ulp_sensitivity(mj, x0, us[:, :1])
+        ref32 = Oracle(mj, np.float32).rollout(x0, us).astype(np.float64)
+        e1_cpu32 = np.abs(ref32[:, 1] - ref[:, 1]).max(axis=1) / scale(1)
+        e5_cpu32 = np.abs(ref32[:, 5] - ref[:, 5]).max(axis=1) / scale(5)
+        print(f"{name}: {(ref_d.min(axis=1) < 0).sum()} of {nenv} envs in contact ({two_c} on two contacts), {nenv - same.sum()} manifold ties, "
+              f"1-step err {e1_env[same].max():.2e}, 5-step err {e5_env[same].max():.2e}")
+        assert (e1_env < np.maximum(1e-5, np.maximum(10 * sens, 2 * e1_cpu32)))[same].all(), (name, e1_env.max())
+        assert (e5_env < np.maximum(2e-5, 2 * e5_cpu32))[same].all(), (name, e5_env.max())
+
+
+@pytest.mark.gpu
+def test_capsule_convex_kats_gpu():
+    """The closed forms of test_capsule_convex_closed_forms on the HIP path itself (fp32: 1e-6)."""
+    import ctypes as C
+    import torch
+    from ambersim_amd import _lib, mjx
+    dev = torch.device("cuda", 0)
+    s = np.sqrt(0.5)
+    cases = (("0 0 0.14", "0 90 0", 0.15, [-0.01, -0.01]), ("0 0 0.14", "0 90 0", 0.3, [-0.01, -0.01]),
+             ("0.05 0.02 0.29", "0 0 0", 0.15, [-0.01, 0.29]), ("0.23 0 0.13", "90 0 0", 0.15, [0.03 / s - 0.05, 1.0]))
+    for pb, eb, half, want in cases:
+        mj = MjModel.from_xml_string(CAPSULE_BOX.format(pb=pb, eb=eb, half=half, ja="", g=0, it=3))
+        model = mjx.put_model(mj, dev)
+        tq = torch.tensor(mj.qpos0[None].astype(np.float32), device=dev)
+        tv = torch.zeros((1, mj.nv), device=dev)
+        cd = torch.zeros((1, 2), device=dev)
+        out = _lib.AmxForwardOut(None, None, None, None, None, None, None, cd.data_ptr(), None)
+        _lib.check(_lib.lib().amx_forward(model._h.ptr, 1, tq.data_ptr(), tv.data_ptr(), torch.zeros((1, 1), device=dev).data_ptr(), None, C.byref(out), None))
+        torch.cuda.synchronize()
+        assert np.allclose(np.sort(cd[0].cpu().numpy()), np.sort(want), atol=1e-6), (pb, eb, cd)
+
+
+def _barrel_vertices():
+    """Eight octagonal rings on a circular-arc profile: 64 vertices, 58 faces (two octagons, 56 quads), 120 edges; bottom ring radius r0 at z = -0.14."""
+    zs = np.linspace(-0.14, 0.14, 8)
+    rs = np.sqrt(0.25 ** 2 - zs ** 2) - 0.05
+    v = [(r * np.cos(2 * np.pi * k / 8), r * np.sin(2 * np.pi * k / 8), z) for z, r in zip(zs, rs) for k in range(8)]
+    return " ".join(f"{x:.9g}" for p in v for x in p), float(rs[0])
+
+
+def _ball_vertices(n, seed, radius=0.2):
+    p = np.random.default_rng(seed).standard_normal((n, 3))
+    p = radius * p / np.linalg.norm(p, axis=1, keepdims=True)
+    return " ".join(f"{x:.9g}" for q in p for x in q)
+
+
+HULL64 = """
+<mujoco><option timestep="0.002" iterations="{it}" ls_iterations="{it}" gravity="0 0 {g}"/>
+<asset><mesh name="a" vertex="{va}" {mha}/><mesh name="b" vertex="{vb}"/></asset><worldbody>
+  <body name="lower" pos="0 0 0">{ja}<geom {ga} mass="5"/></body>
+  <body name="upper" pos="{pb}"><freejoint/><geom type="mesh" mesh="b" mass="0.5"/></body>
+</worldbody></mujoco>
+"""
+_SLAB = 'type="box" size="0.5 0.5 0.1"'
+
+
+def test_hull_64_vertices():
+    """Hull limits (r04): 64 vertices, 128 faces, 192 edges - a triangulated 64-vertex hull (124 faces, 186 edges) fits, 65
+    vertices do not unless the mesh caps its hull with `maxhullvert`.  Closed form: the barrel's bottom octagon 0.01 inside a
+    slab's top face gives four contacts of depth 0.01, midway between the faces, at corners of the octagon - the first two
+    opposite each other, the third at right angles to them (the 4-point manifold rule)."""
+    vb, r0 = _barrel_vertices()
+    mj = MjModel.from_xml_string(HULL64.format(it=10, g=0, va=vb, mha="", vb=vb, ja="", ga=_SLAB, pb="0.1 0.05 0.23"))
+    assert mj.pair_fn.tolist() == [6] and mj.hull_vertnum.tolist() == [8, 64] and mj.hull_facenum.tolist() == [6, 58] and mj.hull_edgenum.tolist() == [12, 120]
+    d, p, f = contacts(mj)
+    assert np.allclose(d, -0.01, atol=1e-12) and np.allclose(p[:, 2], 0.095, atol=1e-12) and np.allclose(f[:, 0], [[0, 0, 1]] * 4)
+    rel = p[:, :2] - [0.1, 0.05]
+    ang = np.degrees(np.arctan2(rel[:, 1], rel[:, 0]))
+    assert np.allclose(np.linalg.norm(rel, axis=1), r0, atol=1e-9) and np.allclose(ang / 45, np.round(ang / 45), atol=1e-6)
+    assert np.allclose(rel[0], -rel[1], atol=1e-9) and abs(rel[2] @ rel[0]) < 1e-9 and len({int(round(a / 45)) % 8 for a in ang}) == 4
+    full = MjModel.from_xml_string(HULL64.format(it=10, g=0, va=_ball_vertices(64, 3), mha="", vb=_ball_vertices(64, 4), ja="", ga='type="mesh" mesh="a"', pb="0 0 0.3"))
+    assert full.nunsupported_pairs == 0 and full.hull_vertnum.tolist() == [64, 64] and full.hull_facenum.tolist() == [124, 124] and full.hull_edgenum.tolist() == [186, 186]
+    over = MjModel.from_xml_string(HULL64.format(it=10, g=0, va=_ball_vertices(65, 3), mha="", vb=vb, ja="", ga='type="mesh" mesh="a"', pb="0 0 0.3"))
+    assert over.nunsupported_pairs == 1
+    capped = MjModel.from_xml_string(HULL64.format(it=10, g=0, va=_ball_vertices(200, 3), mha='maxhullvert="64"', vb=vb, ja="", ga='type="mesh" mesh="a"', pb="0 0 0.3"))
+    assert capped.nunsupported_pairs == 0 and capped.hull_vertnum.tolist() == [64, 64]
+    from ambersim_amd import _spec
+    pl = _spec.plan(full)
+    assert int(pl["ncx"]) == 1 and int(pl["cx_maxv"]) == 64
+
+
+@pytest.mark.gpu
+def test_hull_64_vertices_gpu():
+    """64-vertex hulls on the HIP path: the barrel-on-slab closed form of test_hull_64_vertices (depth from the contact distances,
+    the resultant along +z through the barrel's axis by symmetry of the four picked corners - no oracle in the loop), then seeded
+    random poses of a 64-vertex hull against a slab and against another 64-vertex hull (124 faces, 186 edges each: 34 596 edge
+    axes) against the oracle: one step within 1e-5 / two within 2e-5 of the fp64 or the fp32 oracle (or twice the fp32 oracle's own distance)."""
+    import torch
+    from ambersim_amd import mjx
+    dev = torch.device("cuda", 0)
+    vb, r0 = _barrel_vertices()
+    slick = '<default><geom friction="0.001"/></default><asset>'
+    mj = MjModel.from_xml_string(HULL64.format(it=10, g=-9.81, va=vb, mha="", vb=vb, ja="<freejoint/>", ga=_SLAB, pb="0.1 0.05 0.23").replace("<asset>", slick))
+    dist, fc = _gpu_forward(mj)
+    assert np.allclose(dist, -0.01, atol=2e-6)
+    F = np.linalg.norm(fc[6:9])
+    assert F > 1.0 and np.allclose(fc[6:9] / F, [0, 0, 1], atol=2e-3) and np.allclose(fc[0:3], -fc[6:9], atol=2e-4 * F)
+    for name, ga, va, nenv, zr in (("hull64-slab", _SLAB, vb, 32, (0.27, 0.33)), ("hull64-hull64", 'type="mesh" mesh="a"', _ball_vertices(64, 3), 16, (0.3, 0.44))):
+        mj = MjModel.from_xml_string(HULL64.format(it=3, g=-9.81, va=va, mha="", vb=_ball_vertices(64, 4), ja="<freejoint/>", ga=ga, pb="0 0 0.5"))
+        assert mj.pair_fn.tolist() == [6] and mj.hull_vertnum.max() == 64, name
+        model = mjx.put_model(mj, dev)
+        rng = np.random.default_rng(51 if "slab" in name else 52)
+        q = np.tile(mj.qpos0, (nenv, 1))
+        for k in range(nenv):
+            for a in (3, 10):
+                quat = np.array([1.0, 0, 0, 0]) + 0.5 * rng.uniform(-1, 1, 4)
+                q[k, a:a + 4] = quat / np.linalg.norm(quat)
+            u = rng.standard_normal(3)
+            q[k, 7:10] = u / np.linalg.norm(u) * rng.uniform(*zr) if "hull64-hull64" == name else [0.3 * rng.uniform(-1, 1), 0.3 * rng.uniform(-1, 1), rng.uniform(*zr)]
+        v = 0.3 * rng.standard_normal((nenv, mj.nv))
+        x0 = np.concatenate([q, v], axis=1).astype(np.float32)
+        us = np.zeros((nenv, 2, 0), dtype=np.float32)
+        xs = mjx.rollout(model, torch.tensor(x0), torch.tensor(us)).cpu().numpy().astype(np.float64)
+        ref = Oracle(mj, np.float64).rollout(x0, us)
+        ref32 = Oracle(mj, np.float32).rollout(x0, us).astype(np.float64)
+        o = Oracle(mj, np.float64)
+        nact = 0
+        for k in range(nenv):
+            o.set_state(x0[k, :mj.nq], x0[k, mj.nq:], np.zeros(0)); o.forward()
+            nact += int((o.get("con_dist") < 0).any())
+        assert nenv // 4 <= nact <= nenv - 2, (name, nact)
+        def err(t):
+            e64 = np.abs(xs[:, t] - ref[:, t]).max(axis=1) / np.maximum(1.0, np.abs(ref[:, t]).max(axis=1))
+            e32 = np.abs(xs[:, t] - ref32[:, t]).max(axis=1) / np.maximum(1.0, np.abs(ref32[:, t]).max(axis=1))
+            cpu = np.abs(ref32[:, t] - ref[:, t]).max(axis=1) / np.maximum(1.0, np.abs(ref[:, t]).max(axis=1))
+            return np.minimum(e64, e32), e64, cpu
+        (e1, e1_64, c1), (e2, _, c2) = err(1), err(2)
+        print(f"{name}: {nact} of {nenv} envs in contact; 1-step err {e1.max():.2e} ({(e1_64 < 1e-5).mean():.2f} of the envs within 1e-5 of the fp64 oracle, "
+              f"{(c1 < 1e-5).mean():.2f} of the fp32 oracle's), 2-step err {e2.max():.2e}")
+        # per env: 1e-5, or twice the distance of the oracle's own fp32 run (a flat triangle pressed on the slab is stiff, and the
+        # manifold's fourth pick on a triangle is a tie that fp32 and fp64 break differently)
+        assert (e1 < np.maximum(1e-5, 2 * c1)).all() and (e2 < np.maximum(2e-5, 2 * c2)).all(), (name, e1.max(), e2.max())
+        assert (e1_64 < 1e-5).mean() >= (c1 < 1e-5).mean() - 0.1, name
