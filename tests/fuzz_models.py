@@ -1,6 +1,8 @@
 """Random small MJCF models for the fuzz parity tests (seeded, deterministic): random kinematic trees with free / ball /
 hinge / slide joints, joint limits (ball joints included), damping, armature, springs, motors and position actuators, an optional joint
-equality, sphere / capsule geoms over a plane, random solver options.  Only features of the supported table are drawn."""
+equality, sphere / capsule geoms over a plane, random solver options.  Only features of the supported table are drawn.
+`convex=True` (r04) draws the geoms from spheres, capsules, boxes and small random mesh hulls instead, so that every convex pair
+function occurs: plane-convex, convex-convex, sphere-convex and capsule-convex."""
 import numpy as np
 
 from ambersim_amd.mjcf import MjModel
@@ -10,8 +12,10 @@ def _v(rng, lo, hi, n=3):
     return " ".join(f"{x:.4f}" for x in rng.uniform(lo, hi, n))
 
 
-def random_mjcf(seed: int) -> str:
+def random_mjcf(seed: int, convex: bool = False) -> str:
     rng = np.random.default_rng(seed)
+    rng_c = np.random.default_rng(seed + 200003)  # the convex family's geoms (a generator of its own: the plain family keeps its stream)
+    meshes = []
     rng_b = np.random.default_rng(seed + 100003)  # ball-joint limits (r03)
     nbody = int(rng.integers(2, 9))
     solver = rng.choice(["Newton", "CG"], p=[0.8, 0.2])
@@ -25,11 +29,15 @@ def random_mjcf(seed: int) -> str:
         parents[nbody - 1] = -1  # a second tree
     children = {i: [j for j in range(nbody) if parents[j] == i] for i in range(-1, nbody)}
     scalar_joints, ngeom_budget = [], int(rng.integers(0, 4))
+    if convex:
+        ngeom_budget = int(rng_c.integers(2, 5))
     jid = [0]
 
     def emit(b, ind):
         root = parents[b] == -1
         pos = _v(rng, -0.2, 0.2) if not root else f"{rng.uniform(-0.5, 0.5):.3f} {rng.uniform(-0.5, 0.5):.3f} {rng.uniform(0.4, 1.0):.3f}"
+        if convex and root:  # low over the floor: the geoms start in or near contact with it and with each other
+            pos = " ".join(pos.split()[:2]) + f" {rng_c.uniform(0.03, 0.25):.3f}"
         q = rng.standard_normal(4)
         q /= np.linalg.norm(q)
         out.append(f'{ind}<body name="b{b}" pos="{pos}" quat="{" ".join(f"{x:.5f}" for x in q)}">')
@@ -62,7 +70,23 @@ def random_mjcf(seed: int) -> str:
                 out.append(f"{ind}  <joint {at}/>")
                 jid[0] += 1
         nonlocal ngeom_budget
-        if ngeom_budget > 0 and rng.random() < 0.7:
+        if convex and ngeom_budget > 0 and rng_c.random() < 0.8:
+            ngeom_budget -= 1
+            kind_g = rng_c.choice(["sphere", "capsule", "box", "mesh"], p=[0.2, 0.25, 0.35, 0.2])
+            at = f'name="g{b}" pos="{_v(rng_c, -0.05, 0.05)}" quat="{" ".join(f"{x:.4f}" for x in rng_c.standard_normal(4))}" friction="{rng_c.uniform(0.3, 1.2):.2f}"'
+            if kind_g == "sphere":
+                at += f' type="sphere" size="{rng_c.uniform(0.04, 0.09):.3f}"'
+            elif kind_g == "capsule":
+                at += f' type="capsule" size="{rng_c.uniform(0.03, 0.05):.3f} {rng_c.uniform(0.05, 0.12):.3f}"'
+            elif kind_g == "box":
+                at += f' type="box" size="{_v(rng_c, 0.04, 0.1)}"'
+            else:
+                pts = rng_c.standard_normal((int(rng_c.integers(5, 13)), 3))
+                pts = pts / np.linalg.norm(pts, axis=1, keepdims=True) * rng_c.uniform(0.05, 0.1, (len(pts), 1))
+                meshes.append(f'<mesh name="m{b}" vertex="{" ".join(f"{x:.5f}" for x in pts.ravel())}"/>')
+                at += f' type="mesh" mesh="m{b}"'
+            out.append(f"{ind}  <geom {at}/>")
+        elif not convex and ngeom_budget > 0 and rng.random() < 0.7:
             ngeom_budget -= 1
             if rng.random() < 0.5:
                 out.append(f'{ind}  <geom name="g{b}" type="sphere" size="{rng.uniform(0.03, 0.08):.3f}" pos="{_v(rng, -0.05, 0.05)}" friction="{rng.uniform(0.3, 1.2):.2f}"/>')
@@ -92,14 +116,16 @@ def random_mjcf(seed: int) -> str:
         a, b = rng.choice(len(scalar_joints), 2, replace=False)
         out.append(f'  <equality><joint name="eq0" joint1="{scalar_joints[a]}" joint2="{scalar_joints[b]}" polycoef="0 {rng.uniform(-1, 1):.3f} {rng.uniform(-0.2, 0.2):.3f} 0 0"/></equality>')
     out.append("</mujoco>")
+    if meshes:
+        out.insert(3, "  <asset>" + "".join(meshes) + "</asset>")
     return "\n".join(out)
 
 
-def random_model(seed: int):
+def random_model(seed: int, convex: bool = False):
     """Host model for `seed`, or None when the draw exceeds the device capacity (caller skips it)."""
-    m = MjModel.from_xml_string(random_mjcf(seed))
+    m = MjModel.from_xml_string(random_mjcf(seed, convex))
     nlim = int(np.sum(m.jnt_limited))
-    if m.nv > 32 or m.neq + nlim + 4 * m.ncon > 64 or getattr(m, "nunsupported_pairs", 0) or m.ncon > 63:
+    if m.nv > 32 or m.neq + nlim + 4 * m.ncon > 64 or getattr(m, "nunsupported_pairs", 0) or m.ncon > (16 if convex else 63):
         return None
     return m
 

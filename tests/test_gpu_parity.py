@@ -816,6 +816,59 @@ def test_random_models_vs_oracle(dev):
     assert tested >= 30 and widths == {16, 32, 64}, (tested, widths)  # all three lane-group widths were exercised
 
 
+def test_random_convex_models_vs_oracle(dev):
+    """Fuzz parity, convex family (tests/fuzz_models.py, convex=True: boxes and random mesh hulls beside spheres and capsules on random
+    trees that start in or near contact): plane-convex, convex-convex, sphere-convex and capsule-convex pairs in one model, up to
+    16 contact slots.  Same bars as test_random_models_vs_oracle; where fp32 rounding flips a manifold tie (the oracle's own fp32
+    run then lands far from its fp64 run) the kernel is held to the fp32 oracle instead."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from fuzz_models import random_inputs, random_model
+    from ambersim_amd import mjx
+    from oracle.oracle import Oracle
+    tested, fns, active, worst = 0, set(), 0, 0.0
+    for seed in range(60):
+        mj = random_model(seed, convex=True)
+        if mj is None or mj.ncon == 0:
+            continue
+        x0, us = random_inputs(mj, seed, 8, 5)
+        x0, us = x0.astype(np.float32), us.astype(np.float32)
+        ref = Oracle(mj, np.float64).rollout(x0, us)
+        ref32 = Oracle(mj, np.float32).rollout(x0, us)
+        if not (np.isfinite(ref).all() and np.isfinite(ref32).all()) or np.abs(ref).max() > 100:
+            continue
+        prng = np.random.default_rng(1000 + seed)
+        sens = np.zeros(x0.shape[0])
+        for _ in range(3):
+            xp = (x0 * (1 + 3e-7 * prng.standard_normal(x0.shape))).astype(np.float32)
+            rp = Oracle(mj, np.float64).rollout(xp, us)
+            d = np.abs(np.nan_to_num(rp, nan=1e30) - ref).reshape(len(ref), -1).max(axis=1) / max(1.0, np.abs(ref).max())
+            sens = np.maximum(sens, d)
+        keep = sens < 1e-3
+        if keep.sum() < 4:
+            continue
+        x0, us, ref, ref32 = x0[keep], us[keep], ref[keep], ref32[keep]
+        o = Oracle(mj, np.float64)
+        for k in range(len(x0)):
+            o.set_state(x0[k, :mj.nq], x0[k, mj.nq:], us[k, 0]); o.forward()
+            active += int((o.get("con_dist") < 0).sum())
+        model = mjx.put_model(mj, dev)
+        xs = gpu_rollout(model, x0, us)
+        assert np.isfinite(xs).all(), seed
+        def per_env(a, b, t):
+            return np.abs(a[:, t] - b[:, t]).max(axis=1) / np.maximum(1.0, np.abs(b[:, t]).max())
+        for t, tol, mult in ((1, TOL, 3), (5, 5e-5, 5)):
+            e64, e32, f = per_env(xs, ref, t), per_env(xs, ref32, t), per_env(ref32, ref, t)
+            ok = (e64 <= np.maximum(tol, mult * f)) | (e32 <= tol)
+            assert ok.all(), (seed, t, e64.max(), e32.max(), f.max())
+            if t == 1:
+                worst = max(worst, float(np.minimum(e64, e32).max()))
+        fns |= set(int(f) for f in mj.pair_fn)
+        tested += 1
+    print(f"convex fuzz: {tested} models, pair functions {sorted(fns)}, {active} active contacts, worst one-step error {worst:.2e}")
+    assert tested >= 25 and {2, 6, 7, 11} <= fns and active >= 100, (tested, fns, active)
+
+
 @pytest.mark.parametrize("force", ["32", "64"])
 def test_forced_lane_group_widths(cases, golden, force, dev):
     """Every model also runs on a wider lane group than it needs (AMX_FORCE_G is read when the model is created): the
