@@ -1896,6 +1896,17 @@ struct Env {
   bool cEq;         // the lane's slot B row belongs to a connect / weld equality (a pseudo-pair, [npc, npair - nbl)): active on both sides
   bool cBl;         // ... to a ball joint's limit (pseudo-pair [npair - nbl, npair)): single-sided like a contact row, one row per group
   PROF_DECL
+#ifndef AMX_PHASE_PRIO
+#define AMX_PHASE_PRIO 1  // 0: issue priority by progress only (r03: the lagging wave of a SIMD's pair at 3, the other at 0), A/B switch
+#endif
+  // Issue priority by phase, on top of the pair's fair sharing (amx_rollout_kernel): the solve - issue-bound: eliminations, line search -
+  // runs one level above the tree passes, whose few instructions wait on LDS round trips either way; the wave that is behind its
+  // SIMD partner gets one more level.  Measured (profiles/r04_ab_phase_prio.txt): +1 % on all three biped workloads; the opposite
+  // order -0.3 %, without the lagging wave's bonus -1.3 %, finer levels inside the solve (eliminations or line search on top) +-0.
+  int prio_lag = 0;  // 1: this wave is behind its SIMD partner (set per step by the rollout loop)
+  template <int LEVEL> DEV void phase_prio() const {
+    if (AMX_PHASE_PRIO) { if (prio_lag) __builtin_amdgcn_s_setprio(LEVEL + 1); else __builtin_amdgcn_s_setprio(LEVEL); }
+  }
 
   DEV int nA() const { return m.nefc() == 0 ? 0 : m.neq() + m.nfri() + m.nlim(); }  // nefc == 0: constraints disabled
   DEV int nB() const { return m.nefc() == 0 ? 0 : 4 * m.ncon(); }
@@ -3633,6 +3644,7 @@ struct Env {
   template <class Hook> DEV void forward(Hook after_poses) {
     const int nv = m.nv();
     PROF(0);
+    phase_prio<0>();
     kinematics();
     PROF(1);
     com_pos();
@@ -3662,6 +3674,7 @@ struct Env {
       WSYNC();
       return;
     }
+    phase_prio<2>();
     solve();
     if (gl < nv) dof(D_WARM, gl) = dof(D_QACC, gl);
     WSYNC();
@@ -3801,7 +3814,8 @@ amx_rollout_kernel(const DevModel m_in, int nenv, int nsteps, int x0_batched, co
       const int mine_ = t + 1;
       if (lane == 0) lds[m.c_prog() + wave] = __int_as_float(simd_tag | mine_);
       const int other_ = __builtin_amdgcn_readfirstlane(CI(m.c_prog() + (wave ^ 4)));
-      if (((other_ ^ simd_tag) >> 24) == 0 && (other_ & 0xFFFFFF) > mine_) __builtin_amdgcn_s_setprio(3);
+      if (AMX_PHASE_PRIO) env.prio_lag = (((other_ ^ simd_tag) >> 24) == 0 && (other_ & 0xFFFFFF) > mine_) ? 1 : 0;
+      else if (((other_ ^ simd_tag) >> 24) == 0 && (other_ & 0xFFFFFF) > mine_) __builtin_amdgcn_s_setprio(3);
       else __builtin_amdgcn_s_setprio(0);
     }
     if (t >= 0) {
