@@ -308,15 +308,45 @@ def test_barrett_two_fingers_touch():
     assert o.get("con_dist").min() > 0.5 * d0.min()  # pushed out of the deep overlap
 
 
-def test_two_finger_fixture_is_current():
-    """tests/golden/bh280_twofingers.xml is what its generator derives from the reference model (skipped where the reference is absent)."""
+TOUCH3_Q = np.array([1.89801905, 0.62688226, 2.15748466, 2.00644938, 0.54154126, 2.4753967, 2.17202135, 0.2233661])  # all three fingertips interpenetrate, 0.012 each
+
+
+def threefingers_model():
+    import os
+    from conftest import GOLDEN
+    mj = MjModel.from_xml_path(os.path.join(GOLDEN, "bh280_threefingers.xml"))
+    mj.opt = mj.opt.replace(timestep=0.002, iterations=4, ls_iterations=8)
+    from ambersim_amd.mjcf import recompile_options
+    return recompile_options(mj)
+
+
+def test_barrett_three_fingers_touch():
+    """All three distal links of the reference's Barrett hand with a 32-vertex hull each (r04 fixture, 60 faces and 90 edges per hull -
+    beyond r03's 32 / 64 limits): three convex-convex pairs, 12 contact slots; in the closed pose every pair of fingertips
+    interpenetrates by 0.012 and the contacts push them apart."""
+    mj = threefingers_model()
+    assert (mj.nq, mj.nu, mj.neq) == (8, 4, 4) and mj.pair_fn.tolist() == [6, 6, 6] and mj.ncon == 12
+    assert mj.hull_vertnum.tolist() == [32, 32, 32] and mj.hull_facenum.tolist() == [60, 60, 60] and mj.hull_edgenum.tolist() == [90, 90, 90]
+    o = Oracle(mj)
+    o.set_state(TOUCH3_Q, np.zeros(8), np.zeros(4)); o.forward()
+    d0 = o.get("con_dist").reshape(3, 4).min(axis=1)
+    assert np.allclose(d0, -0.0118, atol=2e-4) and o.get("nefc")[0] == 4 + 3 * 4
+    xs = o.rollout(np.concatenate([TOUCH3_Q, np.zeros(8)]), np.zeros((1, 200, 4)))[0]
+    assert np.isfinite(xs).all()
+    o.set_state(xs[-1, :8], xs[-1, 8:], np.zeros(4)); o.forward()
+    assert o.get("con_dist").min() > 0.5 * d0.min()
+
+
+def test_finger_fixtures_are_current():
+    """tests/golden/bh280_twofingers.xml and bh280_threefingers.xml are what their generator derives from the reference model (skipped where the reference is absent)."""
     import os, subprocess, sys, tempfile
     from conftest import GOLDEN
     if not os.path.exists("/root/reference/ambersim/models/barrett_hand/bh280.xml"):
         pytest.skip("reference not present on this machine")
-    before = open(os.path.join(GOLDEN, "bh280_twofingers.xml")).read()
+    names = ("bh280_twofingers.xml", "bh280_threefingers.xml")
+    before = [open(os.path.join(GOLDEN, n)).read() for n in names]
     subprocess.run([sys.executable, os.path.join(GOLDEN, "make_bh280_twofingers.py")], check=True, capture_output=True)
-    assert open(os.path.join(GOLDEN, "bh280_twofingers.xml")).read() == before
+    assert [open(os.path.join(GOLDEN, n)).read() for n in names] == before
 
 
 @pytest.mark.gpu
@@ -346,6 +376,35 @@ def test_barrett_two_fingers_gpu_vs_oracle():
     e1 = np.minimum(np.abs(xs[:, 1] - ref[:, 1]).max(axis=1), np.abs(xs[:, 1] - ref32[:, 1]).max(axis=1)) / np.maximum(1.0, np.abs(ref[:, 1]).max(axis=1))
     e10 = np.minimum(np.abs(xs[:, 10] - ref[:, 10]).max(axis=1), np.abs(xs[:, 10] - ref32[:, 10]).max(axis=1)) / np.maximum(1.0, np.abs(ref[:, 10]).max(axis=1))
     print(f"bh280 two fingers: {nact} of {nenv} envs in contact; 1-step err {e1.max():.2e}, 10-step err median {np.median(e10):.2e} max {e10.max():.2e}")
+    assert np.isfinite(xs).all() and e1.max() < 1e-5 and np.median(e10) < 1e-5 and e10.max() < 5e-5
+
+
+@pytest.mark.gpu
+def test_barrett_three_fingers_gpu_vs_oracle():
+    """The three-finger Barrett fixture on the GPU (three pairs of 32-vertex hulls, 8 100 edge axes per pair): poses around the one where
+    all three fingertips touch; same bars as the two-finger test."""
+    import torch
+    from ambersim_amd import mjx
+    mj = threefingers_model()
+    dev = torch.device("cuda", 0)
+    model = mjx.put_model(mj, dev)
+    rng = np.random.default_rng(23)
+    nenv = 32
+    q = np.clip(TOUCH3_Q + 0.12 * rng.standard_normal((nenv, 8)), mj.jnt_range[:, 0] + 0.01, mj.jnt_range[:, 1] - 0.01)
+    x0 = np.concatenate([q, 0.2 * rng.standard_normal((nenv, 8))], axis=1).astype(np.float32)
+    us = rng.uniform(-1, 1, (nenv, 10, 4)).astype(np.float32)
+    xs = mjx.rollout(model, torch.tensor(x0), torch.tensor(us)).cpu().numpy().astype(np.float64)
+    ref = Oracle(mj, np.float64).rollout(x0, us)
+    ref32 = Oracle(mj, np.float32).rollout(x0, us).astype(np.float64)
+    o = Oracle(mj, np.float64)
+    npairs = np.zeros(nenv, dtype=int)
+    for k in range(nenv):
+        o.set_state(x0[k, :8], x0[k, 8:], us[k, 0]); o.forward()
+        npairs[k] = int((o.get("con_dist").reshape(3, 4).min(axis=1) < 0).sum())
+    assert (npairs >= 2).sum() >= 4 and (npairs == 0).sum() >= 2, npairs  # several fingertips at once, and free motion, are both in the draw
+    e1 = np.minimum(np.abs(xs[:, 1] - ref[:, 1]).max(axis=1), np.abs(xs[:, 1] - ref32[:, 1]).max(axis=1)) / np.maximum(1.0, np.abs(ref[:, 1]).max(axis=1))
+    e10 = np.minimum(np.abs(xs[:, 10] - ref[:, 10]).max(axis=1), np.abs(xs[:, 10] - ref32[:, 10]).max(axis=1)) / np.maximum(1.0, np.abs(ref[:, 10]).max(axis=1))
+    print(f"bh280 three fingers: pairs in contact per env {np.bincount(npairs, minlength=4).tolist()}; 1-step err {e1.max():.2e}, 10-step err median {np.median(e10):.2e} max {e10.max():.2e}")
     assert np.isfinite(xs).all() and e1.max() < 1e-5 and np.median(e10) < 1e-5 and e10.max() < 5e-5
 
 
