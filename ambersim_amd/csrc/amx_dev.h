@@ -24,7 +24,6 @@
 // Record strides (floats) of the per-environment slab, also odd.
 enum { BODY_E = 29, JNT_E = 7, DOF_E = 17, ROW_E = 3, CON_E = 5, GEO_E = 13 };
 enum { BODY_S = 25, JNT_S = 13, DOF_S = 13, ACT_S = 13, GEOM_S = 13, PAIR_S = 33, LIM_S = 15, EQ_S = 21, HULL_S = 7, FRI_S = 5 };
-// convex-convex scratch per environment (floats): world vertices of both hulls [2][32][3], two clip polygons [2][16][3]
 // convex-convex limits and scratch: world vertices of both hulls [2][cx_maxv][3] (cx_maxv = the model's largest hull in such a pair), two clip
 // polygons [2][CX_MAXP][3], one spare word
 enum { CX_MAXV = 64, CX_MAXF = 128, CX_MAXE = 192, CX_MAXP = 16, CX_TAIL = 6 * CX_MAXP + 1 };
