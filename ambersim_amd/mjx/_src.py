@@ -58,9 +58,10 @@ class _Handle:
 
     def __init__(self, mj: MjModel, device_index: int, specialise: bool = False):
         self.desc = build_desc(mj)
-        self.ptr = C.c_void_p()
+        self._ptr = C.c_void_p()
+        self.refuse = None  # set by Model: why this handle must not be stepped (see Model.__init__)
         self.L = _lib.lib()
-        _lib.check(self.L.amx_model_create(C.byref(self.desc), device_index, C.byref(self.ptr)), self.L)
+        _lib.check(self.L.amx_model_create(C.byref(self.desc), device_index, C.byref(self._ptr)), self.L)
         if specialise and not self.query("specialised"):
             # specialise: True = the caller asked for a per-model build (errors propagate); "auto" = the default: build one when hipcc
             # is on this machine, say so in one line, and run the generic kernels (about half the throughput) when it is not
@@ -78,8 +79,8 @@ class _Handle:
                 L2 = _lib.load(build_specialised_library(mj))
                 ptr2 = C.c_void_p()
                 _lib.check(L2.amx_model_create(C.byref(self.desc), device_index, C.byref(ptr2)), L2)
-                self.L.amx_model_destroy(self.ptr)
-                self.L, self.ptr = L2, ptr2
+                self.L.amx_model_destroy(self._ptr)
+                self.L, self._ptr = L2, ptr2
             except Exception as e:
                 if specialise != "auto":
                     raise
@@ -88,13 +89,21 @@ class _Handle:
 
     def query(self, name: str) -> int:
         out = C.c_int()
-        _lib.check(self.L.amx_model_query(self.ptr, name.encode(), C.byref(out)), self.L)
+        _lib.check(self.L.amx_model_query(self._ptr, name.encode(), C.byref(out)), self.L)
         return out.value
+
+    @property
+    def ptr(self):
+        """The amx_model* every compute entry point passes to the library.  A model whose contact the engine cannot run (see
+        Model.__init__) is refused here, at its first use, with the exception type `mjx.device_put` raises for unsupported features."""
+        if self.refuse:
+            raise NotImplementedError(self.refuse)
+        return self._ptr
 
     def __del__(self):
         try:
-            if self.ptr:
-                self.L.amx_model_destroy(self.ptr)
+            if self._ptr:
+                self.L.amx_model_destroy(self._ptr)
         except Exception:
             pass
 
@@ -115,7 +124,27 @@ class Model:
         self.nq, self.nv, self.nu, self.nbody, self.njnt, self.ngeom, self.neq = mj.nq, mj.nv, mj.nu, mj.nbody, mj.njnt, mj.ngeom, mj.neq
         self.actuator_ctrlrange = torch.as_tensor(np.asarray(mj.actuator_ctrlrange, dtype=np.float32).reshape(-1, 2), device=device)
         self.qpos0 = torch.as_tensor(np.asarray(mj.qpos0, dtype=np.float32), device=device)
-        self._h = _Handle(mj, device.index or 0, specialise)
+        # Collision pairs outside the implemented pair functions (the reference's full Barrett hand: 2000+ mesh-mesh pairs of hulls with
+        # hundreds of vertices).  MJX puts such a model on the device and the reference then switches its contact off
+        # (tests/trajopt/test_predictive_sampler.py:14-31: load, `model.replace(opt=...disableflags=DisableBit.CONTACT)`, shoot), so the
+        # model must survive `put_model` for that flow to work: it is planned without its contact, and every entry point that would step
+        # it WITH contact raises NotImplementedError (reference io_utils.py:228-241's exception type) - `replace(opt=...)` with contact
+        # disabled gives a model that runs.
+        refuse = None
+        if getattr(mj, "nunsupported_pairs", 0) and not (int(self.opt.disableflags) & (DisableBit.CONTACT | DisableBit.CONSTRAINT)):
+            refuse = (f"{mj.nunsupported_pairs} collision pairs are outside the implemented pair functions (condim != 3, a cylinder or ellipsoid, a "
+                      "convex hull beyond 64 vertices / 128 faces / 192 edges - `maxhullvert` caps a mesh's hull): this model cannot be stepped "
+                      "with contact enabled; model.replace(opt=model.opt.replace(disableflags=DisableBit.CONTACT)), restrict contype / "
+                      "conaffinity or simplify the meshes")
+            import logging
+            logging.getLogger("ambersim_amd").warning("put_model: %s", refuse)
+            plan_mj = copy.copy(mj)
+            plan_mj.opt = mj.opt.replace(disableflags=int(mj.opt.disableflags) | DisableBit.CONTACT)
+            mj_for_plan = recompile_options(plan_mj)
+        else:
+            mj_for_plan = mj
+        self._h = _Handle(mj_for_plan, device.index or 0, specialise)
+        self._h.refuse = refuse
         self.ncon = self._h.query("ncon")
         self.nefc_max = self._h.query("nefc_max")
 
@@ -171,11 +200,6 @@ def put_model(mj: MjModel, device=None, specialise: Optional[bool] = None) -> Mo
     hipcc is available, fall back to the generic kernels with one log line when it is not; False: always the library's own kernels."""
     if mj.opt.integrator != 0:
         raise NotImplementedError("only the Euler integrator is implemented")
-    if getattr(mj, "nunsupported_pairs", 0):
-        raise NotImplementedError(
-            f"{mj.nunsupported_pairs} collision pairs are outside the implemented pair functions (condim != 3, a cylinder or "
-            "ellipsoid, or a convex hull beyond 32 vertices / 32 faces / 64 edges); disable contact "
-            "(DisableBit.CONTACT), restrict contype/conaffinity or simplify the meshes")
     if specialise is None:
         # default (r04): "auto" - a model the library ships no kernels for gets a per-model build when hipcc is on this machine
         # (the generic kernels run at about half the throughput: bench.py, "C3 generic kernels"); AMX_SPECIALISE=0 / 1 forces never / always

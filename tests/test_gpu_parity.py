@@ -816,6 +816,46 @@ def test_random_models_vs_oracle(dev):
     assert tested >= 30 and widths == {16, 32, 64}, (tested, widths)  # all three lane-group widths were exercised
 
 
+def test_unsupported_contact_is_refused_at_first_use_not_at_put(dev):
+    """The reference loads its full Barrett hand - mesh-mesh pairs no batched engine here can run - and then switches contact off
+    (reference tests/trajopt/test_predictive_sampler.py:14-31: load, model.replace(opt=...DisableBit.CONTACT), shoot).  The same flow
+    on a model with a pair outside the implemented functions (a cylinder): put_model succeeds, every entry point refuses to step it
+    with contact on (NotImplementedError, the type the reference catches around device_put), and the contact-free replacement runs
+    and matches the oracle."""
+    from ambersim_amd import mjx
+    from ambersim_amd.mjcf import DisableBit, MjModel, recompile_options
+    from oracle.oracle import Oracle
+    import copy
+    xml = """<mujoco><option timestep="0.002" iterations="3" ls_iterations="5"/><worldbody><geom type="plane" size="5 5 .1"/>
+      <body pos="0 0 0.3"><freejoint/><geom type="cylinder" size=".1 .1" mass="1"/></body>
+      <body pos="0.05 0 0.6"><joint name="h" type="hinge" axis="0 1 0" damping="0.1"/><geom type="box" size=".1 .1 .1" pos="0.2 0 0" mass="0.5"/></body>
+      </worldbody><actuator><motor joint="h" gear="1" ctrlrange="-1 1"/></actuator></mujoco>"""
+    mj = MjModel.from_xml_string(xml)
+    assert mj.nunsupported_pairs > 0
+    model = mjx.put_model(mj, dev)
+    assert (model.nq, model.nv, model.nu) == (8, 7, 1) and model.opt.disableflags == 0
+    rng = np.random.default_rng(5)
+    x0 = np.concatenate([np.tile(mj.qpos0, (4, 1)), 0.3 * rng.standard_normal((4, mj.nv))], axis=1).astype(np.float32)
+    us = rng.uniform(-1, 1, (4, 6, 1)).astype(np.float32)
+    with pytest.raises(NotImplementedError, match="collision pairs"):
+        mjx.rollout(model, torch.tensor(x0), torch.tensor(us))
+    with pytest.raises(NotImplementedError):
+        mjx.forward(model, mjx.make_data(model))
+    with pytest.raises(NotImplementedError):
+        mjx.step(model, mjx.make_data(model))
+    off = model.replace(opt=model.opt.replace(disableflags=DisableBit.CONTACT))
+    assert off.opt.disableflags == DisableBit.CONTACT
+    xs = gpu_rollout(off, x0, us)
+    mj_off = copy.copy(mj)
+    mj_off.opt = mj.opt.replace(disableflags=DisableBit.CONTACT)
+    ref = Oracle(recompile_options(mj_off), np.float64).rollout(x0, us)
+    assert np.isfinite(xs).all() and rel(xs[:, -1], ref[:, -1]) < TOL
+    # and back: contact switched on again is refused again
+    on = off.replace(opt=off.opt.replace(disableflags=0))
+    with pytest.raises(NotImplementedError):
+        mjx.rollout(on, torch.tensor(x0), torch.tensor(us))
+
+
 def test_random_convex_models_vs_oracle(dev):
     """Fuzz parity, convex family (tests/fuzz_models.py, convex=True: boxes and random mesh hulls beside spheres and capsules on random
     trees that start in or near contact): plane-convex, convex-convex, sphere-convex and capsule-convex pairs in one model, up to

@@ -66,3 +66,38 @@ def test_shard_range_partitions(n, world):
     assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
     sizes = [hi - lo for lo, hi in spans]
     assert max(sizes) - min(sizes) <= 1
+
+
+def test_full_barrett_hand_follows_the_references_flow(monkeypatch):
+    """reference tests/trajopt/test_predictive_sampler.py:14-31: load bh280.xml, replace(opt=...DisableBit.CONTACT), shoot.  Host side of
+    that flow (the device handle is replaced by a recorder: no GPU here): put_model accepts the full hand although none of its 2000+
+    mesh-mesh pairs can run, plans it without contact, hands out its device pointer only once contact is disabled."""
+    import os
+    import pytest
+    path = "/root/reference/ambersim/models/barrett_hand/bh280.xml"
+    if not os.path.exists(path):
+        pytest.skip("reference not present on this machine")
+    import torch
+    from ambersim_amd.mjx import _src
+    from ambersim_amd.mjcf import DisableBit
+    from ambersim_amd.utils.io_utils import load_mj_model_from_file
+    planned = []
+
+    class FakeHandle:
+        def __init__(self, mj, device_index, specialise=False):
+            planned.append(mj)
+            self.refuse, self._ptr = None, 1234
+
+        def query(self, name):
+            return 0
+        ptr = _src._Handle.ptr
+
+    monkeypatch.setattr(_src, "_Handle", FakeHandle)
+    mj = load_mj_model_from_file(path)
+    assert mj.nunsupported_pairs > 2000
+    model = _src.put_model(mj, torch.device("cpu"), specialise=False)
+    assert (model.nq, model.nu) == (8, 4) and planned[-1].npair == 0 and planned[-1].opt.disableflags & DisableBit.CONTACT and model.opt.disableflags == 0
+    with pytest.raises(NotImplementedError, match="collision pairs"):
+        model._h.ptr
+    off = model.replace(opt=model.opt.replace(timestep=0.002, iterations=1, ls_iterations=4, disableflags=DisableBit.CONTACT))
+    assert off._h.ptr == 1234 and planned[-1].npair == 0 and off.opt.timestep == 0.002

@@ -43,7 +43,7 @@ def test_reference_models_load():
     h = load_mj_model_from_file(base + "/barrett_hand/bh280.xml")
     assert (h.nq, h.nu, h.neq, h.ngeom) == (8, 4, 4, 98)
     assert h.nmesh == 48 and h.mesh_vert.shape[0] > 1000  # 44 collision + 4 visual meshes, stored as convex hulls
-    assert h.nunsupported_pairs == h.npair > 2000  # mesh-mesh pairs: host model loads, device put would refuse
+    assert h.nunsupported_pairs == h.npair > 2000  # mesh-mesh pairs: the host model loads; put_model plans it without contact and refuses to step it with contact on
     # geoms never change the dynamics constants here: explicit inertials win
     g = MjModel.from_xml_path(os.path.join(GOLDEN, "bh280_nomesh.xml"))
     assert np.allclose(h.body_mass, g.body_mass) and np.allclose(h.dof_invweight0, g.dof_invweight0)
