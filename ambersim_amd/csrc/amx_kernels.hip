@@ -52,6 +52,9 @@
 #ifndef AMX_MFMA_AUG_MIN_NV
 #define AMX_MFMA_AUG_MIN_NV 24  // measured: biped (30 dofs) +0.5 %, C4 +1 %; quadruped (18 dofs: three of the tile's eight chunks are zero fill) -1.2 %
 #endif
+#ifndef AMX_GRADCOL_64
+#define AMX_GRADCOL_64 1  // 0: static 64-lane kernels gather J'f per dof as before (A/B switch)
+#endif
 #ifndef AMX_NO_GRADCOL
 #define AMX_NO_GRADCOL 0  // 1: J'f of the contact rows always by the per-dof gather (A/B switch)
 #endif
@@ -594,7 +597,7 @@ typedef float v32f __attribute__((ext_vector_type(32)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 // The matrix-core part: on return lane (b, j) holds row j of its environment's J'DJ as sixteen-byte chunks,
 // lo[q][r] = (J'DJ)[j][8q+r], hi[q][r] = (J'DJ)[j][8q+4+r].  crows, ldc, slot_base are wave-uniform scalars.
-// COL31 (32-lane groups, nv <= 31): lane 31 of each block feeds A = field 1 of the row record (the row's force f_r) instead of
+// COL31 (nv <= 31): lane 31 of each block (64-lane groups: of each K slice) feeds A = field 1 of the row record (the row's force f_r) instead of
 // D_r J_r[31] = 0, so row 31 of the product is sum_r f_r J_r[i] = the contact rows' part of J'f = qfrc_constraint.  Lane i
 // holds column i of the accumulator: the entry reaches it as hi[3][3] with its Hessian row, for four more broadcast loads per
 // contact.
@@ -701,13 +704,19 @@ DEV void jtdj_rows_mfma(unsigned long long crows, int row_base, int J_base, int 
       const int slot = CI(slot_base + 32 * c + j);
       const bool has = slot >= 0;
       const int Jr = J_base + (4 * c + h) * ldc + (has ? slot : 0), Dr = row_base + (4 * c + h) * ROW_E;
-      float d[2], jv[2];
+      float d[2], jv[2], g[2];
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) { d[s2] = lds[Dr + 2 * s2 * ROW_E]; jv[s2] = lds[Jr + 2 * s2 * ldc]; }
+      for (int s2 = 0; s2 < 2; ++s2) {
+        d[s2] = lds[Dr + 2 * s2 * ROW_E]; jv[s2] = lds[Jr + 2 * s2 * ldc];
+        g[s2] = 0.0f;
+        if (COL31) g[s2] = lds[Dr + 2 * s2 * ROW_E + 1];
+      }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const float v = has ? jv[s2] : 0.0f;
-        C = __builtin_amdgcn_mfma_f32_32x32x2f32(d[s2] * v, v, C, 0, 0, 0);
+        // COL31 (r04, as in the two-block form): lane 31 of either K slice feeds the row's force as its A entry - row 31 of the product is J'f
+        const float aop = (COL31 && j == 31) ? g[s2] : d[s2] * v;
+        C = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, v, C, 0, 0, 0);
       }
     }
 #pragma unroll
@@ -1102,7 +1111,7 @@ AMX_STATIC_SOLVE_ATTR bool newton_solve_fused(int M_off, int ld_, int n_, unsign
     float d0 = 0.0f;
     if (owner) { d0 = lds[dg]; lds[dg] = d0 + dlim; }
     float b;
-    if constexpr (GRADCOL && AMX_MFMA_AUG && (S::ldm > S::nv) && (S::nv >= AMX_MFMA_AUG_MIN_NV)) {
+    if constexpr (GRADCOL && G == 32 && AMX_MFMA_AUG && (S::ldm > S::nv) && (S::nv >= AMX_MFMA_AUG_MIN_NV)) {
       // r03: the rows of M, the gradient and the mirrored right-hand-side row all come out of the matrix cores' accumulator.
       //  * The accumulator starts from M instead of zero.  In the 2-block instruction's layout lane l of the wave holds, for block
       //    0 (the wave's first environment) and block 1 (its second), rows 8q + 4 (l / 32) + r of column l % 32; after the
@@ -3076,7 +3085,7 @@ struct Env {
   // also publishes D*active per row for the Hessian assembly.
   // grad_in_solve(): the specialised fused Newton path takes J'f of the contact rows from the matrix cores (newton_solve_fused
   // GRADCOL), so a call that is followed by newton_direction() only publishes the row records and the limit-row force
-  static constexpr bool grad_in_solve() { return S::is_static && G == 32 && S::fusedH && S::solver == 2 && S::nv <= 31 && sym_elim_ok<S, G>() && !AMX_NO_GRADCOL; }
+  static constexpr bool grad_in_solve() { return S::is_static && (G == 32 || (G == 64 && AMX_GRADCOL_64)) && S::fusedH && S::solver == 2 && S::nv <= 31 && sym_elim_ok<S, G>() && !AMX_NO_GRADCOL; }
   // the two-pair Newton solve (newton_solve_pair2) also writes the search vector
   static constexpr bool search_from_solve() { return grad_in_solve() && S::mfma2 && AMX_MFMA_PAIR2; }
   float pend_flim;  // limit-row force on this lane's dof, handed from a deferring constraint_force_and_grad to newton_direction

@@ -12,7 +12,7 @@ dev = torch.device("cuda", 0)
 out = []
 import os
 CASES = (("models/quadruped/quadruped.xml", 4096, 1000), ("models/biped/biped_stand.xml", 4096, 1000), ("models/biped/biped.xml", 4096, 1000), ("models/biped/biped.xml", 1024, 64),
-         ("models/quadruped/quadruped.xml", 32768, 200), ("models/biped/biped_stand.xml", 32768, 100))
+         ("models/quadruped/quadruped.xml", 32768, 200), ("models/biped/biped_stand.xml", 32768, 100), ("models/biped/biped_rest.xml", 4096, 1000))
 if os.environ.get("AB_CASES"):  # e.g. AB_CASES=biped_stand,biped: only those models (a library built with SPECS=... holds no others)
     CASES = tuple(c for c in CASES if c[0].split("/")[-1][:-4] in os.environ["AB_CASES"].split(","))
 for path, nenv, hor in CASES:

@@ -6,6 +6,11 @@ python tools/check_dpp_hazard.py [ambersim_amd/csrc/amx_gfx950.s]   (make -C amb
 import os, re, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "ambersim_amd", "csrc", "amx_gfx950.s")
+if len(sys.argv) <= 1:
+    src = [os.path.join(root, "ambersim_amd", "csrc", f) for f in ("amx_kernels.hip", "amx_api.cpp", "amx_dev.h", "amx_specs_gen.h")]
+    stale = [f for f in src if os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(path)] if os.path.exists(path) else src
+    if stale:
+        sys.exit(f"{os.path.relpath(path, root)} is older than {', '.join(os.path.basename(f) for f in stale)}: run `make -C ambersim_amd/csrc asm` first")
 reg = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 def regs(tok):
     out = set()
