@@ -3440,6 +3440,9 @@ struct Env {
     asm("v_max_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(o) : "v"(x), "v"(y), "n"(K));
     return o;
   }
+#ifndef AMX_LS_PACKED_X
+#define AMX_LS_PACKED_X 1  // 0: the two row slots' residuals at a trial point as two scalar multiply-adds (A/B switch)
+#endif
   struct LSH { float alpha, hd, h; };
   DEV float linesearch_v2(bool alive) {
     const int nv = m.nv();
@@ -3461,8 +3464,14 @@ struct Env {
     }
     // q0 of the lane's rows at alpha = 0 (the acceptance test's constant terms)
     const float a0A = validA ? 0.5f * aD * aJaref * aJaref : 0.0f, a0B = validB ? 0.5f * cD * cJaref * cJaref : 0.0f;
+    const f2v jv2 = {aJv, cJv}, jr2 = {aJaref, cJaref};  // both row slots' residual at a trial point in one packed multiply-add
     auto terms = [&](float alpha) {  // the lane's (q1 / 2, q2) at alpha, Gauss share included
+#if AMX_LS_PACKED_X
+      const f2v x2 = pk_fma(f2v{alpha, alpha}, jv2, jr2);
+      const float xA = x2.x, xB = x2.y;
+#else
       const float xA = __builtin_fmaf(alpha, aJv, aJaref), xB = __builtin_fmaf(alpha, cJv, cJaref);
+#endif
       const float mA = xA < 0.0f ? 1.0f : 0.0f, mB = xB < 0.0f ? 1.0f : 0.0f;
       return pk_fma(pA, f2v{mA, mA}, pk_fma(pB, f2v{mB, mB}, gsh));
     };
