@@ -3040,7 +3040,7 @@ struct Env {
 #endif
     float a0 = 0, a1 = 0;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
+    for (int t = 0; t < 32; ++t) {  // (ldc <= 31: amx_plan.h)
       if (t < m.ldc()) {  // static in the specialised kernels, wave-uniform otherwise
         const float jt = lds[Jr + t], vt = lds[vch_base + t];
         if (t & 1) a1 = __builtin_fmaf(jt, vt, a1); else a0 = __builtin_fmaf(jt, vt, a0);

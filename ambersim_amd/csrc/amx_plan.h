@@ -373,7 +373,7 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
     for (int i = 0; i < nv; i++) if (sign[i]) pairdof.push_back(i | (sign[i] << 8));
     int dn = (int)pairdof.size() - d0;
     im.seti(o + 9, d0); im.seti(o + 10, dn);
-    if (dn > 16) return fail(AMX_ECAPACITY, "pair %d couples %d dofs (limit 16: the row lanes keep the dof list in registers)", p, dn);
+    if (dn > 31) return fail(AMX_ECAPACITY, "pair %d couples %d dofs (limit 31: slot indices of a contact row's dof list take five bits)", p, dn);
     maxchain = std::max(maxchain, dn);
     for (int a = 0; a < dn; a++) {
       for (int k = 0; k < PAIR_NCON[fn]; k++) dofmem[pairdof[d0 + a] & 255].push_back((4 * (ncon + k)) | (a << 8));

@@ -819,6 +819,57 @@ def test_random_models_vs_oracle(dev):
     assert tested >= 30 and widths == {16, 32, 64}, (tested, widths)  # all three lane-group widths were exercised
 
 
+def _two_arm_model():
+    """A floating torso with two six-hinge arms ending in sphere hands: the hand-hand pair couples the base and both arms, 18 dofs -
+    beyond r03's 16-entry dof lists per contact row (r04: 31)."""
+    def arm(side):
+        s = -1 if side == "l" else 1
+        axes = ["0 1 0", "1 0 0", "0 0 1", "0 1 0", "1 0 0", "0 1 0"]
+        out = ""
+        for k in range(6):
+            pos = f"{0.05 * s} {0.15 * s} 0" if k == 0 else "0.12 0 0"
+            out += (f'<body name="{side}{k}" pos="{pos}"><joint name="j{side}{k}" type="hinge" axis="{axes[k]}" damping="0.05" range="-2 2"/>'
+                    '<inertial pos="0.06 0 0" mass="0.3" diaginertia="0.001 0.002 0.002"/>')
+        return out + f'<geom name="hand_{side}" type="sphere" size="0.06" pos="0.1 0 0"/>' + "</body>" * 6
+    motors = "".join(f'<motor joint="j{s}{k}" gear="2" ctrlrange="-1 1"/>' for s in "lr" for k in range(6))
+    return MjModelCls().from_xml_string(f"""<mujoco><option timestep="0.002" iterations="3" ls_iterations="5"/><worldbody><geom type="plane" size="5 5 .1"/>
+      <body name="torso" pos="0 0 1"><freejoint/><inertial pos="0 0 0" mass="5" diaginertia="0.1 0.1 0.1"/>{arm("l")}{arm("r")}</body></worldbody>
+      <actuator>{motors}</actuator></mujoco>""")
+
+
+def MjModelCls():
+    from ambersim_amd.mjcf import MjModel
+    return MjModel
+
+
+@pytest.mark.parametrize("specialise", [False, True])
+def test_contact_row_over_more_than_sixteen_dofs(dev, specialise):
+    """A self-collision between two limbs: the contact row's dof list is the union of both ancestor chains (18 entries here).  Poses around
+    one where the hands interpenetrate, generic kernels and a per-model build: one step within 1e-5, five within 5e-5 of the fp64 oracle."""
+    from ambersim_amd import mjx
+    from oracle.oracle import Oracle
+    mj = _two_arm_model()
+    assert (mj.nv, mj.pair_fn.tolist()) == (18, [0, 0, 3])
+    model = mjx.put_model(mj, dev, specialise=specialise)
+    assert model._h.query("specialised") == int(specialise)
+    touch = np.array([1.495, -0.637, 1.179, 0.016, -0.511, 0.379, 1.39, -1.408, 1.265, -0.02, 0.216, 1.078])
+    rng = np.random.default_rng(9)
+    nenv = 32
+    q = np.tile(mj.qpos0, (nenv, 1))
+    q[:, 7:] = touch + 0.08 * rng.standard_normal((nenv, 12))
+    x0 = np.concatenate([q, 0.2 * rng.standard_normal((nenv, mj.nv))], axis=1).astype(np.float32)
+    us = rng.uniform(-1, 1, (nenv, 5, mj.nu)).astype(np.float32)
+    o = Oracle(mj, np.float64)
+    nact = 0
+    for k in range(nenv):
+        o.set_state(x0[k, :mj.nq], x0[k, mj.nq:], us[k, 0]); o.forward()
+        nact += int(o.get("con_dist")[2] < 0)
+    assert 6 <= nact <= nenv - 4, nact  # hands touching in most draws, apart in some
+    xs = gpu_rollout(model, x0, us)
+    ref = o.rollout(x0, us)
+    assert np.isfinite(xs).all() and rel(xs[:, 1], ref[:, 1]) < TOL and rel(xs[:, 5], ref[:, 5]) < 5e-5, (rel(xs[:, 1], ref[:, 1]), rel(xs[:, 5], ref[:, 5]))
+
+
 def test_unsupported_contact_is_refused_at_first_use_not_at_put(dev):
     """The reference loads its full Barrett hand - mesh-mesh pairs no batched engine here can run - and then switches contact off
     (reference tests/trajopt/test_predictive_sampler.py:14-31: load, model.replace(opt=...DisableBit.CONTACT), shoot).  The same flow
