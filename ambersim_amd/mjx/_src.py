@@ -148,11 +148,29 @@ class Model:
         self.ncon = self._h.query("ncon")
         self.nefc_max = self._h.query("nefc_max")
 
+    # parameter arrays `replace` accepts beside `opt` (the reference itself only replaces `opt`, tests/trajopt/test_predictive_sampler.py:22-31;
+    # these are what domain randomisation over an mjx.Model touches): the array goes into a copy of the host model as it is - like
+    # mjx.Model.replace, nothing derived from it (invweight0, pair friction of explicit <pair>s) is recomputed, except the collision
+    # pair table, which is rebuilt from the geoms - and the constant block is uploaded again.  Same shape, no structural change.
+    REPLACEABLE = ("body_mass", "body_inertia", "body_pos", "body_quat", "body_ipos", "body_iquat", "body_invweight0", "jnt_pos", "jnt_axis",
+                   "jnt_range", "jnt_margin", "jnt_stiffness", "jnt_solref", "jnt_solimp", "qpos0", "qpos_spring", "dof_armature", "dof_damping",
+                   "dof_invweight0", "dof_frictionloss", "dof_solref", "dof_solimp", "geom_pos", "geom_quat", "geom_size", "geom_friction",
+                   "geom_solref", "geom_solimp", "geom_margin", "actuator_gear", "actuator_gainprm", "actuator_biasprm", "actuator_ctrlrange",
+                   "actuator_forcerange", "eq_data", "eq_solref", "eq_solimp")
+
     def replace(self, **kw) -> "Model":
-        if set(kw) - {"opt"}:
-            raise NotImplementedError(f"Model.replace supports only opt= (got {sorted(kw)})")
-        opt: Option = kw["opt"]
+        other = set(kw) - {"opt"}
+        if other - set(self.REPLACEABLE):
+            raise NotImplementedError(f"Model.replace supports opt= and the parameter arrays {', '.join(self.REPLACEABLE)} (got {sorted(other - set(self.REPLACEABLE))})")
+        opt: Option = kw.get("opt", self.opt)
         mj = copy.copy(self.mj_model)
+        for k in sorted(other):
+            old = np.asarray(getattr(self.mj_model, k))
+            v = kw[k]
+            v = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+            if v.shape != old.shape:
+                raise ValueError(f"Model.replace({k}=...): shape {v.shape}, the model's is {old.shape}")
+            setattr(mj, k, v.astype(old.dtype, copy=True))
         mj.opt = self.mj_model.opt.replace(
             timestep=float(opt.timestep), iterations=int(opt.iterations), ls_iterations=int(opt.ls_iterations),
             tolerance=float(opt.tolerance), ls_tolerance=float(opt.ls_tolerance), impratio=float(opt.impratio),

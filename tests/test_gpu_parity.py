@@ -819,6 +819,38 @@ def test_random_models_vs_oracle(dev):
     assert tested >= 30 and widths == {16, 32, 64}, (tested, widths)  # all three lane-group widths were exercised
 
 
+def test_model_replace_parameter_arrays(cases, dev):
+    """Model.replace beside `opt` (domain randomisation over an mjx.Model): friction, damping, masses, actuator gains and joint ranges of the
+    quadruped replaced on the device model - each rollout matches the oracle run on a host model with the same arrays; shapes are
+    checked, structural fields are refused."""
+    import copy
+    from ambersim_amd import mjx
+    from ambersim_amd.mjcf import recompile_options
+    from oracle.oracle import Oracle
+    mj, model, x0, us = cases["quadruped"]
+    x0, us = x0[:16], us[:16, :8]
+    rng = np.random.default_rng(12)
+    changes = {"geom_friction": mj.geom_friction * np.array([0.4, 1.0, 1.0]), "dof_damping": mj.dof_damping * rng.uniform(0.5, 2.0, mj.nv),
+               "body_mass": mj.body_mass * rng.uniform(0.8, 1.2, mj.nbody), "actuator_gear": mj.actuator_gear * 0.7,
+               "jnt_range": mj.jnt_range * 0.05, "dof_armature": mj.dof_armature + 0.01}
+    base = gpu_rollout(model, x0, us)
+    for key, val in changes.items():
+        m2 = model.replace(**{key: torch.tensor(val) if key == "dof_damping" else val})  # tensors and arrays alike
+        host = copy.copy(mj)
+        setattr(host, key, np.asarray(val, dtype=float))
+        host = recompile_options(host)
+        xs = gpu_rollout(m2, x0, us)
+        ref = Oracle(host, np.float64).rollout(x0, us)
+        assert rel(xs[:, 1], ref[:, 1]) < TOL and rel(xs[:, -1], ref[:, -1]) < 5e-5, (key, rel(xs[:, 1], ref[:, 1]), rel(xs[:, -1], ref[:, -1]))
+        assert np.abs(xs - base).max() > 1e-4, key  # the replacement is what ran
+    both = model.replace(opt=model.opt.replace(iterations=2), dof_damping=changes["dof_damping"])
+    assert both.opt.iterations == 2 and np.allclose(both.mj_model.dof_damping, changes["dof_damping"]) and model.opt.iterations != 2
+    with pytest.raises(ValueError):
+        model.replace(dof_damping=np.zeros(3))
+    with pytest.raises(NotImplementedError):
+        model.replace(jnt_type=mj.jnt_type)
+
+
 def _two_arm_model():
     """A floating torso with two six-hinge arms ending in sphere hands: the hand-hand pair couples the base and both arms, 18 dofs -
     beyond r03's 16-entry dof lists per contact row (r04: 31)."""
