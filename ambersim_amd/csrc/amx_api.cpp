@@ -118,6 +118,9 @@ static int model_create_impl(const amx_model_desc *d, int device, amx_model **ou
   const int spec = find_spec(m, d, im);
   if (wide_plan && (spec < 0 || m.G != 64)) return AMX_EUNSUPPORTED;  // only kept when the library holds static kernels for it
   if (AMX_NO_GENERIC && spec < 0) return fail(AMX_EUNSUPPORTED, "this build of the library holds only the kernels of the model it was compiled for");
+  if (m.nbs == 2 && spec < 0)
+    return fail(AMX_EUNSUPPORTED, "needs per-model kernels: %d contact slots take two contact rows per lane, which the generic kernels do not carry - "
+                "put_model(..., specialise=True) or AMX_SPECIALISE=1 builds them (hipcc)", m.ncon);
   const int lds_bytes = (m.nconst + m.wpb * (AMX_WAVE / m.G) * m.env_floats) * (int)sizeof(float);
   // The dynamic-LDS limit is an attribute of the KERNEL, shared by every model handle of the process (the generic kernels
   // serve any number of models): it is set to the device's 160 KiB, never to this model's own size - a smaller model created

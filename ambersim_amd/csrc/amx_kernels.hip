@@ -606,7 +606,7 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 // sum_r D_r J_r[k] Jaref_r = -(J' f)[k] next to whatever cinit put there (see newton_solve_fused)
 template <int G, bool COL31 = false, int AUGN = -1>
 DEV void jtdj_rows_mfma(unsigned long long crows, int row_base, int J_base, int ldc, int slot_base, int gl, unsigned (&lo)[4][4], unsigned (&hi)[4][4],
-                        const v32f *cinit = nullptr) {
+                        const v32f *cinit = nullptr, unsigned long long crows2 = 0ull) {
   const int j = gl & 31, h = gl >> 5;
   // one bit per contact that is active in some environment of the wave (wave-uniform scalar loop over the set bits)
   unsigned long long cm = (crows | (crows >> 1) | (crows >> 2) | (crows >> 3)) & 0x1111111111111111ull;
@@ -698,9 +698,12 @@ DEV void jtdj_rows_mfma(unsigned long long crows, int row_base, int J_base, int 
     // one environment per wave: the single-block K = 2 instruction takes two Jacobian rows at a time (lanes 32-63 feed the
     // second), two instructions per contact
     v16f C = {};
-    while (cm != 0ull) {
-      const int c = __builtin_ctzll(cm) >> 2;
-      cm &= cm - 1ull;
+    // (two contact-row slots per lane, r04: rows 64 .. 127 = contacts 16 .. 31 arrive as a second mask)
+    unsigned long long cm2 = (crows2 | (crows2 >> 1) | (crows2 >> 2) | (crows2 >> 3)) & 0x1111111111111111ull;
+    while ((cm | cm2) != 0ull) {
+      const bool second = cm == 0ull;
+      const int c = second ? 16 + (__builtin_ctzll(cm2) >> 2) : (__builtin_ctzll(cm) >> 2);
+      if (second) cm2 &= cm2 - 1ull; else cm &= cm - 1ull;
       const int slot = CI(slot_base + 32 * c + j);
       const bool has = slot >= 0;
       const int Jr = J_base + (4 * c + h) * ldc + (has ? slot : 0), Dr = row_base + (4 * c + h) * ROW_E;
@@ -1092,7 +1095,7 @@ template <class S, int N, int G, bool TREE, bool GRADCOL = false>
 AMX_STATIC_SOLVE_ATTR bool newton_solve_fused(int M_off, int ld_, int n_, unsigned long long crows_, int row_base, int J_base, int ldc_, int slot_base_,
                                                 int rhs_off, int x_off, float dlim, int gl, int gb4, int rot, int bt_off, float flim = 0.0f, float ma_v = 0.0f,
                                                 float fs_v = 0.0f, int fcon_off = 0, bool store_ok = true, bool early_out = false, bool imp_done = false,
-                                                float scale = 1.0f, float tol = 0.0f, ProfCtx *pc = nullptr, bool *group_done = nullptr) {
+                                                float scale = 1.0f, float tol = 0.0f, ProfCtx *pc = nullptr, bool *group_done = nullptr, unsigned long long crows2_ = 0ull) {
   if constexpr (sym_elim_ok<S, G>() && G >= 32) {
     // crossbar-free elimination (see sym_pivot): b reaches lane N as a row through the staging vector at bt_off
     constexpr int NS = S::nv, lds_ = S::ldm, nchs = lds_ / 4;
@@ -1100,6 +1103,8 @@ AMX_STATIC_SOLVE_ATTR bool newton_solve_fused(int M_off, int ld_, int n_, unsign
     asm volatile("" : "+v"(gle));
     const unsigned long long crows_u = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(crows_ >> 32)) << 32) |
                                        (unsigned)__builtin_amdgcn_readfirstlane((int)crows_);
+    const unsigned long long crows2_u = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(crows2_ >> 32)) << 32) |
+                                        (unsigned)__builtin_amdgcn_readfirstlane((int)crows2_);
     unsigned lo[4][4], hi[4][4];
     const bool owner = gl < NS, brow = gl == NS;
     const int li = owner ? gl : 0;
@@ -1181,7 +1186,7 @@ AMX_STATIC_SOLVE_ATTR bool newton_solve_fused(int M_off, int ld_, int n_, unsign
       static_assert(NS <= 31, "column 31 must be spare");
       const float ma = ma_v, fs = fs_v;  // M*qacc and qfrc_smooth of the lane's dof, from the caller's registers
       PROF_CTX(pc, 24);
-      jtdj_rows_mfma<G, true>(crows_u, row_base, J_base, S::ldc, S::c_slot, gl, lo, hi);
+      jtdj_rows_mfma<G, true>(crows_u, row_base, J_base, S::ldc, S::c_slot, gl, lo, hi, nullptr, crows2_u);
       PROF_CTX(pc, 25);
       const float fcon = __uint_as_float(hi[3][3]) + flim;
       b = ma - fs - fcon;
@@ -1198,7 +1203,7 @@ AMX_STATIC_SOLVE_ATTR bool newton_solve_fused(int M_off, int ld_, int n_, unsign
         }
       }
     } else {
-      jtdj_rows_mfma<G>(crows_u, row_base, J_base, S::ldc, S::c_slot, gl, lo, hi);
+      jtdj_rows_mfma<G>(crows_u, row_base, J_base, S::ldc, S::c_slot, gl, lo, hi, nullptr, crows2_u);
       b = lds[rhs_off + li * DOF_E];
     }
     b = owner ? b : 0.0f;
@@ -1893,6 +1898,12 @@ struct Env {
   // bounded by +-aFl, so its cost is quadratic while |Jaref| < aFl / aD and linear beyond (aFl = 0 on every other row)
   float aFl;
   float cD, cAref, cJaref, cJv;  // slot B solver state
+  // second contact-row slot (r04; per-model kernels with S::nbs == 2 only): row gl + G of the contact rows, same fields
+  static constexpr int NBS = S::is_static ? (S::nbs == 2 ? 2 : 1) : 1;
+  float c2D, c2Aref, c2Jaref, c2Jv;
+  bool c2act;
+  int vch_base2;
+  DEV bool validB2() const { return NBS == 2 && gl + G < nB(); }
   // contact row `gl`: J*v reads v from the pair's gathered copy (stage_chain) - vch_base: where that copy starts;
   // staging item `gl` (slot t of pair p, gl = p*ldc + t): vch_dof = its dof, -1 past the list's end
   int vch_base, vch_dof;
@@ -1935,6 +1946,7 @@ struct Env {
       m_diag = moff(i, i);
     }
     aD = aAref = aJaref = aJv = cD = cAref = cJaref = cJv = rJ1 = rJ2 = aFl = 0.0f;
+    c2D = c2Aref = c2Jaref = c2Jv = 0.0f; c2act = false;
     r_ma = r_fs = r_as = 0.0f;
     aact = cact = false;
     rd1 = 0; rd2 = -1;
@@ -1949,6 +1961,8 @@ struct Env {
       cEq = m.npair() > m.npc() && pr_ >= m.npc() && pr_ < m.npair() - m.nbl();
       cBl = m.nbl() > 0 && pr_ >= m.npair() - m.nbl();
     }
+    vch_base2 = eb + m.e_vch();
+    if (NBS == 2 && lane + G < 4 * m.ncon()) vch_base2 += CI(m.c_conpair() + ((lane + G) >> 2)) * m.ldc();
     {
       const int nvch = m.npair() * m.ldc();
       vch_dof = CI(m.c_vchdof() + (lane < nvch ? lane : 0));
@@ -2949,6 +2963,25 @@ struct Env {
     }
     cD = dd;
     cAref = ar;
+    if constexpr (NBS == 2) {
+      dd = 0; ar = 0;
+      if (con_on && validB2() && !(m.disableflags() & DIS_CONTACT)) {
+        const int cr = gl + G, c = cr >> 2;
+        const int pr = CI(m.c_conpair() + c), prec = m.c_pair() + pr * PAIR_S;
+        const float margin = CF(prec + 21), dist = con(0, c);
+        const float pos = dist - margin;
+        const float invw = CF(prec + 22);
+        const float jv = chain_dot(Jo + cr * ldc, vch_base2);
+        if (dist < margin) {
+          const int rec = prec + 12;
+          const float imp = row_impedance(rec, pos);
+          dd = fdiv(imp, fmaxf(invw * (1 - imp), MINVAL * imp));
+          ar = -CF(rec + 1) * jv - CF(rec) * imp * pos;
+        }
+      }
+      c2D = dd;
+      c2Aref = ar;
+    }
   }
 
   // ------------------------------------------------------------------ A9.13 solver
@@ -3027,7 +3060,8 @@ struct Env {
   // sum over the contact row's dof list of J[t] * v[dof_t]: J at Jr, v staged by stage_chain.  Every term of the row's ldc
   // slots is loaded (slots past the list hold stale - finite - floats of the slab and meet a staged zero), so all the loads are in
   // flight together and each term is one fused multiply-add.  Two partial sums.
-  DEV float chain_dot(int Jr) const {
+  DEV float chain_dot(int Jr) const { return chain_dot(Jr, vch_base); }
+  DEV float chain_dot(int Jr, int vch_base) const {
 #if AMX_PK_DOT
     if constexpr (S::is_static) {  // pairs of terms as packed multiply-adds (the loads are ds_read2_b32 pairs already)
       f2v acc = {0.0f, 0.0f};
@@ -3053,6 +3087,12 @@ struct Env {
     const float a = chain_dot(eb + m.e_J() + (valid ? gl : 0) * m.ldc());  // the caller has staged v = dof field vf (mul_M_row does)
     return valid ? a : 0.0f;
   }
+  DEV float row_dot_B2(int vf) const {
+    if constexpr (NBS != 2) return 0.0f;
+    const bool valid = validB2();
+    const float a = chain_dot(eb + m.e_J() + (valid ? gl + G : 0) * m.ldc(), vch_base2);
+    return valid ? a : 0.0f;
+  }
   // Ma = M v, Jaref = J v - aref  (v = dof field vf)
   DEV void init_context(int vf) {
     const float ma = mul_M_row(vf);
@@ -3060,6 +3100,7 @@ struct Env {
     r_ma = gl < m.nv() ? ma : 0.0f;
     aJaref = row_dot_A(vf) - aAref;
     cJaref = row_dot_B(vf) - cAref;
+    if constexpr (NBS == 2) c2Jaref = row_dot_B2(vf) - c2Aref;
     WSYNC();
   }
   DEV float constraint_cost(int vf, float *gauss_out) const {
@@ -3072,6 +3113,7 @@ struct Env {
       ca_ = aFl > 0.0f ? (fabsf(z) >= rf ? lin : quad) : ca_;
     }
     float c = ca_ + (actB ? 0.5f * cD * cJaref * cJaref : 0.0f);
+    if constexpr (NBS == 2) c += (validB2() & (c2Jaref < 0)) ? 0.5f * c2D * c2Jaref * c2Jaref : 0.0f;
     const int li = gl < m.nv() ? gl : 0;  // unconditional loads, then a select (a lazily evaluated ?: is a branch with its own wait)
     const float gv = (r_ma - r_fs) * (dof(vf, li) - r_as);
     float g = gl < m.nv() ? gv : 0.0f;
@@ -3117,6 +3159,11 @@ struct Env {
     }
     if (gl < nA()) { row(0, gl) = aact ? aD : 0.0f; row(1, gl) = f; }
     if (gl < nB()) { row(0, row0 + gl) = cact ? cD : 0.0f; row(1, row0 + gl) = fc; row(2, row0 + gl) = cJaref; }  // field 2: for the augmented J'DJ (newton_solve_fused)
+    if constexpr (NBS == 2) {
+      c2act = validB2() & (c2Jaref < 0) & (c2D > 0);
+      const float fc2 = c2act ? -c2D * c2Jaref : 0.0f;
+      if (validB2()) { row(0, row0 + gl + G) = c2act ? c2D : 0.0f; row(1, row0 + gl + G) = fc2; row(2, row0 + gl + G) = c2Jaref; }
+    }
     WSYNC();
     if (grad_in_solve() && defer) {
       float fl = 0.0f;
@@ -3183,7 +3230,12 @@ struct Env {
     if constexpr (G >= 32) {
       if (m.fusedH()) {
         const unsigned long long act = __ballot(cact);
-        const unsigned long long rows = G == 32 ? ((act | (act >> 32)) & 0xFFFFFFFFull) : act;  // contact row active in any environment of the wave
+        unsigned long long rows = G == 32 ? ((act | (act >> 32)) & 0xFFFFFFFFull) : act;  // contact row active in any environment of the wave
+        unsigned long long rows2 = 0ull;  // second slot's rows (row gl + G): bits 32 .. 63 of the one mask on 32-lane groups, a mask of their own on 64-lane groups
+        if constexpr (NBS == 2) {
+          const unsigned long long act2 = __ballot(c2act);
+          if (G == 32) rows |= ((act2 | (act2 >> 32)) & 0xFFFFFFFFull) << 32; else rows2 = act2;
+        }
         // diagonal term of the limit row on this lane's dof: D of that row if it is active (J = +-1), through the crossbar
         const float dsrc = aact ? aD : 0.0f;
         const float dlim = nA() > 0 ? dof_rows_fetch(dsrc) : 0.0f;  // J = +-1 on these rows: J' D J is D on the diagonal
@@ -3200,7 +3252,7 @@ struct Env {
         else if constexpr (grad_in_solve())
           stop = newton_solve_fused<S, S::nv, G, S::tree_H, true>(Mo, ldm, nv, rows, eb + m.e_row() + row0 * ROW_E, Jo, ldc, m.c_slot(), dofoff(D_GRAD), dofoff(D_MGRAD), dlim, gl, gb4, m_rot,
                                                                  eb + m.e_H(), pend_flim, r_ma, r_fs, dofoff(D_FCON), alive, early_out, imp_done, m.scale(),
-                                                                 m.tolerance(), pc, group_done);
+                                                                 m.tolerance(), pc, group_done, rows2);
         else if constexpr (S::is_static)
           newton_solve_fused<S, S::nv, G, S::tree_H>(Mo, ldm, nv, rows, eb + m.e_row() + row0 * ROW_E, Jo, ldc, m.c_slot(), dofoff(D_GRAD), dofoff(D_MGRAD), dlim, gl, gb4, m_rot, eb + m.e_H());
         else
@@ -3405,6 +3457,7 @@ struct Env {
       if (gl < nv) { r_ma += alpha * mv; dof(D_QACC, gl) += alpha * dof(D_SEARCH, gl); dof(D_MA, gl) = r_ma; }
       aJaref += alpha * aJv;
       cJaref += alpha * cJv;
+      if constexpr (NBS == 2) c2Jaref += alpha * c2Jv;
     }
     WSYNC();
     return improved ? -fminf(lo_delta, hi_delta) : 0.0f;
@@ -3449,10 +3502,13 @@ struct Env {
     const float mv = mul_M_row(D_SEARCH);
     aJv = row_dot_A(D_SEARCH);
     cJv = row_dot_B(D_SEARCH);
+    if constexpr (NBS == 2) c2Jv = row_dot_B2(D_SEARCH);
     const bool validA = gl < nA(), validB = gl < nB();
     // (q1 / 2, q2) of the lane's two row slots, zero for a slot without a row; the lane's share of the Gauss terms
     const float tA = validA ? aJv * aD : 0.0f, tB = validB ? cJv * cD : 0.0f;
     const f2v pA = {0.5f * tA * aJaref, 0.5f * tA * aJv}, pB = {0.5f * tB * cJaref, 0.5f * tB * cJv};
+    const float tB2 = validB2() ? c2Jv * c2D : 0.0f;  // (the second contact-row slot: zero coefficients without one)
+    const f2v pB2 = {0.5f * tB2 * c2Jaref, 0.5f * tB2 * c2Jv};
     f2v gsh;
     float sn_;
     {
@@ -3464,6 +3520,7 @@ struct Env {
     }
     // q0 of the lane's rows at alpha = 0 (the acceptance test's constant terms)
     const float a0A = validA ? 0.5f * aD * aJaref * aJaref : 0.0f, a0B = validB ? 0.5f * cD * cJaref * cJaref : 0.0f;
+    const float a0B2 = validB2() ? 0.5f * c2D * c2Jaref * c2Jaref : 0.0f;
     const f2v jv2 = {aJv, cJv}, jr2 = {aJaref, cJaref};  // both row slots' residual at a trial point in one packed multiply-add
     auto terms = [&](float alpha) {  // the lane's (q1 / 2, q2) at alpha, Gauss share included
 #if AMX_LS_PACKED_X
@@ -3473,11 +3530,18 @@ struct Env {
       const float xA = __builtin_fmaf(alpha, aJv, aJaref), xB = __builtin_fmaf(alpha, cJv, cJaref);
 #endif
       const float mA = xA < 0.0f ? 1.0f : 0.0f, mB = xB < 0.0f ? 1.0f : 0.0f;
-      return pk_fma(pA, f2v{mA, mA}, pk_fma(pB, f2v{mB, mB}, gsh));
+      f2v r = pk_fma(pA, f2v{mA, mA}, pk_fma(pB, f2v{mB, mB}, gsh));
+      if constexpr (NBS == 2) {
+        const float mB2 = __builtin_fmaf(alpha, c2Jv, c2Jaref) < 0.0f ? 1.0f : 0.0f;
+        r = pk_fma(pB2, f2v{mB2, mB2}, r);
+      }
+      return r;
     };
     auto q0at = [&](float alpha) {
       const float xA = __builtin_fmaf(alpha, aJv, aJaref), xB = __builtin_fmaf(alpha, cJv, cJaref);
-      return (xA < 0.0f ? a0A : 0.0f) + (xB < 0.0f ? a0B : 0.0f);
+      float r = (xA < 0.0f ? a0A : 0.0f) + (xB < 0.0f ? a0B : 0.0f);
+      if constexpr (NBS == 2) r += __builtin_fmaf(alpha, c2Jv, c2Jaref) < 0.0f ? a0B2 : 0.0f;
+      return r;
     };
     const float hmin = 0.5f * MINVAL;
     // hmin with a (fake) data dependence on `dep`: the assembly DPP reads that take it are ordered behind the compiler-padded read that made `dep`
@@ -3548,6 +3612,7 @@ struct Env {
       if (gl < nv) { r_ma += alpha * mv; dof(D_QACC, gl) += alpha * dof(D_SEARCH, gl); dof(D_MA, gl) = r_ma; }
       aJaref += alpha * aJv;
       cJaref += alpha * cJv;
+      if constexpr (NBS == 2) c2Jaref += alpha * c2Jv;
     }
     WSYNC();
     return improved ? -fminf(lo_delta, hi_delta) : 0.0f;
@@ -3557,7 +3622,7 @@ struct Env {
     const int nv = m.nv();
     float gauss, cost;
     bool use_warm = false;
-    float ma_warm = 0, ja_warm = 0, jc_warm = 0;
+    float ma_warm = 0, ja_warm = 0, jc_warm = 0, jc2_warm = 0;
     if (!(m.disableflags() & DIS_WARMSTART)) {
       float gw, gs;
       init_context(D_WARM);
@@ -3565,6 +3630,7 @@ struct Env {
       ma_warm = r_ma;
       ja_warm = aJaref;
       jc_warm = cJaref;
+      if constexpr (NBS == 2) jc2_warm = c2Jaref;
       WSYNC();
       init_context(D_ASMOOTH);
       const float cs = constraint_cost(D_ASMOOTH, &gs);
@@ -3577,7 +3643,7 @@ struct Env {
       if (use_warm) dof(D_MA, gl) = ma_warm;  // context of the chosen start: M*qacc and J*qacc - aref
     }
     r_ma = use_warm ? ma_warm : r_ma;
-    if (use_warm) { aJaref = ja_warm; cJaref = jc_warm; }
+    if (use_warm) { aJaref = ja_warm; cJaref = jc_warm; if constexpr (NBS == 2) c2Jaref = jc2_warm; }
     WSYNC();
     if (m.disableflags() & DIS_WARMSTART) {
       init_context(D_QACC);
@@ -3619,6 +3685,7 @@ struct Env {
       if (!wave_any(alive)) break;
       PROF(12);
       float dec;
+      static_assert(NBS == 1 || (ls_v2_ok() && grad_in_solve()), "two contact-row slots: the planner gives them to models of the fused Newton path and the second-form line search only");
       if constexpr (ls_v2_ok()) dec = linesearch_v2(alive);
       else dec = linesearch(alive);
       improvement = alive ? dec : improvement;
@@ -3982,7 +4049,8 @@ amx_forward_kernel(const DevModel m_in, int nenv, const float *__restrict__ qpos
   });
   const unsigned long long gmask = G == 64 ? ~0ull : ((1ull << (G & 63)) - 1);
   const int nactive = __popcll((__ballot(gl < env.nA() && env.aD > 0) >> (lane & ~(G - 1))) & gmask) +
-                      __popcll((__ballot(gl < env.nB() && env.cD > 0) >> (lane & ~(G - 1))) & gmask);
+                      __popcll((__ballot(gl < env.nB() && env.cD > 0) >> (lane & ~(G - 1))) & gmask) +
+                      __popcll((__ballot(env.validB2() && env.c2D > 0) >> (lane & ~(G - 1))) & gmask);
   if (!live) return;
   if (gl < nv) {
     if (o.qacc) o.qacc[(size_t)e * nv + gl] = env.dof(Env<G, S>::D_QACC, gl);

@@ -394,7 +394,7 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
   m.ncon = ncon; m.njac = (int)jac_items.size(); m.nhent = (int)hent.size();
   m.jac_one_sided = 1;
   for (int it : jac_items) if (((it >> 16) & 3) != 1) m.jac_one_sided = 0;
-  if (ncon > 16) return fail(AMX_ECAPACITY, "%d contact slots (connect / weld row groups included) exceed 16 (4 rows each, one row per lane of a 64-lane group)", ncon);
+  if (ncon > 32) return fail(AMX_ECAPACITY, "%d contact slots (connect / weld row groups included) exceed 32", ncon);
   {
     int first = -1, last = -1, cnt = 0;
     for (int p = 0; p < npc; p++) if (d->pair_fn[p] == 6) { if (first < 0) first = p; last = p; cnt++; }
@@ -475,13 +475,24 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
   const bool con_off = d->disableflags & 1;
   m.nefc = con_off ? 0 : m.neq + m.nfri + m.nlim + 4 * m.ncon;
   if (m.neq + m.nfri + m.nlim > AMX_WAVE) return fail(AMX_ECAPACITY, "%d equality + friction + limit rows exceed the lane-role capacity %d", m.neq + m.nfri + m.nlim, AMX_WAVE);
+  // A lane's contact-row slot holds one row, so a 64-lane group carries 16 contacts.  Two slots per lane (rows gl and gl + G; r04) for
+  // the models the per-model kernels' fused Newton path and second-form line search cover: contacts only (no equality, friction-loss,
+  // connect / weld or ball-limit rows), Newton, nv <= 31, ls_iterations <= 10.  Such a model has no generic kernels (amx_model_create).
+  const bool two_ok = d->solver == 2 && m.neq == 0 && m.nfri == 0 && np == npc && nbl == 0 && nv <= 31 && d->ls_iterations <= 10 && !(d->disableflags & 1);
+  m.nbs = 1;
+  if (two_ok && m.ncon > 16) m.nbs = 2;
+  if (const char *force = getenv("AMX_FORCE_NBS")) { if (atoi(force) == 2 && two_ok && m.ncon > 4) m.nbs = 2; }  // diagnostic: two slots on a narrower group
+  if (m.ncon > 16 * m.nbs)
+    return fail(AMX_ECAPACITY, "%d contact slots (connect / weld row groups included) exceed %d (4 rows each; two rows per lane of a 64-lane group only for "
+                "contact-only Newton models with nv <= 31 and ls_iterations <= 10)", m.ncon, 16 * m.nbs);
   // lanes per environment: the smallest group that holds every lane-role index set.  A lane carries two constraint rows:
   // one equality / limit row and one contact row (amx_kernels.hip, Env), so the rows ask for max(neq + nlim, 4 ncon) lanes.
   {
-    const int need = std::max({nb, nj, nv, np, m.ngc, con_off ? 0 : m.neq + m.nfri + m.nlim, con_off ? 0 : 4 * m.ncon, 1});
+    const int need = std::max({nb, nj, nv, np, m.ngc, con_off ? 0 : m.neq + m.nfri + m.nlim, con_off ? 0 : (4 * m.ncon + m.nbs - 1) / m.nbs, 1});
     m.G = need <= 16 ? 16 : (need <= 32 ? 32 : 64);
     if (const char *force = getenv("AMX_FORCE_G")) { int g = atoi(force); if ((g == 16 || g == 32 || g == 64) && g >= m.G) m.G = g; }
     if (plan_force_lanes >= m.G && (plan_force_lanes == 32 || plan_force_lanes == 64)) m.G = plan_force_lanes;  // the wide plan of a model (amx_model_create)
+    if (m.nbs == 2 && m.G < 32) m.G = 32;  // the two-slot form lives in the fused Newton path (32- and 64-lane groups)
   }
   // lists
   auto add_ints = [&](const std::vector<int> &v) { int o = im.reserve((int)v.size()); for (size_t k = 0; k < v.size(); k++) im.seti(o + (int)k, v[k]); return o; };

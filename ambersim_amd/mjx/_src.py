@@ -61,8 +61,15 @@ class _Handle:
         self._ptr = C.c_void_p()
         self.refuse = None  # set by Model: why this handle must not be stepped (see Model.__init__)
         self.L = _lib.lib()
-        _lib.check(self.L.amx_model_create(C.byref(self.desc), device_index, C.byref(self._ptr)), self.L)
-        if specialise and not self.query("specialised"):
+        needs_build = False
+        try:
+            _lib.check(self.L.amx_model_create(C.byref(self.desc), device_index, C.byref(self._ptr)), self.L)
+        except NotImplementedError as e:
+            # a model only per-model kernels can run (two contact rows per lane): no generic handle exists; build unless told not to
+            if "needs per-model kernels" not in str(e) or specialise is False:
+                raise
+            needs_build = True
+        if needs_build or (specialise and not self.query("specialised")):
             # specialise: True = the caller asked for a per-model build (errors propagate); "auto" = the default: build one when hipcc
             # is on this machine, say so in one line, and run the generic kernels (about half the throughput) when it is not
             import logging
@@ -79,10 +86,11 @@ class _Handle:
                 L2 = _lib.load(build_specialised_library(mj))
                 ptr2 = C.c_void_p()
                 _lib.check(L2.amx_model_create(C.byref(self.desc), device_index, C.byref(ptr2)), L2)
-                self.L.amx_model_destroy(self._ptr)
+                if self._ptr:
+                    self.L.amx_model_destroy(self._ptr)
                 self.L, self._ptr = L2, ptr2
             except Exception as e:
-                if specialise != "auto":
+                if specialise != "auto" or needs_build:
                     raise
                 log.warning("per-model kernels unavailable (%s: %s): this model runs on the generic kernels, at about half the throughput of a "
                             "per-model build", type(e).__name__, str(e).splitlines()[0][:160] if str(e) else "")

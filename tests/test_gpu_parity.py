@@ -851,6 +851,129 @@ def test_model_replace_parameter_arrays(cases, dev):
         model.replace(jnt_type=mj.jnt_type)
 
 
+def _boxes_model(n):
+    """n free boxes over a plane (4 contact slots each); the boxes collide with the plane only (contype / conaffinity)."""
+    bodies = "".join(f'<body pos="{0.5 * k} 0 0.2"><freejoint/><geom type="box" size="0.1 0.08 0.06" mass="1" contype="0" conaffinity="1"/></body>' for k in range(n))
+    return MjModelCls().from_xml_string(f"""<mujoco><option timestep="0.002" iterations="3" ls_iterations="5"/><worldbody><geom type="plane" size="9 9 .1" contype="1" conaffinity="0"/>
+      {bodies}</worldbody></mujoco>""")
+
+
+@pytest.mark.parametrize("nbox,force", [(5, False), (3, True)])
+def test_two_contact_rows_per_lane(dev, nbox, force):
+    """More than 16 contact slots (r04): five free boxes on a plane are 20 contacts, 80 pyramid rows - a lane of the 64-lane group carries
+    rows gl and gl + 64.  Per-model kernels only (the generic ones refuse, saying so).  Second case: the same mechanism forced onto a 32-lane
+    group (three boxes, rows gl and gl + 32; AMX_FORCE_NBS=2), whose matrix-core row mask is built differently.  Boxes start tilted and
+    partly in the floor, so that rows of both slots are active: one step within 1e-5, five within 5e-5 of the fp64 oracle (or the fp32
+    oracle's own distance), and the boxes come to rest carrying their weight."""
+    from ambersim_amd import mjx
+    from oracle.oracle import Oracle
+    mj = _boxes_model(nbox)
+    assert mj.ncon == 4 * nbox
+    if force:
+        os.environ["AMX_FORCE_NBS"] = "2"
+    try:
+        if not force:
+            with pytest.raises(NotImplementedError, match="per-model kernels"):
+                mjx.put_model(mj, dev, specialise=False)
+        model = mjx.put_model(mj, dev, specialise=True)
+        assert model._h.query("specialised") == 1 and model._h.query("lanes_per_env") == (32 if force else 64)
+        rng = np.random.default_rng(31 + nbox)
+        nenv = 16
+        q = np.tile(mj.qpos0, (nenv, 1))
+        for k in range(nenv):
+            for b in range(nbox):
+                quat = np.array([1.0, 0, 0, 0]) + 0.25 * rng.uniform(-1, 1, 4)
+                q[k, 7 * b + 3: 7 * b + 7] = quat / np.linalg.norm(quat)
+                q[k, 7 * b + 2] = rng.uniform(0.05, 0.12)
+        x0 = np.concatenate([q, 0.2 * rng.standard_normal((nenv, mj.nv))], axis=1).astype(np.float32)
+        us = np.zeros((nenv, 5, 0), dtype=np.float32)
+        o = Oracle(mj, np.float64)
+        act2 = 0
+        for k in range(nenv):
+            o.set_state(x0[k, :mj.nq], x0[k, mj.nq:], np.zeros(0)); o.forward()
+            act2 += int((o.get("con_dist")[(64 if not force else 32) // 4:] < 0).sum())  # contacts whose rows sit in the second slot
+        assert act2 >= nenv // 2, act2
+        xs = gpu_rollout(model, x0, us)
+        ref = o.rollout(x0, us)
+        ref32 = Oracle(mj, np.float32).rollout(x0, us).astype(np.float64)
+        def per_env(a, b, t):
+            return np.abs(a[:, t] - b[:, t]).max(axis=1) / np.maximum(1.0, np.abs(b[:, t]).max(axis=1))
+        for t, tol in ((1, TOL), (5, 5e-5)):
+            e64, e32, f = per_env(xs, ref, t), per_env(xs, ref32, t), per_env(ref32, ref, t)
+            assert ((e64 <= np.maximum(tol, 3 * f)) | (e32 <= tol)).all(), (t, e64.max(), e32.max(), f.max())
+        # at rest: every box lies on the floor and the contacts carry it
+        xr = mjx.rollout(model, torch.tensor(np.concatenate([mj.qpos0, np.zeros(mj.nv)]).astype(np.float32)), torch.zeros((1, 1500, 0))).cpu().numpy()[0]
+        z = xr[-1, 2:7 * nbox:7]
+        assert np.isfinite(xr).all() and np.allclose(z, 0.06, atol=2e-3) and np.abs(xr[-1, mj.nq:]).max() < 5e-2, (z, np.abs(xr[-1, mj.nq:]).max())
+    finally:
+        os.environ.pop("AMX_FORCE_NBS", None)
+
+
+def test_biped_with_twenty_four_contact_slots(dev):
+    """VERDICT r03 item 6's capacity case: the falls-and-rests biped (16 contact slots) with eight more resting spheres on its arms and legs -
+    24 slots, 120 constraint rows, two contact rows per lane of a 64-lane group, per-model kernels.  One step within 1e-5 of the fp64 oracle
+    from random poses low over the floor; dropped from standing height under random torques the robots end lying on the floor."""
+    import re
+    from ambersim_amd import mjx
+    from ambersim_amd.mjcf import MjModel
+    from bench import BIPED_REST, make_inputs
+    from oracle.oracle import Oracle
+    import ambersim_amd
+    path = os.path.join(ambersim_amd.ROOT, BIPED_REST)
+    xml = open(path).read()
+    adds = {"l_upper_arm": 'size="0.05" pos="0 0 -0.14"', "r_upper_arm": 'size="0.05" pos="0 0 -0.14"', "l_forearm": 'size="0.05"', "r_forearm": 'size="0.05"',
+            "l_thigh": 'size="0.07" pos="0 0 -0.2"', "r_thigh": 'size="0.07" pos="0 0 -0.2"', "l_shin": 'size="0.05" pos="0 0 -0.2"', "r_shin": 'size="0.05" pos="0 0 -0.2"'}
+    for body, g in adds.items():
+        mt = re.search(rf'<body name="{body}"[^>]*>', xml)
+        xml = xml[:mt.end()] + f'<geom name="{body}_more" class="rest" {g}/>' + xml[mt.end():]
+    from bench import solver_variant
+    # Newton 10 / 10 instead of the file's 3 / 5: the parity part starts the robots IN the floor (every foot corner at once), and on such an
+    # impact three iterations leave the solve unconverged - the distance between two fp32 orderings of an unconverged iterate is 3e-5 ..
+    # 8e-5 on the shipped one-slot kernels too, and 5e-7 once the solve converges (tools/dbg/standing_impact.py)
+    mj = solver_variant(MjModel.from_xml_string(xml, model_dir=os.path.dirname(path)), 10, 10)
+    assert (mj.nv, mj.ncon) == (30, 24)
+    model = mjx.put_model(mj, dev, specialise=True)
+    assert model._h.query("lanes_per_env") == 64 and model.nefc_max == 120
+    rng = np.random.default_rng(77)
+    nenv = 32
+    q = np.tile(mj.qpos0, (nenv, 1))
+    for k in range(nenv):
+        quat = rng.standard_normal(4)
+        q[k, 3:7] = quat / np.linalg.norm(quat)
+        q[k, 2] = 2.0
+        q[k, 7:] += 0.3 * rng.standard_normal(mj.nq - 7)
+    o = Oracle(mj, np.float64)
+    for k in range(nenv):  # lowered until the deepest sphere / foot corner is 0.01 .. 0.03 in the floor: lying in some orientation
+        o.set_state(q[k], np.zeros(mj.nv), np.zeros(mj.nu)); o.forward()
+        q[k, 2] -= o.get("con_dist").min() + rng.uniform(0.01, 0.03)
+    x0 = np.concatenate([q, 0.2 * rng.standard_normal((nenv, mj.nv))], axis=1).astype(np.float32)
+    us = rng.uniform(-1, 1, (nenv, 3, mj.nu)).astype(np.float32) * np.abs(mj.actuator_ctrlrange[:, 1]).astype(np.float32)
+    touching = 0
+    for k in range(nenv):
+        o.set_state(x0[k, :mj.nq], x0[k, mj.nq:], us[k, 0]); o.forward()
+        touching += int((o.get("con_dist")[16:] < 0).sum())  # contacts whose rows sit in the second slot
+    # the feet are the last pairs: their contacts 16 .. 23 are the second slot's rows.  Lying robots touch with whatever is lowest; the
+    # standing start of the bench inputs (below) has all eight foot corners in the floor
+    xb, ub = make_inputs(mj, 32, 3, 1, 2, torch.device("cpu"))
+    xb[:, 2] -= 0.025  # (the keyframe holds the soles 0.018 above the floor)
+    x0, us = np.concatenate([x0, xb.numpy()]), np.concatenate([us, ub.numpy()])
+    for k in range(nenv, 2 * nenv):
+        o.set_state(x0[k, :mj.nq], x0[k, mj.nq:], us[k, 0]); o.forward()
+        touching += int((o.get("con_dist")[16:] < 0).sum())
+    assert touching >= 6 * nenv, touching
+    xs = gpu_rollout(model, x0, us)
+    ref = o.rollout(x0, us)
+    ref32 = Oracle(mj, np.float32).rollout(x0, us).astype(np.float64)
+    e64 = np.abs(xs[:, 1] - ref[:, 1]).max(axis=1) / np.maximum(1.0, np.abs(ref[:, 1]).max(axis=1))
+    e32 = np.abs(xs[:, 1] - ref32[:, 1]).max(axis=1) / np.maximum(1.0, np.abs(ref32[:, 1]).max(axis=1))
+    f = np.abs(ref32[:, 1] - ref[:, 1]).max(axis=1) / np.maximum(1.0, np.abs(ref[:, 1]).max(axis=1))
+    print(f"biped, 24 contact slots: {touching} second-slot contacts touching over {2 * nenv} envs, one-step error {e64.max():.2e} (fp32 oracle's own {f.max():.2e})")
+    assert ((e64 <= np.maximum(TOL, 3 * f)) | (e32 <= TOL)).all(), (e64.max(), e32.max(), f.max())
+    x0f, usf = make_inputs(mj, 256, 1000, 1, 2, dev)
+    z = mjx.rollout(model, x0f, usf)[:, :, 2]
+    assert bool(torch.isfinite(z).all()) and float(z.min()) > -0.05 and float(z[:, -1].median()) < 0.25, (float(z.min()), float(z[:, -1].median()))
+
+
 def _two_arm_model():
     """A floating torso with two six-hinge arms ending in sphere hands: the hand-hand pair couples the base and both arms, 18 dofs -
     beyond r03's 16-entry dof lists per contact row (r04: 31)."""
