@@ -3074,10 +3074,19 @@ struct Env {
 #endif
     float a0 = 0, a1 = 0;
 #pragma unroll
-    for (int t = 0; t < 32; ++t) {  // (ldc <= 31: amx_plan.h)
+    for (int t = 0; t < 16; ++t) {
       if (t < m.ldc()) {  // static in the specialised kernels, wave-uniform otherwise
         const float jt = lds[Jr + t], vt = lds[vch_base + t];
         if (t & 1) a1 = __builtin_fmaf(jt, vt, a1); else a0 = __builtin_fmaf(jt, vt, a0);
+      }
+    }
+    if (m.ldc() > 16) {  // dof lists of 17 .. 31 entries (r04: a contact between two limbs of a floating-base robot): one test for everybody else
+#pragma unroll
+      for (int t = 16; t < 32; ++t) {
+        if (t < m.ldc()) {
+          const float jt = lds[Jr + t], vt = lds[vch_base + t];
+          if (t & 1) a1 = __builtin_fmaf(jt, vt, a1); else a0 = __builtin_fmaf(jt, vt, a0);
+        }
       }
     }
     return a0 + a1;
