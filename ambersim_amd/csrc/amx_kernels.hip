@@ -918,6 +918,9 @@ template <class S, int G, int J, bool TREE, bool BCOL> DEV void sym_pivot(float 
   // the schedule leaves open between the lane swap and this read - the assembly form carried a fixed s_nop 1 per pivot, 8 cycles
   // on every pivot's dependent chain (biped +1 %, C4 +1.7 %).  The assembly multiply-adds below still depend on it through nf.
   rinv = __builtin_amdgcn_rcpf(bcast_row<J>(p));
+#ifdef AMX_EXPERIMENT_PIVOT_REFINE  // accuracy experiment: one Newton step on the pivot's reciprocal (three more vector instructions per pivot)
+  { const float pv = bcast_row<J>(p); rinv = rinv * __builtin_fmaf(-pv, rinv, 2.0f); }
+#endif
 #else
   asm("s_nop 1\n\tv_rcp_f32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(rinv) : "v"(J < 16 ? p.r0 : p.r1), "n"(J & 15));
 #endif
