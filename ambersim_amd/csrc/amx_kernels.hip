@@ -861,6 +861,15 @@ template <int K> DEV float bcast_row(const RowPair &p) { return K < 16 ? dpp_f<0
 template <int K> DEV void fmac_bcast(float &acc, const RowPair &p, float nf) {
   asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(K < 16 ? p.r0 : p.r1), "v"(nf), "n"(K & 15));
 }
+#ifdef AMX_EXPERIMENT_TRUE_ROW  // accuracy experiment (slow): the pivot row's entries from the pivot's own lane (through the crossbar), not from the symmetric column
+template <class S, int G, int K, int J> struct SymAncT {
+  static DEV void run(float (&a)[S::nv + 1], float nf) {
+    a[K] = __builtin_fmaf(nf, gbcast_s<G, J>(a[K]), a[K]);
+    SymAncT<S, G, S::dof_parent[K], J>::run(a, nf);
+  }
+};
+template <class S, int G, int J> struct SymAncT<S, G, -1, J> { static DEV void run(float (&)[S::nv + 1], float) {} };
+#endif
 template <class S, int G, int K> struct SymAnc {  // K walks the pivot's ancestor chain
   static DEV void run(float (&a)[S::nv + 1], const RowPair &p, float nf) {
     fmac_bcast<K>(a[K], p, nf);
@@ -953,6 +962,13 @@ template <class S, int G, int J, bool TREE, bool BCOL> DEV void sym_pivot(float 
   asm volatile("s_lshl_b64 %0, %2, %3" : "=s"(pm) : "0"(pm), "s"(pm0), "n"(J) : "scc");
   nf = sel_zero(pm, nf);           // the pivot row itself is left alone
   diag = sel_mask(pm, piv, diag);  // ... and its diagonal is final: kept for the last division
+#endif
+#ifdef AMX_EXPERIMENT_TRUE_ROW
+  if constexpr (TREE) {
+    a[N] = __builtin_fmaf(nf, gbcast_s<G, J>(a[N]), a[N]);
+    SymAncT<S, G, S::dof_parent[J], J>::run(a, nf);
+    return;
+  }
 #endif
   if constexpr (BCOL) {
     fmac_bcast<N>(a[N], p, nf);
