@@ -945,6 +945,21 @@ template <class S, int G, int J, bool TREE, bool BCOL> DEV void sym_pivot(float 
 #endif
 #if !AMX_PIVOT_CLAMP
   float nf = -c * rinv;
+#ifdef AMX_EXPERIMENT_SYM_EXACT
+  // accuracy experiment: bitwise-symmetric updates.  The column is scaled by 1 / sqrt(pivot) once (both row copies), and an update is
+  // the product of two scaled entries: s_i s_K on lane i, s_K s_i on lane K - the same bits, so the reduced matrix stays as symmetric
+  // as it started and reading the pivot row from the column's lanes loses nothing.  Two multiplies more per pivot.
+  RowPair ps;
+  {
+    const float rsq = __builtin_amdgcn_rsqf(bcast_row<J>(p));
+    ps.r0 = p.r0 * rsq; ps.r1 = p.r1 * rsq;
+    nf = -c * rsq;
+    asm volatile("s_nop 1" : "+v"(ps.r0), "+v"(ps.r1), "+v"(nf));  // the assembly DPP reads below: two wait states after these writes
+  }
+#define AMX_SYM_P ps
+#else
+#define AMX_SYM_P p
+#endif
 #else
   float nf = -c * __builtin_amdgcn_rcpf(piv);
 #endif
@@ -971,13 +986,14 @@ template <class S, int G, int J, bool TREE, bool BCOL> DEV void sym_pivot(float 
   }
 #endif
   if constexpr (BCOL) {
-    fmac_bcast<N>(a[N], p, nf);
+    fmac_bcast<N>(a[N], AMX_SYM_P, nf);
   } else {
     const RowPair pb = row_pair<G>(a[N]);
     a[N] = __builtin_fmaf(nf, bcast_row<J>(pb), a[N]);
   }
-  if constexpr (TREE) SymAnc<S, G, S::dof_parent[J]>::run(a, p, nf);
-  else SymRest<S, G, J + 1>::run(a, p, nf);
+  if constexpr (TREE) SymAnc<S, G, S::dof_parent[J]>::run(a, AMX_SYM_P, nf);
+  else SymRest<S, G, J + 1>::run(a, AMX_SYM_P, nf);
+#undef AMX_SYM_P
 }
 #ifndef AMX_ELIM_ORDER
 #define AMX_ELIM_ORDER 1  // 0: pivots from the last dof to the first; 1: by rounds of leaves (A/B switch)
