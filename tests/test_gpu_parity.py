@@ -854,7 +854,8 @@ def test_model_replace_parameter_arrays(cases, dev):
 def _boxes_model(n):
     """n free boxes over a plane (4 contact slots each); the boxes collide with the plane only (contype / conaffinity)."""
     bodies = "".join(f'<body pos="{0.5 * k} 0 0.2"><freejoint/><geom type="box" size="0.1 0.08 0.06" mass="1" contype="0" conaffinity="1"/></body>' for k in range(n))
-    return MjModelCls().from_xml_string(f"""<mujoco><option timestep="0.002" iterations="3" ls_iterations="5"/><worldbody><geom type="plane" size="9 9 .1" contype="1" conaffinity="0"/>
+    from ambersim_amd.mjcf import MjModel
+    return MjModel.from_xml_string(f"""<mujoco><option timestep="0.002" iterations="3" ls_iterations="5"/><worldbody><geom type="plane" size="9 9 .1" contype="1" conaffinity="0"/>
       {bodies}</worldbody></mujoco>""")
 
 
@@ -987,14 +988,10 @@ def _two_arm_model():
                     '<inertial pos="0.06 0 0" mass="0.3" diaginertia="0.001 0.002 0.002"/>')
         return out + f'<geom name="hand_{side}" type="sphere" size="0.06" pos="0.1 0 0"/>' + "</body>" * 6
     motors = "".join(f'<motor joint="j{s}{k}" gear="2" ctrlrange="-1 1"/>' for s in "lr" for k in range(6))
-    return MjModelCls().from_xml_string(f"""<mujoco><option timestep="0.002" iterations="3" ls_iterations="5"/><worldbody><geom type="plane" size="5 5 .1"/>
+    from ambersim_amd.mjcf import MjModel
+    return MjModel.from_xml_string(f"""<mujoco><option timestep="0.002" iterations="3" ls_iterations="5"/><worldbody><geom type="plane" size="5 5 .1"/>
       <body name="torso" pos="0 0 1"><freejoint/><inertial pos="0 0 0" mass="5" diaginertia="0.1 0.1 0.1"/>{arm("l")}{arm("r")}</body></worldbody>
       <actuator>{motors}</actuator></mujoco>""")
-
-
-def MjModelCls():
-    from ambersim_amd.mjcf import MjModel
-    return MjModel
 
 
 @pytest.mark.parametrize("specialise", [False, True])
