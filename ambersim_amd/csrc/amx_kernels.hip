@@ -861,7 +861,13 @@ template <int K> DEV float bcast_row(const RowPair &p) { return K < 16 ? dpp_f<0
 template <int K> DEV void fmac_bcast(float &acc, const RowPair &p, float nf) {
   asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(K < 16 ? p.r0 : p.r1), "v"(nf), "n"(K & 15));
 }
-#ifdef AMX_EXPERIMENT_TRUE_ROW  // accuracy experiment (slow): the pivot row's entries from the pivot's own lane (through the crossbar), not from the symmetric column
+#ifndef AMX_TRUE_ROW_ELIM
+#define AMX_TRUE_ROW_ELIM 0  // 1: the pivot row's entries come from the pivot's own lane (through the crossbar), not from the symmetric column's lanes.
+#endif                       // The reduced matrix is symmetric only up to rounding and the substitution multiplies that asymmetry by the multipliers: with the
+                             // solver unconverged on a hard impact (every foot corner at once, Newton 3 / 5) the product form sits 1e-5 .. 6e-5 from fp64 after one
+                             // step, this form 3e-6 .. 7e-6 like the CPU oracle (profiles/r04_standing_impact.txt) - at 0.85 of the throughput.  Per-model builds
+                             // take it with AMX_ACCURATE_ELIM=1 (ambersim_amd/_spec.py).
+#if AMX_TRUE_ROW_ELIM
 template <class S, int G, int K, int J> struct SymAncT {
   static DEV void run(float (&a)[S::nv + 1], float nf) {
     a[K] = __builtin_fmaf(nf, gbcast_s<G, J>(a[K]), a[K]);
@@ -978,7 +984,7 @@ template <class S, int G, int J, bool TREE, bool BCOL> DEV void sym_pivot(float 
   nf = sel_zero(pm, nf);           // the pivot row itself is left alone
   diag = sel_mask(pm, piv, diag);  // ... and its diagonal is final: kept for the last division
 #endif
-#ifdef AMX_EXPERIMENT_TRUE_ROW
+#if AMX_TRUE_ROW_ELIM
   if constexpr (TREE) {
     a[N] = __builtin_fmaf(nf, gbcast_s<G, J>(a[N]), a[N]);
     SymAncT<S, G, S::dof_parent[J], J>::run(a, nf);

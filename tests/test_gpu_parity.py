@@ -851,6 +851,35 @@ def test_model_replace_parameter_arrays(cases, dev):
         model.replace(jnt_type=mj.jnt_type)
 
 
+def test_accurate_elimination_build_on_a_hard_impact(dev, monkeypatch):
+    """AMX_ACCURATE_ELIM=1: per-model kernels whose eliminations read the pivot row from the pivot's own lane.  The scenario where it matters
+    (profiles/r04_standing_impact.txt): the standing biped started with every foot corner already in the floor, solver cut off at the
+    file's Newton 3 / 5.  The accurate build stays within 1e-5 of the fp64 oracle after one step (the CPU fp32 oracle: 6e-6); the fast
+    build is measured beside it and must at least stay within 1e-4."""
+    from ambersim_amd import mjx
+    from ambersim_amd.utils.io_utils import load_mj_model_from_file
+    from bench import BIPED_STAND, make_inputs
+    from oracle.oracle import Oracle
+    mj = load_mj_model_from_file(BIPED_STAND)
+    fast = mjx.put_model(mj, dev, specialise=False)
+    monkeypatch.setenv("AMX_ACCURATE_ELIM", "1")
+    accurate = mjx.put_model(mj, dev, specialise=True)
+    assert accurate._h.L is not fast._h.L and accurate._h.query("specialised") == 1
+    worst = {"fast": 0.0, "accurate": 0.0, "cpu fp32": 0.0}
+    for low in (0.019, 0.021, 0.025):
+        xb, ub = make_inputs(mj, 32, 1, 1, 2, torch.device("cpu"))
+        xb[:, 2] -= low
+        x0, us = xb.numpy(), ub.numpy()
+        ref = Oracle(mj, np.float64).rollout(x0, us)
+        ref32 = Oracle(mj, np.float32).rollout(x0, us).astype(np.float64)
+        err = lambda a: float((np.abs(a[:, 1] - ref[:, 1]).max(axis=1) / np.maximum(1.0, np.abs(ref[:, 1]).max(axis=1))).max())
+        worst["fast"] = max(worst["fast"], err(gpu_rollout(fast, x0, us)))
+        worst["accurate"] = max(worst["accurate"], err(gpu_rollout(accurate, x0, us)))
+        worst["cpu fp32"] = max(worst["cpu fp32"], err(ref32))
+    print("hard impact, one step, worst of three depths:", {k: f"{v:.2e}" for k, v in worst.items()})
+    assert worst["accurate"] < TOL and worst["fast"] < 1e-4, worst
+
+
 def _boxes_model(n):
     """n free boxes over a plane (4 contact slots each); the boxes collide with the plane only (contype / conaffinity)."""
     bodies = "".join(f'<body pos="{0.5 * k} 0 0.2"><freejoint/><geom type="box" size="0.1 0.08 0.06" mass="1" contype="0" conaffinity="1"/></body>' for k in range(n))
