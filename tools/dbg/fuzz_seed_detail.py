@@ -7,8 +7,9 @@ from fuzz_models import *
 from oracle.oracle import Oracle
 dev=torch.device("cuda",0)
 np.set_printoptions(linewidth=200, precision=3)
-for seed in [int(s) for s in sys.argv[1:]]:
-    mj = random_model(seed, True)
+convex = "--plain" not in sys.argv
+for seed in [int(s) for s in sys.argv[1:] if not s.startswith("--")]:
+    mj = random_model(seed, convex)
     x0, us = random_inputs(mj, seed, 8, 5); x0=x0.astype(np.float32); us=us.astype(np.float32)
     ref = Oracle(mj, np.float64).rollout(x0, us); ref32 = Oracle(mj, np.float32).rollout(x0, us).astype(np.float64)
     ref32k = Oracle(mj, np.float32, ls_rule=3).rollout(x0, us).astype(np.float64)
