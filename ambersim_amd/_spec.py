@@ -149,11 +149,8 @@ def _extra_flags():
     """AMX_SPEC_FORCE_FALLBACK=1: build with the crash-fallback flags from the start (tests/test_gpu_parity.py runs that build
     against the oracle, so the instruction mix a compiler crash would silently switch to is a tested one)."""
     flags = list(CRASH_FALLBACK_FLAGS) if os.environ.get("AMX_SPEC_FORCE_FALLBACK", "0") not in ("", "0") else []
-    # AMX_ACCURATE_ELIM=1: the eliminations read the pivot row from the pivot's own lane instead of the symmetric column's lanes - the form
-    # that stays at the CPU oracle's distance from fp64 when the solver is cut off unconverged on a hard impact, at 0.85 of the throughput
-    # (csrc/amx_kernels.hip, AMX_TRUE_ROW_ELIM; profiles/r04_standing_impact.txt)
-    if os.environ.get("AMX_ACCURATE_ELIM", "0") not in ("", "0"):
-        flags.append("-DAMX_TRUE_ROW_ELIM=1")
+    # (r04's AMX_ACCURATE_ELIM=1 - true pivot rows through the crossbar - is retired: since r05 the default eliminations are bitwise
+    #  symmetric and ARE the true-row eliminations, csrc/amx_kernels.hip sym_pivot; -DAMX_TRUE_ROW_ELIM=1 remains as an A/B switch of tools/devbuild.sh)
     return flags
 
 

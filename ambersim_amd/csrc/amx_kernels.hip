@@ -61,6 +61,13 @@
 #ifndef AMX_NO_SYM_ELIM
 #define AMX_NO_SYM_ELIM 0  // 1: the static eliminations broadcast pivot rows through the crossbar as before (A/B switch)
 #endif
+#ifndef AMX_SQRT_D
+#define AMX_SQRT_D 1  // 0: the matrix cores' operands are (D J, J) as before r05 (A/B switch).  1: both operands are sqrt(D) J - every product
+#endif                //    (sqrt(D) J_i)(sqrt(D) J_k) is commutative, so J'DJ comes out bitwise symmetric; with the symmetric updates of sym_pivot
+                      //    (AMX_SYM_EXACT) the column the elimination reads in place of the pivot row IS that row, bit for bit.
+#ifndef AMX_SYM_EXACT
+#define AMX_SYM_EXACT 1  // 0: pivot updates as (c_i / pivot) c_K (r02 - r04: symmetric only up to rounding), A/B switch
+#endif
 #define MINVAL 1e-15f
 
 enum { JFREE = 0, JBALL = 1, JSLIDE = 2, JHINGE = 3 };
@@ -634,7 +641,7 @@ DEV void jtdj_rows_mfma(unsigned long long crows, int row_base, int J_base, int 
       for (int r = 0; r < 4; ++r) {
         o.d[r] = lds[Dr + r * ROW_E]; o.jv[r] = lds[Jr + r * ldc];
         o.g[r] = 0.0f;
-        if (COL31) o.g[r] = lds[Dr + r * ROW_E + 1];
+        if (COL31) o.g[r] = AMX_SQRT_D ? -lds[Dr + r * ROW_E + 2] : lds[Dr + r * ROW_E + 1];  // sqrt form: the force f = -D Jaref as (-Jaref sqrt D) sqrt D
         if (AUGN >= 0) o.g[r] = lds[Dr + r * ROW_E + 2];
       }
       // a pyramid row that is inactive in both environments has D = 0 and f = 0 everywhere: its instruction (64 cycles of the
@@ -646,8 +653,14 @@ DEV void jtdj_rows_mfma(unsigned long long crows, int row_base, int J_base, int 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float v0 = o.has ? o.jv[r] : 0.0f;
+#if AMX_SQRT_D
+        // o.d is sqrt(D) (constraint_force_and_grad publishes it): A = B = sqrt(D) J - the same bits on both sides of every product
+        const float v = o.d[r] * ((AUGN >= 0 && j == AUGN) ? o.g[r] : ((COL31 && j == 31) ? 0.0f : v0));
+        const float aop = (COL31 && j == 31) ? o.d[r] * o.g[r] : v;
+#else
         const float v = (AUGN >= 0 && j == AUGN) ? o.g[r] : v0;
         const float aop = (COL31 && j == 31) ? o.g[r] : o.d[r] * v;
+#endif
         if (AUGN < 0 && decltype(first)::value && r == 0) { const v32f Z = {}; C = __builtin_amdgcn_mfma_f32_32x32x1f32(aop, v, Z, 0, 0, 0); }
         else if (AMX_MFMA_ALL_ROWS || ((o.rbits >> r) & 1u)) {
           C = __builtin_amdgcn_mfma_f32_32x32x1f32(aop, v, C, 0, 0, 0);
@@ -712,13 +725,18 @@ DEV void jtdj_rows_mfma(unsigned long long crows, int row_base, int J_base, int 
       for (int s2 = 0; s2 < 2; ++s2) {
         d[s2] = lds[Dr + 2 * s2 * ROW_E]; jv[s2] = lds[Jr + 2 * s2 * ldc];
         g[s2] = 0.0f;
-        if (COL31) g[s2] = lds[Dr + 2 * s2 * ROW_E + 1];
+        if (COL31) g[s2] = AMX_SQRT_D ? -lds[Dr + 2 * s2 * ROW_E + 2] : lds[Dr + 2 * s2 * ROW_E + 1];
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const float v = has ? jv[s2] : 0.0f;
         // COL31 (r04, as in the two-block form): lane 31 of either K slice feeds the row's force as its A entry - row 31 of the product is J'f
+#if AMX_SQRT_D
+        const float v = d[s2] * (has ? jv[s2] : 0.0f);
+        const float aop = (COL31 && j == 31) ? d[s2] * g[s2] : v;
+#else
+        const float v = has ? jv[s2] : 0.0f;
         const float aop = (COL31 && j == 31) ? g[s2] : d[s2] * v;
+#endif
         C = __builtin_amdgcn_mfma_f32_32x32x2f32(aop, v, C, 0, 0, 0);
       }
     }
@@ -868,6 +886,8 @@ template <int K> DEV void fmac_bcast(float &acc, const RowPair &p, float nf) {
                              // step, this form 3e-6 .. 7e-6 like the CPU oracle (profiles/r04_standing_impact.txt) - at 0.85 of the throughput.  Per-model builds
                              // take it with AMX_ACCURATE_ELIM=1 (ambersim_amd/_spec.py).
 #if AMX_TRUE_ROW_ELIM
+#undef AMX_SYM_EXACT
+#define AMX_SYM_EXACT 0  // the true-row form multiplies the pivot row by c_i / pivot
 template <class S, int G, int K, int J> struct SymAncT {
   static DEV void run(float (&a)[S::nv + 1], float nf) {
     a[K] = __builtin_fmaf(nf, gbcast_s<G, J>(a[K]), a[K]);
@@ -951,25 +971,45 @@ template <class S, int G, int J, bool TREE, bool BCOL> DEV void sym_pivot(float 
 #endif
 #if !AMX_PIVOT_CLAMP
   float nf = -c * rinv;
-#ifdef AMX_EXPERIMENT_SYM_EXACT
-  // accuracy experiment: bitwise-symmetric updates.  The column is scaled by 1 / sqrt(pivot) once (both row copies), and an update is
-  // the product of two scaled entries: s_i s_K on lane i, s_K s_i on lane K - the same bits, so the reduced matrix stays as symmetric
-  // as it started and reading the pivot row from the column's lanes loses nothing.  Two multiplies more per pivot.
+#if AMX_SYM_EXACT
+  // Bitwise-symmetric updates (r05).  The column is scaled by 1 / sqrt(pivot) once (both row copies) and an update is the product of two
+  // scaled entries: s_i s_K on lane i, s_K s_i on lane K - the same bits, so the reduced matrix stays exactly as symmetric as it started
+  // (M is stored symmetric, J'DJ is formed from sqrt(D) J on both operands: AMX_SQRT_D) and the column's lanes hold the pivot ROW bit for
+  // bit: the elimination IS the true-row elimination (profiles/r04_standing_impact.txt: 5.7e-5 -> 5e-6 on the hard impact) without a
+  // crossbar operation.  Two multiplies more per pivot than (c_i / pivot) c_K.
+#ifdef AMX_EXPERIMENT_RSQ_REFINE  // accuracy experiment: one Newton step on 1 / sqrt(pivot)
+  float rsq = __builtin_amdgcn_rsqf(bcast_row<J>(p));
+  { const float pv = bcast_row<J>(p); rsq = rsq * __builtin_fmaf(-0.5f * pv * rsq, rsq, 1.5f); }
+#else
+  const float rsq = __builtin_amdgcn_rsqf(bcast_row<J>(p));
+#endif
+  nf = -c * rsq;  // compiler-visible: it pads the wait state a transcendental's result needs before its first use
   RowPair ps;
-  {
-    const float rsq = __builtin_amdgcn_rsqf(bcast_row<J>(p));
-    ps.r0 = p.r0 * rsq; ps.r1 = p.r1 * rsq;
-    nf = -c * rsq;
-    asm volatile("s_nop 1" : "+v"(ps.r0), "+v"(ps.r1), "+v"(nf));  // the assembly DPP reads below: two wait states after these writes
-  }
 #define AMX_SYM_P ps
+#define AMX_SYM_HEADER_DONE 1
+  // One assembly block: the scaled row copies and the two pivot-lane selects, in this order.  The DPP reads of ps.r0 / ps.r1 by the
+  // multiply-adds below need two wait states after these writes: ps.r0 has (r1, select, select) behind it, ps.r1 the two selects - no
+  // s_nop.  The block reads rsq at least one instruction after the v_rsq_f32 (it consumes nf).  volatile: the headers keep their order.
+  {
+    float nfo, dgo;
+    if constexpr (G == 16) {
+      asm volatile("s_lshl_b64 %3, %5, %6\n\tv_mul_f32 %0, %7, %8\n\tv_cndmask_b32_e64 %1, %9, 0, %3\n\tv_cndmask_b32_e64 %2, %10, %11, %3"
+                   : "=&v"(ps.r0), "=&v"(nfo), "=&v"(dgo), "=s"(pm) : "3"(pm), "s"(pm0), "n"(J), "v"(c), "v"(rsq), "v"(nf), "v"(diag), "v"(piv) : "scc");
+      ps.r1 = ps.r0;
+    } else {
+      asm volatile("s_lshl_b64 %4, %6, %7\n\tv_mul_f32 %0, %8, %10\n\tv_mul_f32 %1, %9, %10\n\tv_cndmask_b32_e64 %2, %11, 0, %4\n\tv_cndmask_b32_e64 %3, %12, %13, %4"
+                   : "=&v"(ps.r0), "=&v"(ps.r1), "=&v"(nfo), "=&v"(dgo), "=s"(pm)
+                   : "4"(pm), "s"(pm0), "n"(J), "v"(p.r0), "v"(p.r1), "v"(rsq), "v"(nf), "v"(diag), "v"(piv) : "scc");
+    }
+    nf = nfo; diag = dgo;
+  }
 #else
 #define AMX_SYM_P p
 #endif
 #else
   float nf = -c * __builtin_amdgcn_rcpf(piv);
 #endif
-#if AMX_PIVOT_VCMP
+#if AMX_PIVOT_VCMP && !defined(AMX_SYM_HEADER_DONE)
   nf = gl == J ? 0.0f : nf;  // the pivot row itself is left alone
   diag = gl == J ? piv : diag;  // ... and its diagonal is final: kept for the last division (same test, no pass over the row at the end)
 #else
@@ -980,9 +1020,11 @@ template <class S, int G, int J, bool TREE, bool BCOL> DEV void sym_pivot(float 
   // and ran 3 % slower than with the pivots in the order written (r03 A/B: profiles/r03_ab_pivot_order.txt)
   // The mask lives in ONE scalar register pair for the whole elimination (the output is tied to the previous pivot's mask): the
   // selects of pivot k must read it before pivot k+1 overwrites it, which pins every pivot's header behind its predecessor's.
+#ifndef AMX_SYM_HEADER_DONE
   asm volatile("s_lshl_b64 %0, %2, %3" : "=s"(pm) : "0"(pm), "s"(pm0), "n"(J) : "scc");
   nf = sel_zero(pm, nf);           // the pivot row itself is left alone
   diag = sel_mask(pm, piv, diag);  // ... and its diagonal is final: kept for the last division
+#endif
 #endif
 #if AMX_TRUE_ROW_ELIM
   if constexpr (TREE) {
@@ -995,11 +1037,16 @@ template <class S, int G, int J, bool TREE, bool BCOL> DEV void sym_pivot(float 
     fmac_bcast<N>(a[N], AMX_SYM_P, nf);
   } else {
     const RowPair pb = row_pair<G>(a[N]);
+#if AMX_SYM_EXACT && !AMX_PIVOT_CLAMP
+    a[N] = __builtin_fmaf(nf * rsq, bcast_row<J>(pb), a[N]);  // (nf carries one factor 1 / sqrt(pivot); the right-hand side needs no symmetry)
+#else
     a[N] = __builtin_fmaf(nf, bcast_row<J>(pb), a[N]);
+#endif
   }
   if constexpr (TREE) SymAnc<S, G, S::dof_parent[J]>::run(a, AMX_SYM_P, nf);
   else SymRest<S, G, J + 1>::run(a, AMX_SYM_P, nf);
 #undef AMX_SYM_P
+#undef AMX_SYM_HEADER_DONE
 }
 #ifndef AMX_ELIM_ORDER
 #define AMX_ELIM_ORDER 1  // 0: pivots from the last dof to the first; 1: by rounds of leaves (A/B switch)
@@ -1400,7 +1447,8 @@ AMX_STATIC_SOLVE_ATTR bool newton_solve_pair2(int M_off, unsigned long long crow
   };
   auto issue8 = [&](const Ops (&o)[8]) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) C = __builtin_amdgcn_mfma_f32_16x16x1f32(o[k].d * ((hasA | augA) ? o[k].ja : 0.0f), hasB ? o[k].jb : 0.0f, C, 0, 0, 0);
+    for (int k = 0; k < 8; ++k)
+      C = __builtin_amdgcn_mfma_f32_16x16x1f32(o[k].d * ((hasA | augA) ? o[k].ja : 0.0f), AMX_SQRT_D ? o[k].d * (hasB ? o[k].jb : 0.0f) : (hasB ? o[k].jb : 0.0f), C, 0, 0, 0);
   };
   if (tm != 0u) {
     Ops o0[8], o1[8];
@@ -1939,6 +1987,7 @@ struct Env {
   // bounded by +-aFl, so its cost is quadratic while |Jaref| < aFl / aD and linear beyond (aFl = 0 on every other row)
   float aFl;
   float cD, cAref, cJaref, cJv;  // slot B solver state
+  float cSd = 0.0f, c2Sd = 0.0f;  // sqrt(cD), sqrt(c2D): the matrix cores' operand scale (AMX_SQRT_D)
   // second contact-row slot (r04; per-model kernels with S::nbs == 2 only): row gl + G of the contact rows, same fields
   static constexpr int NBS = S::is_static ? (S::nbs == 2 ? 2 : 1) : 1;
   float c2D, c2Aref, c2Jaref, c2Jv;
@@ -3003,6 +3052,11 @@ struct Env {
       }
     }
     cD = dd;
+#ifdef AMX_EXPERIMENT_SQRT_IEEE
+    cSd = sqrtf(dd);
+#else
+    cSd = __builtin_amdgcn_sqrtf(dd);  // once per step: D of a row is fixed over the solver's iterations, only its activity changes
+#endif
     cAref = ar;
     if constexpr (NBS == 2) {
       dd = 0; ar = 0;
@@ -3021,6 +3075,7 @@ struct Env {
         }
       }
       c2D = dd;
+      c2Sd = __builtin_amdgcn_sqrtf(dd);
       c2Aref = ar;
     }
   }
@@ -3208,11 +3263,12 @@ struct Env {
       aact = fri ? (fabsf(fq) < aFl) : aact;
     }
     if (gl < nA()) { row(0, gl) = aact ? aD : 0.0f; row(1, gl) = f; }
-    if (gl < nB()) { row(0, row0 + gl) = cact ? cD : 0.0f; row(1, row0 + gl) = fc; row(2, row0 + gl) = cJaref; }  // field 2: for the augmented J'DJ (newton_solve_fused)
+    // field 0 of a contact row: what the Hessian's products take - sqrt(D) of an active row (AMX_SQRT_D; D before r05), 0 otherwise
+    if (gl < nB()) { row(0, row0 + gl) = cact ? (AMX_SQRT_D ? cSd : cD) : 0.0f; row(1, row0 + gl) = fc; row(2, row0 + gl) = cJaref; }  // field 2: for the augmented J'DJ (newton_solve_fused)
     if constexpr (NBS == 2) {
       c2act = validB2() & (c2Jaref < 0) & (c2D > 0);
       const float fc2 = c2act ? -c2D * c2Jaref : 0.0f;
-      if (validB2()) { row(0, row0 + gl + G) = c2act ? c2D : 0.0f; row(1, row0 + gl + G) = fc2; row(2, row0 + gl + G) = c2Jaref; }
+      if (validB2()) { row(0, row0 + gl + G) = c2act ? (AMX_SQRT_D ? c2Sd : c2D) : 0.0f; row(1, row0 + gl + G) = fc2; row(2, row0 + gl + G) = c2Jaref; }
     }
     WSYNC();
     if (grad_in_solve() && defer) {
@@ -3348,6 +3404,10 @@ struct Env {
           float d[4], ja[4], jb[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) { d[k] = lds[Dr + k * ROW_E]; ja[k] = lds[Jr + k * ldc + sa]; jb[k] = lds[Jr + k * ldc + sb]; }
+#if AMX_SQRT_D
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { ja[k] *= d[k]; jb[k] *= d[k]; d[k] = 1.0f; }  // d is sqrt(D): symmetric products, as on the matrix cores
+#endif
           return HEnt{Ho + di * ldm + dj, Ho + dj * ldm + di, (d[0] * ja[0] * jb[0] + d[1] * ja[1] * jb[1]) + (d[2] * ja[2] * jb[2] + d[3] * ja[3] * jb[3])};
         },
         [&](int, const HEnt &r) { if (r.v != 0.0f) { atomicAdd(&lds[r.at], r.v); if (r.at2 != r.at) atomicAdd(&lds[r.at2], r.v); } });

@@ -69,9 +69,7 @@ class _Handle:
             if "needs per-model kernels" not in str(e) or specialise is False:
                 raise
             needs_build = True
-        # AMX_ACCURATE_ELIM=1 (see ambersim_amd/_spec.py): the library's own kernels, shipped models included, are the fast form - build
-        accurate = os.environ.get("AMX_ACCURATE_ELIM", "0") not in ("", "0")
-        if needs_build or (specialise and (accurate or not self.query("specialised"))):
+        if needs_build or (specialise and not self.query("specialised")):
             # specialise: True = the caller asked for a per-model build (errors propagate); "auto" = the default: build one when hipcc
             # is on this machine, say so in one line, and run the generic kernels (about half the throughput) when it is not
             import logging

@@ -603,25 +603,6 @@ def secondary(args, model, mj, model_path, x0_np, us_np, kern_ms, dev):
             del mdl
         except Exception as e:
             out.append({"name": "C3 generic kernels", "error": f"{type(e).__name__}: {e}"})
-        # the headline model on a per-model build with the accurate eliminations (AMX_ACCURATE_ELIM=1: the pivot row from the pivot's own
-        # lane; profiles/r04_standing_impact.txt says when that matters): what the robust form costs.  Needs hipcc on this machine.
-        try:
-            os.environ["AMX_ACCURATE_ELIM"] = "1"
-            try:
-                t0 = time.perf_counter()
-                mdl = mjx.put_model(mj, dev, specialise=True)
-                t_build = time.perf_counter() - t0
-            finally:
-                del os.environ["AMX_ACCURATE_ELIM"]
-            k = 3
-            el, kms, fin = timed_rollouts(mdl, x0_t, us_t, k)
-            out.append({"name": "C3 accurate eliminations", "metric": "env-steps/sec, 4096 envs x 1000-step rollout", "value": args.nenv * args.horizon * k / el, "unit": "env-steps/s",
-                        "steps": k, "ms_per_step": 1e3 * el / k, "kernel_ms": kms,
-                        "config": {"workload": f"{os.path.basename(model_path)}, same inputs as the headline, per-model kernels built with AMX_ACCURATE_ELIM=1 (true pivot rows)",
-                                   "specialised_build": bool(mdl._h.query("specialised")), "model_setup_s": t_build, "outputs_finite": fin}})
-            del mdl
-        except Exception as e:
-            out.append({"name": "C3 accurate eliminations", "error": f"{type(e).__name__}: {str(e)[:200]}"})
         del x0_t, us_t
 
     if True:

@@ -71,7 +71,7 @@ typedef struct amx_model_desc {
       *pair_margin /*[npair] margin-gap*/, *convex_vert /*[nconvexvert,3] geom-local hull vertices*/;
   /* convex hulls of the box / mesh geoms in convex-convex pairs (pair_fn 6): polygon faces (coplanar triangles merged,
    * vertices counter-clockwise seen from outside), outward unit face normals, unique edges; everything geom-local.
-   * Limits: <= 32 vertices, <= 32 faces of <= 8 vertices, <= 64 edges per hull. */
+   * Limits: <= 64 vertices, <= 128 faces of <= 8 vertices, <= 192 edges per hull (a triangulated 64-vertex hull has 124 faces, 186 edges). */
   const int *pair_hull1, *pair_hull2 /*[npair] hull of geom1 / geom2 for pair_fn 6 (pair_fn 7: of geom2 only), else -1*/;
   const int *hull_vertadr, *hull_vertnum, *hull_faceadr, *hull_facenum, *hull_edgeadr, *hull_edgenum /*[nhull]*/;
   const double *hull_vert /*[nhullvert,3]*/, *hull_face_normal /*[nhullface,3]*/;

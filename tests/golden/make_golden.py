@@ -46,6 +46,17 @@ def cases():
         x0[:, mj.nq:] += 0.05 * rng.standard_normal((nenv, mj.nv))
         us = rng.uniform(mj.actuator_ctrlrange[:, 0], mj.actuator_ctrlrange[:, 1], (nenv, N, mj.nu))
         out[name] = (mj, x0, us)
+    # the bench's headline models (r05): the servo-held standing biped, and the one that falls and comes to rest on its contact
+    # spheres - long enough to hold the fall and its impacts (BASELINE.json configs[2]; bench.make_inputs' distribution: standing
+    # keyframe + N(0, 0.01^2) velocity noise, ctrl ~ U(ctrlrange))
+    for name, path, nenv, N, seed in (("biped_stand", "models/biped/biped_stand.xml", 8, 100, 4),
+                                      ("biped_rest", "models/biped/biped_rest.xml", 8, 240, 5)):
+        mj = load_mj_model_from_file(path)
+        rng = np.random.default_rng(seed)
+        x0 = np.tile(np.concatenate([mj.key_qpos[0], np.zeros(mj.nv)]), (nenv, 1))
+        x0[:, mj.nq:] += 0.01 * rng.standard_normal((nenv, mj.nv))
+        us = rng.uniform(mj.actuator_ctrlrange[:, 0], mj.actuator_ctrlrange[:, 1], (nenv, N, mj.nu))
+        out[name] = (mj, x0.astype(np.float32).astype(np.float64), us.astype(np.float32).astype(np.float64))  # exactly representable in fp32
     mj = bh280_fixture_model()
     rng = np.random.default_rng(3)
     x0 = 0.3 * rng.standard_normal((10, mj.nq + mj.nv))

@@ -206,7 +206,9 @@ def test_parity_per_horizon(dev):
             # statistic: two builds whose 256-env medians at N = 1000 are 1.80e-4 and 1.75e-4 (CPU fp32: 1.21e-4) measured
             # 4.5e-4 and 1.3e-3 on these 64 envs (CPU fp32: 1.5e-4).  Bounds: 4x / 0.15 at N = 100, 10x / 0.15 at N = 1000;
             # the committed 256-env table (profiles/r02_parity_horizons.txt) is the record
-            fm, ff = (2, 0.1) if h <= 10 else ((4, 0.15) if h <= 100 else (10, 0.15))
+            # (r05: 0.25 from N = 100 on - on 64 envs the fraction has a standard error of 0.06 per run and the standing biped's median sits AT 1e-5
+            #  there: 0.45 against 0.61 was measured; the 256-env table profiles/r05_parity_horizons.txt has 0.53 / 0.51 / 0.57)
+            fm, ff = (2, 0.1) if h <= 10 else ((4, 0.25) if h <= 100 else (10, 0.25))
             assert r["gpu_fp32_median"] <= fm * r["cpu_fp32_median"] + 1e-6, (name, h, r)
             # r04: the same against the fp32 CPU oracle that runs the KERNEL's line-search rule and arithmetic (ls_rule 3,
             # tests/test_ls_rule.py) - the build of the checker that states the algorithm the HIP path runs
@@ -222,7 +224,7 @@ def test_parity_per_horizon(dev):
             if h <= 10:
                 assert r["gpu_fp32_max"] <= 4 * r["cpu_fp32_max"] + 2e-6, (name, h, r)
         assert rows[1]["gpu_fp32_max"] <= 1e-5
-        if not name.startswith("C3"):
+        if not name.startswith("C3") or name == "C3 stand":  # the bench headline (servo-held standing biped): every env within 1e-5 at N = 10 too (measured 1.6e-6)
             assert rows[10]["gpu_fp32_max"] <= 1e-5
 
 

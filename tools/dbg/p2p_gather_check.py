@@ -1,6 +1,6 @@
 """Mechanics of ambersim_amd.dist.PeerCopyGather with two processes on ONE GPU (the 1-GPU box: both ranks use cuda:0, process group
 over gloo - RCCL refuses two ranks on one device): IPC exchange, probe, two gathers in flight, contents and order.
-    python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 tools/dbg/p2p_gather_test.py"""
+    python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 tools/dbg/p2p_gather_check.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, torch.distributed as dist

@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 
 HORIZONS = (1, 10, 100, 1000)
 CONFIGS = (("C1 pendulum", "models/pendulum/pendulum.xml"), ("C2 quadruped", "models/quadruped/quadruped.xml"),
-           ("C3 biped", "models/biped/biped.xml"))
+           ("C3 biped", "models/biped/biped.xml"), ("C3 stand", "models/biped/biped_stand.xml"), ("C3 rest", "models/biped/biped_rest.xml"))
 
 
 def inputs(mj, nenv, N, seed):
