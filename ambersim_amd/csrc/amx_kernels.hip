@@ -896,13 +896,15 @@ template <class S, int G, int K, int J> struct SymAncT {
 };
 template <class S, int G, int J> struct SymAncT<S, G, -1, J> { static DEV void run(float (&)[S::nv + 1], float) {} };
 #endif
-template <class S, int G, int K> struct SymAnc {  // K walks the pivot's ancestor chain
+template <class S, int G, int K, int LO = 0> struct SymAnc {  // K walks the pivot's ancestor chain (columns below LO are somebody else's: see ElimDefer)
   static DEV void run(float (&a)[S::nv + 1], const RowPair &p, float nf) {
-    fmac_bcast<K>(a[K], p, nf);
-    SymAnc<S, G, S::dof_parent[K]>::run(a, p, nf);
+    if constexpr (K >= LO) {  // (a dof's ancestors have lower indices: the first one below LO ends the walk)
+      fmac_bcast<K>(a[K], p, nf);
+      SymAnc<S, G, S::dof_parent[K], LO>::run(a, p, nf);
+    }
   }
 };
-template <class S, int G> struct SymAnc<S, G, -1> { static DEV void run(float (&)[S::nv + 1], const RowPair &, float) {} };
+template <class S, int G, int LO> struct SymAnc<S, G, -1, LO> { static DEV void run(float (&)[S::nv + 1], const RowPair &, float) {} };
 template <class S, int G, int K> struct SymRest {  // dense order: every column after the pivot
   static DEV void run(float (&a)[S::nv + 1], const RowPair &p, float nf) {
     if constexpr (K < S::nv) {
@@ -938,8 +940,19 @@ DEV float sel_mask(unsigned long long mask, float yes, float no) {  // masked la
   asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(o) : "v"(no), "v"(yes), "s"(mask));
   return o;
 }
-template <class S, int G, int J, bool TREE, bool BCOL> DEV void sym_pivot(float (&a)[S::nv + 1], int gl, float &diag, unsigned long long pm0, unsigned long long &pm) {
+typedef float v16acc __attribute__((ext_vector_type(16)));
+// NDEF > 0 (r05, tree eliminations of 32- and 64-lane groups): this pivot's updates of the columns 0 .. NDEF - 1 - the root chain every limb
+// hangs off: six of a floating base - are not made here.  They are rank-1 terms s_k(J) * (-s_i(J)) of a 16 x 16 product per (environment,
+// 16-lane row): one v_mfma_f32_16x16x1_4b_f32 per pivot takes A = the scaled column as row 0's lanes hold it (ps.r0: every 16-lane row has a
+// copy, so register k of every block stands for dof k) and B = the lane's own multiplier, and accumulates ALL the deferred pivots' terms on
+// the matrix cores; sym_defer_collect adds the sums to a[0 .. NDEF - 1] before the first pivot that reads one of those columns.  Same
+// products, same bits on both sides of the diagonal (s_k * -s_i = s_i * -s_k), summed in pivot order: the reduced matrix stays bitwise
+// symmetric.  Biped: 144 of an elimination's 254 multiply-adds leave the vector unit for 24 matrix instructions and 20 lane swaps / adds.
+template <class S, int G, int J, bool TREE, bool BCOL, int NDEF = 0, bool FIRST = false>
+DEV void sym_pivot(float (&a)[S::nv + 1], int gl, float &diag, unsigned long long pm0, unsigned long long &pm, v16acc *cdef = nullptr, unsigned long long rowm = 0ull) {
   constexpr int N = S::nv;
+  // the right-hand-side column's multiply-add rides in the pivot header's assembly block (see there)
+  constexpr bool rhs_in_block = AMX_SYM_EXACT && !AMX_PIVOT_CLAMP && !AMX_PIVOT_VCMP && !AMX_TRUE_ROW_ELIM && G != 16 && BCOL && N >= 16 && N < 32;
   const float c = a[J];
   const RowPair p = row_pair<G>(c);
   float piv;
@@ -983,25 +996,43 @@ template <class S, int G, int J, bool TREE, bool BCOL> DEV void sym_pivot(float 
 #else
   const float rsq = __builtin_amdgcn_rsqf(bcast_row<J>(p));
 #endif
-  nf = -c * rsq;  // compiler-visible: it pads the wait state a transcendental's result needs before its first use
+  if constexpr (!rhs_in_block) nf = -c * rsq;  // compiler-visible: it pads the wait state a transcendental's result needs before its first use (the
+                                               // block of 32- / 64-lane groups opens with a scalar instruction instead and never reads c)
   RowPair ps;
 #define AMX_SYM_P ps
 #define AMX_SYM_HEADER_DONE 1
-  // One assembly block: the scaled row copies and the two pivot-lane selects, in this order.  The DPP reads of ps.r0 / ps.r1 by the
-  // multiply-adds below need two wait states after these writes: ps.r0 has (r1, select, select) behind it, ps.r1 the two selects - no
-  // s_nop.  The block reads rsq at least one instruction after the v_rsq_f32 (it consumes nf).  volatile: the headers keep their order.
+  // One assembly block: the scaled row copies, the two pivot-lane selects and - 32- / 64-lane groups - the right-hand-side column's
+  // multiply-add, in this order.  Readers of the outputs need two wait states after these writes (the DPP reads of ps.r0 / ps.r1 by
+  // the multiply-adds, the matrix instruction's reads of ps.r0 and nf): ps.r1 has four instructions behind it inside the block, ps.r0
+  // three, nf two - no s_nop.  The block reads rsq at least one instruction after the v_rsq_f32 (it consumes nf).  volatile: the
+  // headers keep their order.
   {
     float nfo, dgo;
     if constexpr (G == 16) {
       asm volatile("s_lshl_b64 %3, %5, %6\n\tv_mul_f32 %0, %7, %8\n\tv_cndmask_b32_e64 %1, %9, 0, %3\n\tv_cndmask_b32_e64 %2, %10, %11, %3"
                    : "=&v"(ps.r0), "=&v"(nfo), "=&v"(dgo), "=s"(pm) : "3"(pm), "s"(pm0), "n"(J), "v"(c), "v"(rsq), "v"(nf), "v"(diag), "v"(piv) : "scc");
       ps.r1 = ps.r0;
+    } else if constexpr (rhs_in_block) {
+      // (r05b) the lane's own multiplier is minus its own scaled entry - ps.r0 on the lanes of a group's first 16-lane row, ps.r1 on the
+      // second's (rowm: a select with negated sources) - instead of a product with the unswapped column: nothing reads a[J] after the lane
+      // swap, so the swap works in place on it and one of its two copies goes (one vector instruction less per pivot)
+      float nfr;
+      asm volatile("s_lshl_b64 %4, %8, %9\n\tv_mul_f32 %1, %11, %12\n\tv_mul_f32 %0, %10, %12\n\tv_cndmask_b32_e64 %6, -%0, -%1, %15\n\t"
+                   "v_cndmask_b32_e64 %2, %6, 0, %4\n\tv_cndmask_b32_e64 %3, %13, %14, %4\n\t"
+                   "v_fmac_f32_dpp %5, %1, %2 row_newbcast:%16 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                   : "=&v"(ps.r0), "=&v"(ps.r1), "=&v"(nfo), "=&v"(dgo), "=s"(pm), "+v"(a[N]), "=&v"(nfr)
+                   : "4"(pm), "s"(pm0), "n"(J), "v"(p.r0), "v"(p.r1), "v"(rsq), "v"(diag), "v"(J < 16 ? p.r0 : p.r1), "s"(rowm), "n"(N & 15) : "scc");
     } else {
       asm volatile("s_lshl_b64 %4, %6, %7\n\tv_mul_f32 %0, %8, %10\n\tv_mul_f32 %1, %9, %10\n\tv_cndmask_b32_e64 %2, %11, 0, %4\n\tv_cndmask_b32_e64 %3, %12, %13, %4"
                    : "=&v"(ps.r0), "=&v"(ps.r1), "=&v"(nfo), "=&v"(dgo), "=s"(pm)
                    : "4"(pm), "s"(pm0), "n"(J), "v"(p.r0), "v"(p.r1), "v"(rsq), "v"(nf), "v"(diag), "v"(piv) : "scc");
     }
     nf = nfo; diag = dgo;
+  }
+  if constexpr (NDEF > 0) {
+    static_assert(G >= 32 && TREE && BCOL && J >= NDEF, "deferred columns: tree eliminations of 32- / 64-lane groups");
+    if constexpr (FIRST) { const v16acc Z = {}; *cdef = __builtin_amdgcn_mfma_f32_16x16x1f32(ps.r0, nf, Z, 0, 0, 0); }
+    else *cdef = __builtin_amdgcn_mfma_f32_16x16x1f32(ps.r0, nf, *cdef, 0, 0, 0);
   }
 #else
 #define AMX_SYM_P p
@@ -1034,7 +1065,7 @@ template <class S, int G, int J, bool TREE, bool BCOL> DEV void sym_pivot(float 
   }
 #endif
   if constexpr (BCOL) {
-    fmac_bcast<N>(a[N], AMX_SYM_P, nf);
+    if constexpr (!rhs_in_block) fmac_bcast<N>(a[N], AMX_SYM_P, nf);
   } else {
     const RowPair pb = row_pair<G>(a[N]);
 #if AMX_SYM_EXACT && !AMX_PIVOT_CLAMP
@@ -1043,7 +1074,7 @@ template <class S, int G, int J, bool TREE, bool BCOL> DEV void sym_pivot(float 
     a[N] = __builtin_fmaf(nf, bcast_row<J>(pb), a[N]);
 #endif
   }
-  if constexpr (TREE) SymAnc<S, G, S::dof_parent[J]>::run(a, AMX_SYM_P, nf);
+  if constexpr (TREE) SymAnc<S, G, S::dof_parent[J], NDEF>::run(a, AMX_SYM_P, nf);
   else SymRest<S, G, J + 1>::run(a, AMX_SYM_P, nf);
 #undef AMX_SYM_P
 #undef AMX_SYM_HEADER_DONE
@@ -1069,20 +1100,66 @@ template <class S> struct ElimOrder {
     }
   }
 };
+#ifndef AMX_ELIM_DEFER
+#define AMX_ELIM_DEFER 0  // 0: every pivot updates all of its ancestors' columns on the vector unit (r04), A/B switch
+#endif
+// Which columns a tree elimination defers to the matrix cores (sym_pivot, NDEF) and for how many leading pivots.  Columns 0 .. ndef - 1 are
+// the chain at the root of the dof tree (dof k's parent is k - 1, at most 8: a floating base has 6); the pivots that defer are the leading
+// ones of the order whose index is >= ndef - a dof's ancestors have lower indices, so none of them reads a deferred column.  Worth it when
+// the multiply-adds saved outnumber the collection's swaps and adds several times.
+template <class S, int G, bool BCOL> struct ElimDefer {
+  int ndef, npre;
+  constexpr ElimDefer() : ndef(0), npre(0) {
+    constexpr ElimOrder<S> ord{};
+    constexpr int N = S::nv;
+    if (AMX_ELIM_DEFER && AMX_SYM_EXACT && !AMX_PIVOT_CLAMP && !AMX_PIVOT_VCMP && !AMX_TRUE_ROW_ELIM && G >= 32 && BCOL && N >= 16 && N < 32) {
+      int c = 1;
+      while (c < 8 && c < N && S::dof_parent[c] == c - 1) ++c;
+      int pre = 0, saved = 0;
+      while (pre < N && ord.seq[pre] >= c) {
+        for (int k = S::dof_parent[ord.seq[pre]]; k >= 0; k = S::dof_parent[k]) saved += k < c ? 1 : 0;
+        ++pre;
+      }
+      if (saved >= 4 * (2 * c + 4)) { ndef = c; npre = pre; }
+    }
+  }
+};
+// adds the deferred columns' sums to a[0 .. NDEF - 1].  Register 4 b + r of lane (g, j) of the accumulator holds entry 4 g + r of column j of
+// block b = the sum for dof 4 g + r (the A operand's index) of the row lane j of block b holds (the B operand's): the same 4 x 4 transpose of
+// 16-lane row pieces as newton_solve_pair2's, but only the first NDEF entries are wanted.
+template <int NDEF, int NV> DEV void sym_defer_collect(float (&a)[NV + 1], const v16acc &C) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (r >= NDEF) break;
+    auto s01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(C[r]), __float_as_uint(C[4 + r]), false, false);
+    auto s23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(C[8 + r]), __float_as_uint(C[12 + r]), false, false);
+    auto t02 = __builtin_amdgcn_permlane32_swap(s01[0], s23[0], false, false);
+    a[r] += __uint_as_float(t02[0]);
+    if (4 + r < NDEF) {
+      auto t13 = __builtin_amdgcn_permlane32_swap(s01[1], s23[1], false, false);
+      a[4 + r] += __uint_as_float(t13[0]);
+    }
+  }
+}
 template <class S, int G, int I, bool BCOL> struct SymTree {  // leaves before their ancestors
-  static DEV void run(float (&a)[S::nv + 1], int gl, float &diag, unsigned long long pm0, unsigned long long &pm) {
+  static DEV void run(float (&a)[S::nv + 1], int gl, float &diag, unsigned long long pm0, unsigned long long &pm, v16acc &cdef, unsigned long long rowm) {
     if constexpr (I < S::nv) {
       constexpr ElimOrder<S> ord{};
-      sym_pivot<S, G, ord.seq[I], true, BCOL>(a, gl, diag, pm0, pm);
-      SymTree<S, G, I + 1, BCOL>::run(a, gl, diag, pm0, pm);
+      constexpr ElimDefer<S, G, BCOL> df{};
+      if constexpr (I < df.npre) sym_pivot<S, G, ord.seq[I], true, BCOL, df.ndef, I == 0>(a, gl, diag, pm0, pm, &cdef, rowm);
+      else {
+        if constexpr (df.npre > 0 && I == df.npre) sym_defer_collect<df.ndef, S::nv>(a, cdef);
+        sym_pivot<S, G, ord.seq[I], true, BCOL>(a, gl, diag, pm0, pm, nullptr, rowm);
+      }
+      SymTree<S, G, I + 1, BCOL>::run(a, gl, diag, pm0, pm, cdef, rowm);
     }
   }
 };
 template <class S, int G, int J, bool BCOL> struct SymDense {
-  static DEV void run(float (&a)[S::nv + 1], int gl, float &diag, unsigned long long pm0, unsigned long long &pm) {
+  static DEV void run(float (&a)[S::nv + 1], int gl, float &diag, unsigned long long pm0, unsigned long long &pm, unsigned long long rowm) {
     if constexpr (J < S::nv) {
-      sym_pivot<S, G, J, false, BCOL>(a, gl, diag, pm0, pm);
-      SymDense<S, G, J + 1, BCOL>::run(a, gl, diag, pm0, pm);
+      sym_pivot<S, G, J, false, BCOL>(a, gl, diag, pm0, pm, nullptr, rowm);
+      SymDense<S, G, J + 1, BCOL>::run(a, gl, diag, pm0, pm, rowm);
     }
   }
 };
@@ -1090,8 +1167,10 @@ template <class S, int G, int J, bool BCOL> struct SymDense {
 template <class S, int G, bool TREE, bool BCOL> DEV void sym_eliminate(float (&a)[S::nv + 1], int gl, float &diag) {
   unsigned long long pm0 = lane_mask<G, 0>(), pm = 0;
   asm volatile("" : "+s"(pm0), "+s"(pm));  // opaque: thirty constant masks would be hoisted out of the step loop and spilled
-  if constexpr (TREE) SymTree<S, G, 0, BCOL>::run(a, gl, diag, pm0, pm);
-  else SymDense<S, G, 0, BCOL>::run(a, gl, diag, pm0, pm);
+  unsigned long long rowm = 0xFFFF0000FFFF0000ull;  // the lanes of every second 16-lane row
+  asm volatile("" : "+s"(rowm));
+  if constexpr (TREE) { v16acc cdef; SymTree<S, G, 0, BCOL>::run(a, gl, diag, pm0, pm, cdef, rowm); }
+  else SymDense<S, G, 0, BCOL>::run(a, gl, diag, pm0, pm, rowm);
 }
 // (64-lane groups, r04: one environment per wave with its matrix rows in lanes 0..nv-1 < 32 - the same two DPP rows as a 32-lane
 // group; lanes 32..63 hold all-zero rows and compute on them, their results are never stored)
@@ -1377,7 +1456,6 @@ AMX_STATIC_SOLVE_ATTR bool newton_solve_fused(int M_off, int ld_, int n_, unsign
 #ifndef AMX_MFMA_PAIR2
 #define AMX_MFMA_PAIR2 1  // 0: two-pair models keep the 32 x 32 two-block product (A/B switch)
 #endif
-typedef float v16acc __attribute__((ext_vector_type(16)));
 template <int CTRL_SHL, int ROWS, int BANKS> DEV void p2_add(float &acc, float src) {
   // acc += src read through DPP (row_shl:CTRL_SHL, or in place), on the lanes of the 16-lane rows ROWS (mask) and banks BANKS only
   if constexpr (CTRL_SHL == 0)
@@ -3598,9 +3676,12 @@ struct Env {
   template <int K> static DEV void fmac_rowb(float &acc, float x, float y) {  // acc += (lane K of the lane's 16-lane row of x) * y
     asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x), "v"(y), "n"(K));
   }
-  template <int K> static DEV float max_rowb(float x, float y) {  // max(lane K of the lane's 16-lane row of x, y) - one instruction (fmaxf adds a canonicalising v_max)
+  // max(lane K of the lane's 16-lane row of x, y) - one instruction (fmaxf adds a canonicalising v_max).  `dep`: an unused operand that
+  // orders the instruction behind the compiler-padded DPP read that produced it (r05: as an operand of THIS instruction - carried through y
+  // by an empty asm, the constant y was copied afresh for every use: three v_mov per bracketing iteration)
+  template <int K> static DEV float max_rowb(float x, float y, float dep) {
     float o;
-    asm("v_max_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(o) : "v"(x), "v"(y), "n"(K));
+    asm("v_max_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(o) : "v"(x), "v"(y), "n"(K), "v"(dep));
     return o;
   }
 #ifndef AMX_LS_PACKED_X
@@ -3654,8 +3735,8 @@ struct Env {
       return r;
     };
     const float hmin = 0.5f * MINVAL;
-    // hmin with a (fake) data dependence on `dep`: the assembly DPP reads that take it are ordered behind the compiler-padded read that made `dep`
-    auto hmin_v = [&](float dep) { float o = hmin; asm("" : "+v"(o) : "v"(dep)); return o; };
+    float hmin_r = hmin;
+    asm volatile("" : "+v"(hmin_r));  // one register for the whole search (rematerialised per use it is a v_mov each time)
     const float q0_start = q0at(0.0f);
     LSH p0;
     float sn;
@@ -3664,7 +3745,7 @@ struct Env {
       const float u = gsum_pack4<G>(t.x, t.y, sn_, 0.0f);
       sn = quad_value<3>(u);
       const float hd0 = quad_value<0>(u);  // (compiler-visible DPP read of u first: it carries the wait states the assembly reads below rely on)
-      p0 = LSH{0.0f, hd0, max_rowb<4>(u, hmin_v(hd0))};
+      p0 = LSH{0.0f, hd0, max_rowb<4>(u, hmin_r, hd0)};
     }
     PROF(21);
     const float hgtol = 0.5f * (m.tolerance() * m.ls_tolerance() * __builtin_amdgcn_sqrtf(sn) * m.scale());
@@ -3675,7 +3756,7 @@ struct Env {
       const float r = gsum_pack2<G>(t.x, t.y);
       float hd = quad_value<0>(r);
       fmac_rowb<4>(hd, r, a1);
-      p1 = LSH{a1, hd, max_rowb<4>(r, hmin_v(hd))};
+      p1 = LSH{a1, hd, max_rowb<4>(r, hmin_r, hd)};
     }
     const lmask first = LT(p1.hd, p0.hd);
     LSH lo = {SEL(first, p1.alpha, p0.alpha), SEL(first, p1.hd, p0.hd), SEL(first, p1.h, p0.h)};
@@ -3696,7 +3777,7 @@ struct Env {
       fmac_rowb<8>(hd_hi, u, a_hi);
       fmac_rowb<4>(hd_mid, w, a_mid);
       // (ordered behind the compiler-visible DPP reads of u and w through their results: the two wait states after the lane swaps)
-      const float h_lo = max_rowb<4>(u, hmin_v(hd_lo)), h_hi = max_rowb<8>(u, hmin_v(hd_hi)), h_mid = max_rowb<4>(w, hmin_v(hd_mid));
+      const float h_lo = max_rowb<4>(u, hmin_r, hd_lo), h_hi = max_rowb<8>(u, hmin_r, hd_hi), h_mid = max_rowb<4>(w, hmin_r, hd_mid);
       const lmask s_lo_next = nd & (LT(0.0f, lo.hd) | LT(lo.hd, hd_lo));
       LSH nlo = {SEL(s_lo_next, a_lo, lo.alpha), SEL(s_lo_next, hd_lo, lo.hd), SEL(s_lo_next, h_lo, lo.h)};
       const lmask s_lo_mid = nd & LT(hd_mid, 0.0f) & LT(nlo.hd, hd_mid);

@@ -21,6 +21,10 @@ def regs(tok):
 bad = checked = 0
 func = None
 hist = []  # (written vgprs, wait states this instruction accounts for)
+# (r05) second rule, same reason - inline assembly that consumes a compiler-emitted transcendental's result: on gfx940 / gfx950 a VALU read
+# of a VGPR written by v_rcp / v_rsq / v_sqrt / v_exp / v_log / v_sin / v_cos needs 1 wait state (the compiler pads its own uses only)
+TRANS = ("v_rcp_", "v_rsq_", "v_sqrt_", "v_exp_", "v_log_", "v_sin_", "v_cos_")
+last_trans = set()  # VGPRs written by the immediately preceding instruction, if it was a transcendental
 for line in open(path):
     m = re.match(r"^(_Z\w+):", line)
     if m: func, hist = m.group(1), []; continue
@@ -28,6 +32,13 @@ for line in open(path):
     if not line.startswith("\t") or t.startswith((".", ";")) or not t: continue
     op, _, rest = t.partition(" ")
     ops = [o.strip() for o in rest.split(",")]
+    if op.startswith("v_") and last_trans and not op.startswith(TRANS):
+        srcs = set()
+        for o in ops[1:]: srcs |= regs(o)
+        if srcs & last_trans:
+            bad += 1
+            print(f"TRANS HAZARD in {func}: `{t}` reads {sorted(srcs & last_trans)} written by a transcendental 0 wait states earlier")
+    last_trans = regs(ops[0]) if op.startswith(TRANS) else set()
     if "_dpp" in op and op.startswith("v_"):  # every DPP instruction: the inline-assembly ones (v_fmac, v_add, v_max) are the ones the compiler cannot pad
         checked += 1
         src0 = regs(ops[1].split()[0])
