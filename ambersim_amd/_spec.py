@@ -154,15 +154,30 @@ def _extra_flags():
     return flags
 
 
+_SRC_DIGEST = {}
+
+
+def _sources_digest() -> bytes:
+    """sha256 over the kernel sources, once per process and (mtime, size) state: Model.replace(opt=...) asks for a library path on every
+    call, and re-reading 300 KB of sources each time was the cost of a cached build."""
+    srcs = [_CSRC / f for f in ("amx_api.cpp", "amx_kernels.hip", "amx_plan.h", "amx_dev.h")] + [_CSRC.parent.parent / "include" / "amx.h"]
+    key = tuple((str(f), f.stat().st_mtime_ns, f.stat().st_size) for f in srcs)
+    if key not in _SRC_DIGEST:
+        h = hashlib.sha256()
+        for f in srcs:
+            h.update(f.read_bytes())
+        _SRC_DIGEST.clear()
+        _SRC_DIGEST[key] = h.digest()
+    return _SRC_DIGEST[key]
+
+
 def specialised_library_path(mj):
     """(path, header text) of the per-model build of `mj`: keyed by the record, the sources, the compile flags, the
     architecture and the compiler's version string."""
     header = render_header([("model", mj)], "// generated by ambersim_amd._spec.build_specialised_library for one model; do not edit.")
-    srcs = [_CSRC / f for f in ("amx_api.cpp", "amx_kernels.hip", "amx_plan.h", "amx_dev.h")] + [_CSRC.parent.parent / "include" / "amx.h"]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     h = hashlib.sha256(header.encode())
-    for f in srcs:
-        h.update(f.read_bytes())
+    h.update(_sources_digest())
     h.update(" ".join(FLAGS + _extra_flags()).encode())
     h.update(_hipcc_id(hipcc).encode())
     return cache_dir() / f"libamx_{h.hexdigest()[:16]}.so", header

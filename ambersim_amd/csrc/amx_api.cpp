@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/amx.h"
@@ -98,6 +99,11 @@ template <class S> static bool spec_matches(const DevModel &m, const amx_model_d
   AMX_MODEL_INTS(X)
 #undef X
   for (int i = 0; i < m.nv; i++) if (d->dof_parentid[i] != S::dof_parent[i]) return false;
+  // the two-pair Hessian (newton_solve_pair2) reads S::p2_col at compile time to decide which register each accumulator column is added to;
+  // the columns come from the pairs' dof lists, which none of the integers above fixes (two models can share the tree, the list lengths and
+  // the banks / shifts and still put their feet on sibling branches): compare the planner's list for THIS model (plan_model left it in the
+  // thread-local p2_col) - ADVICE r04
+  if (m.mfma2) for (int k = 0; k < 32; k++) if (p2_col[k] != S::p2_col[k]) return false;
   return tree_H == S::tree_H;
 }
 static int find_spec(const DevModel &m, const amx_model_desc *d, const Image &im) {
@@ -108,6 +114,19 @@ static int find_spec(const DevModel &m, const amx_model_desc *d, const Image &im
   AMX_SPECS(X)
 #undef X
   return found;
+}
+
+// Tooling (not part of include/amx.h; no device call): the index of the compiled-in specialisation the library would run this
+// model on (-1: none - the generic kernels), as amx_model_create decides it.  poke_k >= 0 overrides entry poke_k of the planner's
+// two-pair column list with poke_v before the comparison - tests/test_abi.py checks with it that a model whose pair dof lists
+// differ from a record's is not matched to that record even when every integer of the plan agrees.
+extern "C" int amx_spec_index_of(const amx_model_desc *d, int poke_k, int poke_v) {
+  if (!d) return -2;
+  DevModel m;
+  Image im;
+  if (plan_model(d, m, im)) return -2;
+  if (poke_k >= 0 && poke_k < 32) p2_col[poke_k] = poke_v;
+  return find_spec(m, d, im);
 }
 
 static int model_create_impl(const amx_model_desc *d, int device, amx_model **out, bool wide_plan) {
@@ -155,7 +174,9 @@ extern "C" int amx_model_create(const amx_model_desc *d, int device, amx_model *
   // environments per wave (C4: 1024 rollouts = 512 waves on 1024 SIMDs).  Opt-in (AMX_WIDE_SMALL_BATCH=1, see pick_plan): it
   // measured slower than the regular plan, and by default every batch size runs one kernel (results bit-identical across launch sizes).
   amx_model *h = *out;
-  if (h->dev.G == 32 && h->spec >= 0 && !getenv("AMX_NO_WIDE")) {
+  // (the wide plan is opt-in at run time - pick_plan, AMX_WIDE_SMALL_BATCH=1 - so its device image is only built when that is set)
+  const char *wide_env = getenv("AMX_WIDE_SMALL_BATCH");
+  if (h->dev.G == 32 && h->spec >= 0 && !getenv("AMX_NO_WIDE") && wide_env && atoi(wide_env) != 0) {
     amx_plan_force_lanes(64);
     amx_model *w = nullptr;
     const int rc = model_create_impl(d, device, &w, true);
@@ -192,23 +213,33 @@ extern "C" int amx_model_destroy(amx_model *m) {
 // workgroup per CU, 512 threads), cached: 1 yes on every workgroup, 0 no (the rollout kernel then leaves the pair to the
 // hardware's arbitration: it re-checks per step), -1 the probe could not run.
 static int simd_pairing(int device, int ncu) {
+  // one probe per device and process, under a lock (handles may be queried from several threads); the probe runs on a stream of its
+  // own and waits for that stream only - a null-stream launch + hipDeviceSynchronize from a query would invalidate a stream capture
+  // in progress on the caller's side (the PPO collector captures its unroll as a HIP graph)
+  static std::mutex mu;
   static int cache[64];
   static bool have[64];
   if (device < 0 || device >= 64) return -1;
+  std::lock_guard<std::mutex> lock(mu);
   if (have[device]) return cache[device];
   int verdict = -1;
   const int nwg = ncu > 0 ? ncu : 256;
   int *d = nullptr;
+  hipStream_t st = nullptr;
   std::vector<int> h((size_t)nwg * 8, -1);
-  if (hipMalloc(&d, h.size() * sizeof(int)) == hipSuccess) {
-    hipLaunchKernelGGL(amx_simd_probe_kernel, dim3(nwg), dim3(512), 0, 0, d);
-    if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(h.data(), d, h.size() * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess) {
-      verdict = 1;
-      for (int b = 0; b < nwg; b++)
-        for (int w = 0; w < 4; w++)
-          if (h[(size_t)b * 8 + w] < 0 || h[(size_t)b * 8 + w] != h[(size_t)b * 8 + w + 4]) verdict = 0;
+  if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess) {
+    if (hipMalloc(&d, h.size() * sizeof(int)) == hipSuccess) {
+      hipLaunchKernelGGL(amx_simd_probe_kernel, dim3(nwg), dim3(512), 0, st, d);
+      if (hipGetLastError() == hipSuccess && hipMemcpyAsync(h.data(), d, h.size() * sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess &&
+          hipStreamSynchronize(st) == hipSuccess) {
+        verdict = 1;
+        for (int b = 0; b < nwg; b++)
+          for (int w = 0; w < 4; w++)
+            if (h[(size_t)b * 8 + w] < 0 || h[(size_t)b * 8 + w] != h[(size_t)b * 8 + w + 4]) verdict = 0;
+      }
+      (void)hipFree(d);
     }
-    (void)hipFree(d);
+    (void)hipStreamDestroy(st);
   }
   cache[device] = verdict;
   have[device] = true;

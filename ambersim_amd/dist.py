@@ -99,6 +99,12 @@ def gather_trajectories_async(xs_local: torch.Tensor) -> PendingGather:
     return PendingGather(out, work, xs_local)
 
 
+def _open_shared_cpu(reduced_storage, shape, dtype):
+    """A tensor over another process's shared-memory storage (PeerCopyGather's CPU rehearsal)."""
+    fn, args = reduced_storage
+    return torch.empty(0, dtype=dtype).set_(fn(*args), 0, shape)
+
+
 class PeerCopyGather:
     """Equal-block all-gather of trajectories by peer-to-peer copies instead of a collective kernel (r03).
 
@@ -122,6 +128,9 @@ class PeerCopyGather:
         from torch.multiprocessing.reductions import reduce_tensor
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self.device, self.nbuf, self.k = device, nbuf, 0
+        # CPU rehearsal (r05; bench.py --dry-run, tests/test_dist_cpu.py at world size 8): the same exchange, ownership protocol and
+        # failure handling with the buffers in shared host memory (torch's shared-memory handles instead of CUDA IPC) and no streams
+        self.on_cpu = torch.device(device).type == "cpu"
         self.held = [False] * nbuf  # buffer b handed out by wait() and not yet released by this rank
         self.cpu_group = dist.new_group(backend="gloo")
         self.block_shape = tuple(block_shape)
@@ -139,7 +148,18 @@ class PeerCopyGather:
         try:
             self.bufs = [torch.empty((self.world,) + self.block_shape, dtype=dtype, device=device) for _ in range(nbuf)]
             self.probe = torch.full((self.world, 4), -1.0, device=device)
-            mine = [reduce_tensor(t) for t in self.bufs + [self.probe]]
+            if self.on_cpu:
+                import torch.multiprocessing as tmp_
+                tmp_.set_sharing_strategy("file_system")  # handles that are names in /dev/shm: they survive a plain pickle (gloo's object exchange)
+                for t_ in self.bufs + [self.probe]:
+                    t_.share_memory_()
+            if self.on_cpu:
+                # (reduce_tensor of a CPU tensor carries the storage OBJECT, which a plain pickle copies by value: export the storage's
+                #  shared-memory name instead and rebuild the tensor over it on the other side)
+                from torch.multiprocessing.reductions import reduce_storage
+                mine = [(_open_shared_cpu, (reduce_storage(t.untyped_storage()), tuple(t.shape), t.dtype)) for t in self.bufs + [self.probe]]
+            else:
+                mine = [reduce_tensor(t) for t in self.bufs + [self.probe]]
         except Exception as e:
             err = e
         everyone = [None] * self.world
@@ -157,12 +177,16 @@ class PeerCopyGather:
         # probe: every rank writes its number into its slot of every peer's probe; all slots must arrive
         ok = 0
         try:
-            self.stream = torch.cuda.Stream(device)
-            with torch.cuda.stream(self.stream):
-                src = torch.full((4,), float(self.rank), device=device)
+            self.stream = None if self.on_cpu else torch.cuda.Stream(device)
+            src = torch.full((4,), float(self.rank), device=device)
+            if self.on_cpu:
                 for p in range(self.world):
-                    self.peer[p][nbuf][self.rank].copy_(src, non_blocking=True)
-            self.stream.synchronize()
+                    self.peer[p][nbuf][self.rank].copy_(src)
+            else:
+                with torch.cuda.stream(self.stream):
+                    for p in range(self.world):
+                        self.peer[p][nbuf][self.rank].copy_(src, non_blocking=True)
+                self.stream.synchronize()
         except Exception as e:
             err = e
         dist.barrier(group=self.cpu_group)
@@ -190,6 +214,10 @@ class PeerCopyGather:
                                    "was not released): call release() on that handle, or use wait(copy=True)")
         self.k += 1
         xs_local = xs_local.contiguous()
+        if self.on_cpu:
+            for d in range(self.world):
+                self.peer[(self.rank + d) % self.world][b][self.rank].copy_(xs_local)
+            return PendingPeerCopy(self, b, None)
         ready = torch.cuda.Event()
         ready.record()
         self.stream.wait_event(ready)
@@ -205,7 +233,8 @@ class PeerCopyGather:
 
     def close(self) -> None:
         """Drops this process's mappings of the peers' buffers, then meets the peers: a rank must not free buffers its peers still map."""
-        self.stream.synchronize()
+        if self.stream is not None:
+            self.stream.synchronize()
         self.peer = None
         dist.barrier(group=self.cpu_group)
 
@@ -221,12 +250,14 @@ class PendingPeerCopy:
         The result is a view of the rotating buffer and stays valid until `release()`; with copy=True it is a private copy and
         the buffer is released here."""
         o = self.owner
-        self.done.synchronize()             # my outgoing copies of THIS gather are done
+        if self.done is not None:
+            self.done.synchronize()         # my outgoing copies of THIS gather are done
         dist.barrier(group=o.cpu_group)     # ... and so are everybody else's (a CPU barrier: no kernel behind the rollout)
         buf = o.bufs[self.b].view((o.world * o.block_shape[0],) + o.block_shape[1:])
         if copy:
             out = buf.clone()
-            torch.cuda.current_stream(o.device).synchronize()  # the copy has read the buffer before a peer may write it again
+            if not o.on_cpu:
+                torch.cuda.current_stream(o.device).synchronize()  # the copy has read the buffer before a peer may write it again
             return out
         o.held[self.b] = True
         return buf
@@ -237,7 +268,8 @@ class PendingPeerCopy:
         device's streams): the current stream is synchronised here."""
         o = self.owner
         if o.held[self.b]:
-            torch.cuda.current_stream(o.device).synchronize()
+            if not o.on_cpu:
+                torch.cuda.current_stream(o.device).synchronize()
             o.held[self.b] = False
 
 

@@ -90,6 +90,10 @@ class _Handle:
                     self.L.amx_model_destroy(self._ptr)
                 self.L, self._ptr = L2, ptr2
             except Exception as e:
+                if needs_build and isinstance(e, (FileNotFoundError, RuntimeError)) and "hipcc" in str(e):
+                    # the ABI's documented answer to "this model cannot run here": NotImplementedError, with the original reason
+                    raise NotImplementedError(f"this model needs per-model kernels (two contact rows per lane) and they cannot be built on this "
+                                              f"machine: {e}") from e
                 if specialise != "auto" or needs_build:
                     raise
                 log.warning("per-model kernels unavailable (%s: %s): this model runs on the generic kernels, at about half the throughput of a "

@@ -275,7 +275,7 @@ def worker(args):
     # the gather method: peer-to-peer copies (copy engines) or the RCCL collective (kernels)
     p2p, p2p_note = None, None
     want_p2p = args.gather == "p2p" or (args.gather == "traj" and not args.no_scaling_report)  # the alternative is measured beside the collective
-    if world > 1 and not dry and want_p2p:
+    if world > 1 and want_p2p:  # (dry run: the same class on shared host memory - the protocol without the copy engines)
         try:
             p2p = PeerCopyGather((args.nenv, args.horizon + 1, nx), torch.float32, dev, nbuf=2)
         except Exception as e:  # IPC not available, peer access refused, probe lost: the collective still works
@@ -356,10 +356,12 @@ def worker(args):
             activity = activity_stats(model, mj, xs[:args.nenv], us)
         except Exception as e:  # a diagnostic must never take the headline down
             activity = {"error": f"{type(e).__name__}: {e}"}
+    block_order_ok = None
     if dry:
         # gathered blocks are in rank order: block r is filled with r
         want = torch.arange(world, dtype=torch.float32).repeat_interleave(args.nenv) if mode != "none" else torch.full((args.nenv,), float(rank))
         assert torch.equal(xs[:, 0, 0], want), "gathered trajectory blocks are out of order"
+        block_order_ok = True
 
     report = None
     if world > 1 and not args.no_scaling_report:
@@ -399,6 +401,8 @@ def worker(args):
                            "peer_copy_alone_ms": 1e3 * t_pg / k, "peer_copy_GBps_per_rank_received": gb * (world - 1) / world / (t_pg / k)})
         if p2p_note:
             report["peer_copy"] = p2p_note
+        if block_order_ok is not None:
+            report["block_order_ok"] = block_order_ok  # dry run: every rank found block r of the gathered tensor filled by rank r
         report.update(backend_report())
 
     if rank == 0:

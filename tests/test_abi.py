@@ -145,6 +145,28 @@ def test_generated_spec_header_is_current():
     assert subprocess.run([sys.executable, os.path.join(root, "tools", "gen_specs.py"), "--check"], cwd=root).returncode == 0
 
 
+def test_spec_matching_compares_the_two_pair_columns(mj_models):
+    """ADVICE r04: the two-pair Hessian of a per-model kernel adds each accumulator column to the register `Spec::p2_col` names at compile
+    time, and those columns come from the pairs' dof lists - which no integer of the launch plan fixes.  amx_model_create must therefore
+    compare the list itself: the shipped bipeds match their record; the same plan with ONE column of the list changed (every integer, the
+    dof tree and the sparsity class still equal) matches nothing; a model without the two-pair form ignores the list."""
+    import ctypes as C
+    from ambersim_amd import _lib
+    from ambersim_amd._desc import build_desc
+    from ambersim_amd.utils.io_utils import load_mj_model_from_file
+    L = _lib.lib()  # (loads the HIP runtime the library binds to first)
+    L.amx_spec_index_of.restype = C.c_int
+    for path in ("models/biped/biped.xml", "models/biped/biped_stand.xml"):
+        d = build_desc(load_mj_model_from_file(path))
+        idx = L.amx_spec_index_of(C.byref(d), -1, 0)
+        assert idx >= 0, path
+        assert L.amx_spec_index_of(C.byref(d), 7, 24) == -1, path  # pair 0's second leg column moved to the other leg's dof
+        assert L.amx_spec_index_of(C.byref(d), 7, 19) == idx, path  # (poking the value it already has changes nothing)
+    dq = build_desc(mj_models["quadruped"])
+    iq = L.amx_spec_index_of(C.byref(dq), -1, 0)
+    assert iq >= 0 and L.amx_spec_index_of(C.byref(dq), 7, 24) == iq  # four single-contact pairs: no two-pair form, the list is not consulted
+
+
 def jit_test_model():
     """A model the library ships no specialisation for: the quadruped with two solver iterations instead of three."""
     import copy

@@ -131,3 +131,75 @@ def test_bench_workload_is_the_same_at_every_n():
         assert out["n_gpus"] == n and out["config"]["nenv_per_gpu"] == 4096 and out["config"]["horizon"] == 1000
         loads.append(out["config"]["workload"])
     assert loads[0] == loads[1] and "biped_stand.xml" in loads[0]
+
+
+def _worker_peer_copy(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from ambersim_amd.dist import PeerCopyGather, init_from_env
+    init_from_env("gloo")
+    nenv, T, nx = 3, 2, 5
+    pg = PeerCopyGather((nenv, T, nx), torch.float32, torch.device("cpu"), nbuf=2)
+    want = lambda k: torch.arange(world, dtype=torch.float32).repeat_interleave(nenv)[:, None, None].expand(world * nenv, T, nx) + 100.0 * k
+    held = []
+    for k in range(2):  # two gathers fill both rotating buffers; their results are kept (not released)
+        h = pg.start(torch.full((nenv, T, nx), float(rank) + 100.0 * k))
+        full = h.wait()
+        assert full.shape == (world * nenv, T, nx) and torch.equal(full, want(k)), (rank, k)  # blocks in rank order 0 .. world - 1
+        held.append((h, full))
+    # a third gather would let the peers overwrite buffer 0, which THIS job still holds on every rank: every rank is refused, nobody hangs
+    try:
+        pg.start(torch.zeros(nenv, T, nx))
+        raise AssertionError("a held buffer was reused")
+    except RuntimeError as e:
+        assert "still held" in str(e)
+    pg.k -= 0  # (the refused start() did not advance the rotation)
+    # one rank alone keeping its view is enough to refuse everybody
+    for h, _ in held[1:]:
+        h.release()
+    if rank != world - 1:
+        held[0][0].release()
+    try:
+        pg.start(torch.zeros(nenv, T, nx))
+        raise AssertionError("a buffer held by the last rank was reused")
+    except RuntimeError as e:
+        assert "still held" in str(e)
+    held[0][0].release()
+    assert torch.equal(held[0][1], want(0))  # untouched while it was held
+    h = pg.start(torch.full((nenv, T, nx), float(rank) + 200.0))
+    full = h.wait(copy=True)  # a private copy: released at once
+    assert torch.equal(full, want(2))
+    h2 = pg.start(torch.full((nenv, T, nx), float(rank) + 300.0))
+    assert torch.equal(h2.wait(copy=True), want(3))
+    pg.close()
+    torch.save(full, os.path.join(out_dir, f"peer{rank}.pt"))
+
+
+def test_peer_copy_gather_protocol_at_world_size_eight(tmp_path):
+    """The peer-copy gather (ambersim_amd.dist.PeerCopyGather: what `bench.py --gather p2p` runs over xGMI) rehearsed at the width of
+    the node the driver benches on - eight ranks, buffers in shared host memory instead of IPC-mapped device memory: blocks land in rank
+    order 0 .. 7 on every rank, a buffer still held by ANY rank refuses the gather that would overwrite it on EVERY rank (no hang), a
+    released one is reused, wait(copy=True) releases at once.  No hardware run is claimed: the copy engines and xGMI are not involved."""
+    world = 8
+    mp.spawn(_worker_peer_copy, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    ref = torch.load(tmp_path / "peer0.pt")
+    for r in range(1, world):
+        assert torch.equal(torch.load(tmp_path / f"peer{r}.pt"), ref)
+
+
+def test_bench_self_launch_dry_run_eight_ranks():
+    """`python bench.py --gpus 8 --dry-run` (the driver's widest launch, on the CPU over gloo): eight ranks, one JSON line, the collective
+    as the headline's gather and the peer-copy gather measured beside it (shared-memory transport), per-rank blocks in order."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--dry-run", "--nenv", "3", "--horizon", "2"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 8 and out["config"]["gather"] == "traj+overlapped" and out["scaling_report"]["gathered_GB_per_rank"] > 0
+    assert out["scaling_report"].get("block_order_ok") is True
+    p = subprocess.run(cmd + ["--gather", "p2p"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 8 and "peer-to-peer" in out["config"]["gather"] and out["scaling_report"].get("block_order_ok") is True

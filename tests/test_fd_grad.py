@@ -146,13 +146,17 @@ def test_c4_fd_gradient_vs_oracle(name, tolJ):
 def test_wide_plan_is_opt_in_and_agrees(monkeypatch):
     """The biped also has a WIDE plan (the same model on a 64-lane group, one environment per wavefront, static kernels
     Spec_biped_w64) meant for batches that cannot give every SIMD a two-environment wave (C4: 1024 rollouts = 512 waves on 1024 SIMDs).
-    It measured slower than the regular plan (profiles/r04_c4_fd_grad.txt), so it is opt-in (AMX_WIDE_SMALL_BATCH=1, read per call);
-    by default every batch size runs the same kernels.  Here: the plan exists, the switch selects it (through a foot impact the two
-    lane layouts round differently), and the two agree to rounding after one step and stay finite."""
+    It measured slower than the regular plan (profiles/r04_c4_fd_grad.txt), so it is opt-in: AMX_WIDE_SMALL_BATCH=1 at model creation
+    builds its device image (r05: not otherwise), and the same variable, read per call, selects it; by default every batch size runs the
+    same kernels.  Here: the plan exists when asked for, the switch selects it (through a foot impact the two lane layouts round
+    differently), and the two agree to rounding after one step and stay finite."""
     from ambersim_amd import mjx
     mj, x0, us, Qf, xg, eps = c4_case("biped_stance")
     dev = torch.device("cuda", 0)
+    assert mjx.put_model(mj, dev)._h.query("wide_plan") == 0
+    monkeypatch.setenv("AMX_WIDE_SMALL_BATCH", "1")
     model = mjx.put_model(mj, dev)
+    monkeypatch.delenv("AMX_WIDE_SMALL_BATCH")
     assert model._h.query("wide_plan") == 1 and model._h.query("lanes_per_env") == 32
     t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
     usp = t(us).unsqueeze(0).repeat(256, 1, 1) + 0.01 * torch.randn((256,) + us.shape, generator=torch.Generator(device=dev).manual_seed(0), device=dev)
