@@ -175,12 +175,31 @@ def specialised_library_path(mj):
     """(path, header text) of the per-model build of `mj`: keyed by the record, the sources, the compile flags, the
     architecture and the compiler's version string."""
     header = render_header([("model", mj)], "// generated by ambersim_amd._spec.build_specialised_library for one model; do not edit.")
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     h = hashlib.sha256(header.encode())
     h.update(_sources_digest())
     h.update(" ".join(FLAGS + _extra_flags()).encode())
-    h.update(_hipcc_id(hipcc).encode())
+    # (r05: the compiler's version is no longer part of the name - a host without hipcc must be able to find a library that
+    #  `python -m ambersim_amd.prebuild` made elsewhere; it is recorded beside the library and checked wherever hipcc is runnable)
     return cache_dir() / f"libamx_{h.hexdigest()[:16]}.so", header
+
+
+def _compiler_note(out: Path) -> Path:
+    return out.with_suffix(".hipcc.txt")
+
+
+def _cached_build_usable(out: Path) -> bool:
+    """The cached library exists and - where this machine has a runnable hipcc - was made by that very compiler (an upgrade must not
+    reuse the old compiler's code); on a machine without hipcc a prebuilt library is taken as it is."""
+    if not out.exists():
+        return False
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        return True
+    note = _compiler_note(out)
+    try:
+        return note.exists() and note.read_text() == _hipcc_id(hipcc)
+    except RuntimeError:
+        return True
 
 
 # What a per-model build is retried with when the compiler itself crashes (see build_specialised_library): the packed-fp32 forms
@@ -196,10 +215,10 @@ def build_specialised_library(mj, verbose: bool = False) -> Path:
     lock, writes to a name of its own and is renamed into place; a process that finds the library there uses it.
     Needs hipcc (ROCm) on the machine; raises RuntimeError otherwise."""
     out, header = specialised_library_path(mj)
-    if out.exists():
+    if _cached_build_usable(out):
         return out
     with _build_lock():
-        if out.exists():  # another rank built it while this one waited
+        if _cached_build_usable(out):  # another rank built it while this one waited
             return out
         tag = out.stem.split("_")[-1]
         hdr = cache_dir() / f"amx_spec_{tag}.h"
@@ -229,6 +248,9 @@ def build_specialised_library(mj, verbose: bool = False) -> Path:
             except OSError:
                 pass
             raise RuntimeError(f"specialised build failed ({' '.join(cmd)}):\n{r.stderr[-2000:]}")
+        note = _unique_tmp(_compiler_note(out))
+        note.write_text(_hipcc_id(hipcc))
+        os.replace(note, _compiler_note(out))
         os.replace(tmp, out)
     if verbose:
         print(f"built {out}")

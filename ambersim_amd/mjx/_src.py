@@ -78,9 +78,11 @@ class _Handle:
             try:
                 if specialise == "auto":
                     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-                    if not os.path.exists(hipcc):
-                        raise FileNotFoundError(f"{hipcc} not found")
-                    if not specialised_library_path(mj)[0].exists():
+                    prebuilt = specialised_library_path(mj)[0].exists()  # e.g. by `python -m ambersim_amd.prebuild model.xml` on a build host
+                    if not os.path.exists(hipcc) and not prebuilt:
+                        raise FileNotFoundError(f"{hipcc} not found (and no prebuilt library for this model under {specialised_library_path(mj)[0].parent}: "
+                                                f"`python -m ambersim_amd.prebuild <model>` makes one where hipcc is installed)")
+                    if not prebuilt:
                         log.warning("no kernels are compiled for this model's launch plan: building them with hipcc (about ten seconds, once; "
                                     "cached under %s; AMX_SPECIALISE=0 keeps the generic kernels)", specialised_library_path(mj)[0].parent)
                 L2 = _lib.load(build_specialised_library(mj))

@@ -206,6 +206,38 @@ def test_per_model_specialised_build():
     assert _spec.build_specialised_library(mj2).exists()
 
 
+def test_prebuild_cli_makes_what_a_host_without_hipcc_finds(tmp_path, monkeypatch):
+    """`python -m ambersim_amd.prebuild model.xml --cache-dir D` (r05) bakes a model's per-model kernels where hipcc is installed; a host
+    WITHOUT the compiler finds that library by the same key (record + sources + flags - the compiler's version is a note beside the
+    library, checked only where hipcc can be asked) instead of falling back to the generic kernels.  Here: the CLI builds the quadruped
+    at Newton 2 / 5 into a fresh directory and prints the path; with HIPCC pointing nowhere the cached build is still what
+    build_specialised_library returns; with a compiler whose version differs from the note the cache is NOT reused."""
+    import subprocess, sys
+    from ambersim_amd import _spec
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-m", "ambersim_amd.prebuild", "models/quadruped/quadruped.xml", "--iterations", "2", "--cache-dir", str(tmp_path)],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr[-1500:]
+    built = [f for f in os.listdir(tmp_path) if f.startswith("libamx_") and f.endswith(".so")]
+    assert len(built) == 1 and built[0] in r.stdout and os.path.exists(tmp_path / built[0].replace(".so", ".hipcc.txt"))
+    monkeypatch.setenv("AMX_CACHE_DIR", str(tmp_path))
+    mj = jit_test_model()  # the same plan: quadruped, two solver iterations
+    assert _spec.specialised_library_path(mj)[0].name == built[0]
+    monkeypatch.setenv("HIPCC", str(tmp_path / "no_such_hipcc"))
+    assert _spec.build_specialised_library(mj).name == built[0]  # no compiler here: the prebuilt library is taken as it is
+    fake = tmp_path / "other_hipcc"
+    fake.write_text("#!/bin/sh\necho 'HIP version: 0.0.0-other'\nexit 1\n")
+    fake.chmod(0o755)
+    monkeypatch.setenv("HIPCC", str(fake))
+    _spec._HIPCC_ID.clear()
+    with pytest.raises(RuntimeError, match="specialised build failed"):  # another compiler: rebuild attempted (and this stand-in cannot build)
+        _spec.build_specialised_library(mj)
+    _spec._HIPCC_ID.clear()
+    r = subprocess.run([sys.executable, "-m", "ambersim_amd.prebuild", "models/does_not_exist.xml", "--cache-dir", str(tmp_path)],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert r.returncode == 1 and "FAILED" in r.stderr
+
+
 def test_compiler_crash_fallback_is_pinned(tmp_path, monkeypatch):
     """A per-model build whose compile dies inside the compiler ("frontend command failed due to signal", seen once on ROCm 7.2's
     register allocator in r03; the source site that triggered it has since been rewritten, so no current plan reproduces it) is

@@ -4,7 +4,7 @@ means plus the derived figures bench.py and DESIGN.md quote.  python tools/pmc_t
 import os, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r04"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r05"
 G, waves, passes = 32, 2048, 1001  # 4096 envs x 1000 steps, two environments per wave
 if tag == "biped_rest":
     G, waves = 64, 4096  # sixteen contact slots: one environment per wave
