@@ -753,13 +753,15 @@ DEV void jtdj_rows_mfma(unsigned long long crows, int row_base, int J_base, int 
 
 template <int G>
 __device__ __noinline__ void build_H_mfma(int M_off, int H_off, int ld_, int n_, unsigned long long crows_, int ncon, int row_base, int J_base, int ldc_,
-                                          int slot_base_, int gl) {
+                                          int slot_base_, int gl, unsigned long long crows2_ = 0ull) {
   // arguments of an out-of-line function arrive in vector registers; these are wave-uniform, and saying so keeps the
   // loops and the chunk guards below on the scalar unit
   const int ld = __builtin_amdgcn_readfirstlane(ld_), n = __builtin_amdgcn_readfirstlane(n_), ldc = __builtin_amdgcn_readfirstlane(ldc_);
   const int slot_base = __builtin_amdgcn_readfirstlane(slot_base_);
   const unsigned long long crows = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(crows_ >> 32)) << 32) |
                                    (unsigned)__builtin_amdgcn_readfirstlane((int)crows_);
+  const unsigned long long crows2 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(crows2_ >> 32)) << 32) |
+                                    (unsigned)__builtin_amdgcn_readfirstlane((int)crows2_);  // second contact-row slot of a 64-lane group (r05)
   const int j = gl & 31;
   unsigned lo[4][4], hi[4][4];  // after the swaps: lo[q][r] = H[j][8q+r], hi[q][r] = H[j][8q+4+r] of the lane's environment
   const bool writer = (G == 32 || gl < 32) && j < n;
@@ -767,7 +769,7 @@ __device__ __noinline__ void build_H_mfma(int M_off, int H_off, int ld_, int n_,
   const float4 *mrow = reinterpret_cast<const float4 *>(lds + M_off + jr);
   float4 *hrow = reinterpret_cast<float4 *>(lds + H_off + jr);
   const int nch = ld >> 2;  // 16-byte chunks per row
-  jtdj_rows_mfma<G>(crows, row_base, J_base, ldc, slot_base, gl, lo, hi);
+  jtdj_rows_mfma<G>(crows, row_base, J_base, ldc, slot_base, gl, lo, hi, nullptr, crows2);
   // H row = M row + J'DJ row, two halves of four chunks: the four loads of a half are in flight together
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
@@ -3448,9 +3450,14 @@ struct Env {
     bool scalar_rows = true;  // wave-uniform: some equality / limit row is active
     if (G >= 32) {
       const unsigned long long act = __ballot(cact);
-      const unsigned long long rows = G == 32 ? ((act | (act >> 32)) & 0xFFFFFFFFull) : act;  // contact row active in any environment of the wave
+      unsigned long long rows = G == 32 ? ((act | (act >> 32)) & 0xFFFFFFFFull) : act;  // contact row active in any environment of the wave
+      unsigned long long rows2 = 0ull;  // second contact-row slot (r05: also on this path - models with joint-equality rows): as in the fused path
+      if constexpr (NBS == 2) {
+        const unsigned long long act2 = __ballot(c2act);
+        if (G == 32) rows |= ((act2 | (act2 >> 32)) & 0xFFFFFFFFull) << 32; else rows2 = act2;
+      }
       scalar_rows = wave_any(aact);
-      build_H_mfma<G>(Mo, Ho, ldm, nv, rows, m.ncon(), eb + m.e_row() + row0 * ROW_E, Jo, ldc, m.c_slot(), gl);
+      build_H_mfma<G>(Mo, Ho, ldm, nv, rows, m.ncon(), eb + m.e_row() + row0 * ROW_E, Jo, ldc, m.c_slot(), gl, rows2);
     } else {
       lds_copy<G>(Ho, Mo, nv * ldm, gl);
       WSYNC();
@@ -3523,6 +3530,12 @@ struct Env {
     r.q1 = a1 + (actB ? cJv * cJaref * cD : 0.0f);
     r.q2 = a2 + (actB ? 0.5f * cJv * cJv * cD : 0.0f);
     if (q0) *q0 = a0 + (actB ? 0.5f * cJaref * cJaref * cD : 0.0f);
+    if constexpr (NBS == 2) {  // second contact-row slot (a contact row: one-sided)
+      const bool actB2 = validB2() & (c2Jaref + alpha * c2Jv < 0);
+      r.q1 += actB2 ? c2Jv * c2Jaref * c2D : 0.0f;
+      r.q2 += actB2 ? 0.5f * c2Jv * c2Jv * c2D : 0.0f;
+      if (q0) *q0 += actB2 ? 0.5f * c2Jaref * c2Jaref * c2D : 0.0f;
+    }
     return r;
   }
   struct LSD { float alpha, d0, d1; };
@@ -3537,6 +3550,7 @@ struct Env {
     const float mv = mul_M_row(D_SEARCH);
     aJv = row_dot_A(D_SEARCH);
     cJv = row_dot_B(D_SEARCH);
+    if constexpr (NBS == 2) c2Jv = row_dot_B2(D_SEARCH);
     float sn = 0, g1 = 0, g2 = 0;
     {  // unconditional loads, selects at the end
       const int li = gl < nv ? gl : 0;
@@ -3876,7 +3890,7 @@ struct Env {
       if (!wave_any(alive)) break;
       PROF(12);
       float dec;
-      static_assert(NBS == 1 || (ls_v2_ok() && grad_in_solve()), "two contact-row slots: the planner gives them to models of the fused Newton path and the second-form line search only");
+      static_assert(NBS == 1 || (S::is_static && S::solver == 2 && G >= 32), "two contact-row slots: per-model Newton kernels on 32- / 64-lane groups");
       if constexpr (ls_v2_ok()) dec = linesearch_v2(alive);
       else dec = linesearch(alive);
       improvement = alive ? dec : improvement;

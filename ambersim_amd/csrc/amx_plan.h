@@ -478,13 +478,15 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
   // A lane's contact-row slot holds one row, so a 64-lane group carries 16 contacts.  Two slots per lane (rows gl and gl + G; r04) for
   // the models the per-model kernels' fused Newton path and second-form line search cover: contacts only (no equality, friction-loss,
   // connect / weld or ball-limit rows), Newton, nv <= 31, ls_iterations <= 10.  Such a model has no generic kernels (amx_model_create).
-  const bool two_ok = d->solver == 2 && m.neq == 0 && m.nfri == 0 && np == npc && nbl == 0 && nv <= 31 && d->ls_iterations <= 10 && !(d->disableflags & 1);
+  // (r05: joint-equality rows allowed too - the reference's Barrett hand, bh280.xml:195-200; their Newton path stores H and runs the
+  //  first-form line search, both of which carry the second slot since r05)
+  const bool two_ok = d->solver == 2 && m.nfri == 0 && np == npc && nbl == 0 && nv <= 31 && d->ls_iterations <= 10 && !(d->disableflags & 1);
   m.nbs = 1;
   if (two_ok && m.ncon > 16) m.nbs = 2;
   if (const char *force = getenv("AMX_FORCE_NBS")) { if (atoi(force) == 2 && two_ok && m.ncon > 4) m.nbs = 2; }  // diagnostic: two slots on a narrower group
   if (m.ncon > 16 * m.nbs)
     return fail(AMX_ECAPACITY, "%d contact slots (connect / weld row groups included) exceed %d (4 rows each; two rows per lane of a 64-lane group only for "
-                "contact-only Newton models with nv <= 31 and ls_iterations <= 10)", m.ncon, 16 * m.nbs);
+                "Newton models with nv <= 31 and ls_iterations <= 10 whose other rows are joint limits and joint equalities)", m.ncon, 16 * m.nbs);
   // lanes per environment: the smallest group that holds every lane-role index set.  A lane carries two constraint rows:
   // one equality / limit row and one contact row (amx_kernels.hip, Env), so the rows ask for max(neq + nlim, 4 ncon) lanes.
   {

@@ -343,9 +343,10 @@ def test_finger_fixtures_are_current():
     from conftest import GOLDEN
     if not os.path.exists("/root/reference/ambersim/models/barrett_hand/bh280.xml"):
         pytest.skip("reference not present on this machine")
-    names = ("bh280_twofingers.xml", "bh280_threefingers.xml")
+    names = ("bh280_twofingers.xml", "bh280_threefingers.xml", "bh280_ninehulls.xml")
     before = [open(os.path.join(GOLDEN, n)).read() for n in names]
     subprocess.run([sys.executable, os.path.join(GOLDEN, "make_bh280_twofingers.py")], check=True, capture_output=True)
+    subprocess.run([sys.executable, os.path.join(GOLDEN, "make_bh280_ninehulls.py")], check=True, capture_output=True)
     assert [open(os.path.join(GOLDEN, n)).read() for n in names] == before
 
 
@@ -405,6 +406,137 @@ def test_barrett_three_fingers_gpu_vs_oracle():
     e1 = np.minimum(np.abs(xs[:, 1] - ref[:, 1]).max(axis=1), np.abs(xs[:, 1] - ref32[:, 1]).max(axis=1)) / np.maximum(1.0, np.abs(ref[:, 1]).max(axis=1))
     e10 = np.minimum(np.abs(xs[:, 10] - ref[:, 10]).max(axis=1), np.abs(xs[:, 10] - ref32[:, 10]).max(axis=1)) / np.maximum(1.0, np.abs(ref[:, 10]).max(axis=1))
     print(f"bh280 three fingers: pairs in contact per env {np.bincount(npairs, minlength=4).tolist()}; 1-step err {e1.max():.2e}, 10-step err median {np.median(e10):.2e} max {e10.max():.2e}")
+    assert np.isfinite(xs).all() and e1.max() < 1e-5 and np.median(e10) < 1e-5 and e10.max() < 5e-5
+
+
+TOUCH9_Q = np.array([2.1931613, 0.84, 1.92933041, 2.39511336, 0.84, 2.39621383, 2.44, 0.84])  # nine-hull hand: two fingertips on the palm, all three on each other
+
+
+def ninehulls_model():
+    import os
+    from conftest import GOLDEN
+    mj = MjModel.from_xml_path(os.path.join(GOLDEN, "bh280_ninehulls.xml"))
+    mj.opt = mj.opt.replace(timestep=0.002, iterations=4, ls_iterations=8)
+    from ambersim_amd.mjcf import recompile_options
+    return recompile_options(mj)
+
+
+def _sat_depth(o, mj, pair):
+    """Penetration depth of one convex-convex pair by brute force, independent of oracle/amx_oracle.c and of the kernel: the least overlap of
+    the two hulls' projections over EVERY face normal of either hull and EVERY cross product of an edge of one with an edge of the other
+    (numpy, fp64, world frame from the oracle's body poses).  Negative = separated along some axis.  Any axis bounds the depth from above and
+    the minimum over this family is the depth of two convex polytopes, so no supporting-edge test is needed here."""
+    def world(g):
+        b = mj.geom_bodyid[g]
+        xq = o.get("xquat").reshape(-1, 4)[b]
+        w, x, y, z = xq
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        return R, o.get("xpos").reshape(-1, 3)[b]
+    out = []
+    for g, h in ((mj.pair_geom1[pair], mj.pair_hull1[pair]), (mj.pair_geom2[pair], mj.pair_hull2[pair])):
+        R, t = world(g)
+        assert np.allclose(mj.geom_pos[g], 0) and np.allclose(mj.geom_quat[g], [1, 0, 0, 0])  # the fixture's hulls sit at their bodies' origins
+        v = mj.hull_vert[mj.hull_vertadr[h]: mj.hull_vertadr[h] + mj.hull_vertnum[h]] @ R.T + t
+        n = mj.hull_face_normal[mj.hull_faceadr[h]: mj.hull_faceadr[h] + mj.hull_facenum[h]] @ R.T
+        e = mj.hull_edge[mj.hull_edgeadr[h]: mj.hull_edgeadr[h] + mj.hull_edgenum[h]]
+        out.append((v, n, v[e[:, 1]] - v[e[:, 0]]))
+    (va, na, ea), (vb, nb, eb) = out
+    cr = np.cross(ea[:, None, :], eb[None, :, :]).reshape(-1, 3)
+    ln = np.linalg.norm(cr, axis=1)
+    axes = np.concatenate([na, nb, cr[ln > 1e-9] / ln[ln > 1e-9, None]])
+    pa, pb = va @ axes.T, vb @ axes.T
+    return float(np.minimum(pa.max(axis=0) - pb.min(axis=0), pb.max(axis=0) - pa.min(axis=0)).min())
+
+
+def test_barrett_nine_hulls_touch():
+    """One hull on EVERY link of the reference's Barrett hand (r05 fixture bh280_ninehulls.xml: 32-vertex hulls on the distal links, 16
+    elsewhere; the reference's own file has 89 pieces, bh280.xml:58-183), eight body pairs selected by contype / conaffinity = 32 contact
+    slots - two contact rows per lane of a 64-lane group, for the first time on a model WITH joint-equality rows (the hand's four couplings,
+    bh280.xml:195-200; r04 allowed the second slot to contact-only models).  Structure; the launch plan; in the three-fingertip pose of the
+    r04 fixture the same three pairs interpenetrate by the same 0.0118 (they now sit in both row slots); every pair's depth agrees with a
+    brute-force separating-axis computation written independently in numpy; the contacts push the hand open."""
+    from ambersim_amd._spec import plan
+    mj = ninehulls_model()
+    assert (mj.nq, mj.nu, mj.neq, mj.ncon) == (8, 4, 4, 32) and mj.pair_fn.tolist() == [6] * 8
+    bodies = [(int(mj.geom_bodyid[a]), int(mj.geom_bodyid[b])) for a, b in zip(mj.pair_geom1, mj.pair_geom2)]
+    assert all(mj.body_parentid[b] != a and mj.body_parentid[a] != b for a, b in bodies)  # parent - child pairs are filtered
+    assert sorted(mj.hull_vertnum.tolist()) == [16] * 5 + [32] * 3 and mj.ngeom == 9  # (the hull of finger 3's medial link is in no pair: not tabulated)
+    p = plan(mj)
+    assert (p["G"], p["nbs"], p["nefc"], p["fusedH"]) == ("64", "2", "140", "0")  # 4 equalities + 8 limits + 128 pyramid rows; H is stored (equality rows)
+    o = Oracle(mj)
+    for q, expect_pairs in ((TOUCH3_Q, (3, 4, 7)), (TOUCH9_Q, (1, 2, 3, 4, 7))):
+        o.set_state(q, np.zeros(8), np.zeros(4)); o.forward()
+        d = o.get("con_dist").reshape(8, 4)
+        assert tuple(np.nonzero(d.min(axis=1) < 0)[0]) == expect_pairs
+        for pr in range(8):
+            depth = _sat_depth(o, mj, pr)
+            if pr in expect_pairs:
+                # the engine's axis is "the lowest index within 1e-4 of the least penetration": its deepest contact is that penetration
+                assert abs(-d[pr].min() - depth) < 2e-4 * depth + 1e-7, (pr, d[pr], depth)
+            else:
+                assert depth < 0 and (d[pr] > 0).all(), (pr, d[pr], depth)  # separated: no slot of the pair is active
+    o.set_state(TOUCH3_Q, np.zeros(8), np.zeros(4)); o.forward()
+    d0 = o.get("con_dist").reshape(8, 4).min(axis=1)
+    assert np.allclose(d0[[3, 4, 7]], -0.0118, atol=2e-4) and o.get("nefc")[0] == 4 + 3 * 4
+    xs = o.rollout(np.concatenate([TOUCH9_Q, np.zeros(8)]), np.zeros((1, 200, 4)))[0]
+    assert np.isfinite(xs).all()
+    o.set_state(xs[-1, :8], xs[-1, 8:], np.zeros(4)); o.forward()
+    assert o.get("con_dist").min() > -0.004  # (0.0146 at the start)
+    from ambersim_amd import _spec
+    assert _spec.build_specialised_library(mj).exists()  # the per-model kernels the GPU test of this model runs (cached in csrc/jit/; hipcc cross-compiles)
+
+
+@pytest.mark.gpu
+def test_barrett_nine_hulls_gpu_vs_oracle():
+    """The nine-hull hand on the HIP path (per-model kernels: 32 contact slots need the second contact row per lane, which the generic
+    kernels do not carry and say so): poses around the two touching ones, so that contacts of BOTH row slots are active together with limit
+    and equality rows.  Known answers on the HIP path alone: amx_forward's contact distances against the independent numpy separating-axis
+    depth.  Then the bars of the three-finger test against the oracle: one step within 1e-5, ten steps within 1e-5 in the median and 5e-5
+    at worst."""
+    import ctypes as C
+    import torch
+    from ambersim_amd import _lib, mjx
+    mj = ninehulls_model()
+    dev = torch.device("cuda", 0)
+    with pytest.raises(NotImplementedError, match="per-model kernels"):
+        mjx.put_model(mj, dev, specialise=False)
+    model = mjx.put_model(mj, dev, specialise=True)
+    assert model._h.query("specialised") == 1 and model._h.query("lanes_per_env") == 64
+    rng = np.random.default_rng(29)
+    nenv = 32
+    base = np.where(rng.random((nenv, 1)) < 0.5, TOUCH3_Q, TOUCH9_Q)
+    q = np.clip(base + 0.06 * rng.standard_normal((nenv, 8)), mj.jnt_range[:, 0] + 0.01, mj.jnt_range[:, 1] - 0.01)
+    q[0], q[1] = TOUCH3_Q, TOUCH9_Q
+    x0 = np.concatenate([q, 0.2 * rng.standard_normal((nenv, 8))], axis=1).astype(np.float32)
+    us = rng.uniform(-1, 1, (nenv, 10, 4)).astype(np.float32)
+    # known answers on the HIP path: contact distances of every pair vs the brute-force depth
+    cdist = torch.zeros((nenv, 32), device=dev)
+    tq, tv, tu = (torch.tensor(a, dtype=torch.float32, device=dev) for a in (x0[:, :8], x0[:, 8:], us[:, 0]))
+    out = _lib.AmxForwardOut(None, None, None, None, None, None, None, cdist.data_ptr(), None)
+    _lib.check(model._h.L.amx_forward(model._h.ptr, nenv, tq.data_ptr(), tv.data_ptr(), tu.data_ptr(), None, C.byref(out), None), model._h.L)
+    torch.cuda.synchronize()
+    cd = cdist.cpu().numpy().reshape(nenv, 8, 4)
+    o = Oracle(mj, np.float64)
+    second, npairs = 0, np.zeros(nenv, dtype=int)
+    for k in range(nenv):
+        o.set_state(x0[k, :8], x0[k, 8:], us[k, 0]); o.forward()
+        for pr in range(8):
+            depth = _sat_depth(o, mj, pr)
+            if depth > 1e-4:
+                assert abs(-cd[k, pr].min() - depth) < 2e-4 * depth + 2e-6, (k, pr, cd[k, pr], depth)
+            elif depth < -1e-4:
+                assert (cd[k, pr] > 0).all(), (k, pr, cd[k, pr], depth)
+        act = o.get("con_dist").reshape(8, 4).min(axis=1) < 0
+        npairs[k] = int(act.sum()); second += int(act[4:].any())
+    assert second >= nenv // 2 and (npairs >= 4).sum() >= 4, (second, npairs)  # the second row slot is exercised, several pairs at once
+    xs = mjx.rollout(model, torch.tensor(x0), torch.tensor(us)).cpu().numpy().astype(np.float64)
+    ref = Oracle(mj, np.float64).rollout(x0, us)
+    ref32 = Oracle(mj, np.float32).rollout(x0, us).astype(np.float64)
+    e1 = np.abs(xs[:, 1] - ref[:, 1]).max(axis=1) / np.maximum(1.0, np.abs(ref[:, 1]).max(axis=1))
+    e10 = np.minimum(np.abs(xs[:, 10] - ref[:, 10]).max(axis=1), np.abs(xs[:, 10] - ref32[:, 10]).max(axis=1)) / np.maximum(1.0, np.abs(ref[:, 10]).max(axis=1))
+    print(f"bh280 nine hulls: pairs in contact per env {np.bincount(npairs, minlength=6).tolist()}, second slot active in {second} envs; 1-step err {e1.max():.2e}, "
+          f"10-step err median {np.median(e10):.2e} max {e10.max():.2e}")
     assert np.isfinite(xs).all() and e1.max() < 1e-5 and np.median(e10) < 1e-5 and e10.max() < 5e-5
 
 
