@@ -781,8 +781,8 @@ def test_random_models_vs_oracle(dev):
     """Fuzz parity: 40 seeded random trees (tests/fuzz_models.py: free/ball/hinge/slide joints, several roots, limits,
     springs, armature, motors and position servos, a polynomial joint equality, sphere/capsule contacts, Newton and CG with
     random iteration counts) - every lane-group width and most index paths.  One step must agree with the fp64 oracle
-    to north_star's 1e-5, or to 3x the distance of the fp32 CPU oracle from it where fp32 itself cannot do better
-    (ill-conditioned draws); five steps to 5e-5 or 5x that floor.  Draws whose fp64 trajectory blows up are skipped."""
+    to north_star's 1e-5 (r05: plain - until r04 "or 3x the distance of the fp32 CPU oracle"; no draw of the suite needs that);
+    five steps to 5e-5 or 5x the fp32 CPU oracle's own distance.  Draws whose fp64 trajectory blows up are skipped."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from fuzz_models import random_inputs, random_model
@@ -827,10 +827,11 @@ def test_random_models_vs_oracle(dev):
         assert np.isfinite(xs).all(), seed
         e1, f1 = rel(xs[:, 1], ref[:, 1]), rel(ref32[:, 1], ref[:, 1])
         e5, f5 = rel(xs[:, 5], ref[:, 5]), rel(ref32[:, 5], ref[:, 5])
-        assert e1 <= max(TOL, 3 * f1), (seed, e1, f1)
+        assert e1 <= TOL, (seed, e1, f1)  # r05: the plain tolerance (r02 - r04 allowed 3x the fp32 CPU oracle's own error; no draw needs it: worst 7.8e-6)
         assert e5 <= max(5e-5, 5 * f5), (seed, e5, f5)
         tested += 1
         worst = max(worst, e1)
+    print(f"fuzz: {tested} models, worst one-step error {worst:.2e} (plain 1e-5 bound)")
     assert tested >= 30 and widths == {16, 32, 64}, (tested, widths)  # all three lane-group widths were exercised
 
 
