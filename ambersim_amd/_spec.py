@@ -206,7 +206,8 @@ def _cached_build_usable(out: Path) -> bool:
 # off.  tests/test_abi.py::test_compiler_crash_fallback_is_pinned holds the plan that needs it and checks that these two macros
 # gate nothing but the packed spellings of the same sums.
 CRASH_FALLBACK_FLAGS = ("-DAMX_PK_SV=0", "-DAMX_PK_DOT=0")
-_LAST_BUILD = {"path": None, "fallback": False}  # what the last compile in this process did (tests, logs)
+SCHED_FLAGS = ("-mllvm", "-amdgpu-sched-strategy=iterative-ilp")  # second retry: dropped (see build_specialised_library)
+_LAST_BUILD = {"path": None, "fallback": False, "stage": None}  # what the last compile in this process did (tests, logs)
 
 
 def build_specialised_library(mj, verbose: bool = False) -> Path:
@@ -229,19 +230,29 @@ def build_specialised_library(mj, verbose: bool = False) -> Path:
         tmp = _unique_tmp(out)
         cmd = [hipcc] + _extra_flags() + FLAGS + [f'-DAMX_SPECS_HEADER="{hdr}"', "-DAMX_NO_GENERIC=1", "-no-hip-rt", "-shared", "-o", str(tmp), "-x", "hip", str(_CSRC / "amx_api.cpp")]
         r = subprocess.run(cmd, capture_output=True, text=True, cwd=str(_CSRC))
-        _LAST_BUILD.update(path=str(out), fallback=False)
-        if r.returncode != 0 and "frontend command failed due to signal" in r.stderr and os.environ.get("AMX_SPEC_NO_RETRY", "0") in ("", "0"):
-            # ROCm 7.2's register allocator has crashed on one plan's packed-fp32 spatial sums (r03: a 16-lane model with two free
-            # bodies); the same kernels with those sums as scalar instructions compile.  Same arithmetic, the same HIP path.
-            first = r.stderr
-            cmd = cmd[:1] + list(CRASH_FALLBACK_FLAGS) + cmd[1:]
-            _LAST_BUILD.update(fallback=True)
+        _LAST_BUILD.update(path=str(out), fallback=False, stage=None)
+        crashed = lambda rr: rr.returncode != 0 and "frontend command failed due to signal" in rr.stderr
+        if crashed(r) and os.environ.get("AMX_SPEC_NO_RETRY", "0") in ("", "0"):
+            # ROCm 7.2's greedy register allocator crashes (a segmentation fault inside VirtRegAuxInfo::isRematerializable) on some plans'
+            # rollout kernels.  Two retries, each the same arithmetic on the same HIP path:
+            #  1. the packed-fp32 spellings of the spatial sums off (r03: a 16-lane model with two free bodies compiled that way);
+            #  2. the default machine scheduler instead of -amdgpu-sched-strategy=iterative-ilp (r05: a 32-lane CG model of the fuzz family,
+            #     tests/fuzz_models.py seed 1005, crashes with and without the packed forms and compiles so; the kernels lose the
+            #     latency-oriented schedule, ~10 % on the shipped models, and keep everything else).
             import logging
-            logging.getLogger("ambersim_amd").warning("hipcc crashed on this model's kernels (%s); rebuilding with %s", first.strip().splitlines()[-1][:120] if first.strip() else "",
-                                                      " ".join(CRASH_FALLBACK_FLAGS))
-            r = subprocess.run(cmd, capture_output=True, text=True, cwd=str(_CSRC))
+            log = logging.getLogger("ambersim_amd")
+            first = r.stderr
+            base = list(cmd)
+            ladder = (("packed_off", base[:1] + list(CRASH_FALLBACK_FLAGS) + base[1:], "with " + " ".join(CRASH_FALLBACK_FLAGS)),
+                      ("default_scheduler", [a for a in base if a not in SCHED_FLAGS], "without " + " ".join(SCHED_FLAGS)))
+            for stage, cmd, what in ladder:
+                _LAST_BUILD.update(fallback=True, stage=stage)
+                log.warning("hipcc crashed on this model's kernels (%s); rebuilding %s", first.strip().splitlines()[-1][:120] if first.strip() else "", what)
+                r = subprocess.run(cmd, capture_output=True, text=True, cwd=str(_CSRC))
+                if not crashed(r):
+                    break
             if r.returncode != 0:
-                r.stderr = first[-1000:] + "\n--- retry without packed fp32 ---\n" + r.stderr
+                r.stderr = first[-1000:] + "\n--- after the retries ---\n" + r.stderr
         if r.returncode != 0:
             try:
                 tmp.unlink()

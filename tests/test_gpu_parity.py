@@ -295,6 +295,24 @@ def test_crash_fallback_build_matches_the_oracle(cases, dev, monkeypatch):
         assert rel(b[:, 1], ref[:, 1]) < TOL and rel(a[:, 3], b[:, 3]) < 5e-5
 
 
+def test_per_model_build_of_the_plan_that_crashes_the_compiler(dev):
+    """tests/fuzz_models.py seed 1005 (see tests/test_abi.py::test_a_plan_that_crashes_the_compiler_still_gets_its_kernels: built through the retry
+    ladder, with the default machine scheduler): the per-model kernels against the fp64 oracle, and against the generic kernels."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from fuzz_models import random_inputs, random_model
+    from ambersim_amd import mjx
+    from oracle.oracle import Oracle
+    mj = random_model(1005)
+    x0, us = random_inputs(mj, 1005, 8, 5)
+    x0, us = x0.astype(np.float32), us.astype(np.float32)
+    model = mjx.put_model(mj, dev, specialise=True)
+    assert model._h.query("specialised") == 1
+    xs, xg = gpu_rollout(model, x0, us), gpu_rollout(mjx.put_model(mj, dev, specialise=False), x0, us)
+    ref = Oracle(mj, np.float64).rollout(x0, us)
+    assert rel(xs[:, 1], ref[:, 1]) < TOL and rel(xs[:, 5], ref[:, 5]) < 5e-5 and rel(xs[:, 5], xg[:, 5]) < 5e-5
+
+
 def test_step_api_matches_rollout_bitwise(cases):
     """amx_step (state through HBM each call, warm start carried) and amx_rollout (state in LDS) run the same phases:
     identical bits after 20 steps."""
