@@ -146,6 +146,23 @@ DEV f3 mulTv(const m33 &M, f3 v) {
              M.a[2] * v.x + M.a[5] * v.y + M.a[8] * v.z);
 }
 DEV f3 qrot(f4 q, f3 v) { return mulv(q2m(q), v); }
+// The same rotation for ONE vector per quaternion (r05 experiment): v + 2 u x (u x v + w v), u = (x, y, z) - 18 multiply-adds where the matrix
+// route costs 21 to form R and 9 per vector; at the levels of the pose composition, a body's centre of mass, a geom's offset.  MEASURED AND
+// REJECTED: -165 static vector instructions, +0.6 % throughput - and noisier poses (the form cancels v against 2 u x (u x v) for large rotations):
+// the hard-impact worst case went 9.9e-6 -> 1.3e-5 and one fuzz draw 8e-6 -> 1.3e-5, over the tolerance.  Off; kept as an A/B switch.
+#ifndef AMX_QROT1
+#define AMX_QROT1 0  // 1: single-vector rotations without the 3 x 3 matrix (A/B switch)
+#endif
+DEV f3 qrot1(f4 q, f3 v) {
+#if AMX_QROT1
+  const f3 u = mk3(q.x, q.y, q.z);
+  const f3 t = mk3(__builtin_fmaf(q.w, v.x, u.y * v.z - u.z * v.y), __builtin_fmaf(q.w, v.y, u.z * v.x - u.x * v.z), __builtin_fmaf(q.w, v.z, u.x * v.y - u.y * v.x));
+  const f3 c = cross(u, t);
+  return mk3(__builtin_fmaf(2.0f, c.x, v.x), __builtin_fmaf(2.0f, c.y, v.y), __builtin_fmaf(2.0f, c.z, v.z));
+#else
+  return qrot(q, v);
+#endif
+}
 // x / y without the IEEE expansion (two v_div_scale, v_div_fmas, v_div_fixup around the same v_rcp_f32): reciprocal, one
 // residual correction.  Within 1 ulp of the correctly rounded quotient for operands whose reciprocal neither overflows nor
 // goes denormal - used where the operands are sums of squares, clamped pivots and step lengths (AMX_IEEE_DIV=1: plain x / y).
@@ -2228,10 +2245,10 @@ struct Env {
             q = qnormalize(q);
             lds[qa] = q.w; lds[qa + 1] = q.x; lds[qa + 2] = q.y; lds[qa + 3] = q.z;
             quat = qmul(quat, q);
-            pos = anchor - qrot(quat, jpos);
+            pos = anchor - qrot1(quat, jpos);
           } else if (t_ == JHINGE) {
             quat = qmul(quat, axisangle(jax, lds[qa] - CF(jr + 10)));
-            pos = anchor - qrot(quat, jpos);
+            pos = anchor - qrot1(quat, jpos);
           } else {
             pos = pos + axis * (lds[qa] - CF(jr + 10));
           }
@@ -2269,7 +2286,7 @@ struct Env {
 #pragma unroll
       for (int k = 1; k < W; ++k) {
         const int a = CI(ar + k);
-        ap = ap + qrot(aq, ld_xpos(a));
+        ap = ap + qrot1(aq, ld_xpos(a));
         aq = qmul(aq, ld_xquat(a));
       }
       const m33 Rp = q2m(aq);  // (ap, aq) is the parent's world pose
@@ -2335,7 +2352,7 @@ struct Env {
     const float ms = isb ? CF(br + 21) : 0.0f;
     if (isb) {
       xq = ld_xquat(b);
-      xi = ld_xpos(b) + qrot(xq, mk3(CF(br + 14), CF(br + 15), CF(br + 16)));
+      xi = ld_xpos(b) + qrot1(xq, mk3(CF(br + 14), CF(br + 15), CF(br + 16)));
     }
     for (int r = 0; r < m.nroot(); ++r) {
       const bool mine = isb && b_root == r;
@@ -2398,7 +2415,7 @@ struct Env {
     if (gl < m.ngc()) {
       const int g = gl, gr = m.c_geom() + g * GEOM_S, gb = CI(gr);
       const f4 q = ld_xquat(gb);
-      const f3 pos = ld_xpos(gb) + qrot(q, mk3(CF(gr + 2), CF(gr + 3), CF(gr + 4)));
+      const f3 pos = ld_xpos(gb) + qrot1(q, mk3(CF(gr + 2), CF(gr + 3), CF(gr + 4)));
       const f4 gq = {CF(gr + 5), CF(gr + 6), CF(gr + 7), CF(gr + 8)};
       const m33 R = q2m(qmul(q, gq));
       geo(0, g) = pos.x; geo(1, g) = pos.y; geo(2, g) = pos.z;
