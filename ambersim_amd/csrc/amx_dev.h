@@ -55,7 +55,7 @@ enum { CX_MAXV = 64, CX_MAXF = 128, CX_MAXE = 192, CX_MAXP = 16, CX_TAIL = 6 * C
   X(fusedH) /* 1: Newton eliminates H in registers, no H buffer (G >= 32, no equality rows) */                            \
   X(mfma2) /* 1: the contacts belong to exactly two pairs (two feet): J'DJ runs chain-compressed on the 4-block 16x16 matrix instruction, one block per (environment, pair) - amx_kernels.hip, newton_solve_pair2 */ X(p2_shl0) X(p2_shl1) /* row shift that takes a pair's rows from their lanes in the other 16-lane row to their dofs' lanes */ X(p2_banks) /* four 4-bit DPP bank masks: home adds of pair 0 | of pair 1 << 4 | cross adds into pair 1's row-0 dofs << 8 | into pair 0's row-1 dofs << 12 */ \
   X(nchol) X(njac) X(nhent) X(subtree_contig) /* 1: every body's descendants are the bodies right after it (field 6 of the body record carries the end) */ X(sub_iter) /* largest subtree (bodies, itself included) below the tree roots */ X(deep_free) /* 1: a free joint below the first tree level (the chain-walking velocity pass assumes none) */ X(max_dofmem) /* most contacts any one dof takes part in */ X(max_jntnum) /* most joints on one body */ X(max_bgrp) /* most dof groups on one body (c_bgrp) */ X(jac_one_sided) /* 1: every contact Jacobian entry belongs to the chain of geom2's body alone (geom1 on a body without dofs: the ground) */                                                                                               \
-  X(nbs) /* contact-row slots per lane: 1, or 2 (r04; per-model kernels of contact-only Newton models): rows gl and gl + G */ X(cx_first) X(ncx) X(cx_maxv) /* run of convex-convex pairs (fn 6), processed one after the other by the whole lane group */         \
+  X(nbs) /* contact-row slots per lane: 1, or 2 (r04; per-model kernels of Newton models with limit / joint-equality rows besides): rows gl and gl + G */ X(cx_first) X(ncx) X(cx_maxv) /* run of convex-convex pairs (fn 6), processed one after the other by the whole lane group */         \
   X(pcx_first) X(npcx) /* run of plane - convex pairs (<= 32 hull vertices) handled one lane per vertex; npcx = 0: none */ X(pcx_unit) /* lanes per pair in that routine: 16 when every hull of the run has at most 16 vertices, else 32 */   \
   X(iterations) X(ls_iterations) X(solver) X(disableflags)                                                                 \
   X(G)   /* lanes per environment: 16, 32 or 64 */                                                                         \
