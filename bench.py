@@ -408,7 +408,7 @@ def worker(args):
     if rank == 0:
         env_steps = args.nenv * args.horizon * args.steps * world
         tag = {QUADRUPED: "BASELINE.md C2", BIPED: "BASELINE.md C3 per GPU / C5 sharded; legacy: random torques, feet-only contact",
-               BIPED_STAND: "BASELINE.md C3 per GPU / C5 sharded; held standing on its convex-mesh feet by joint position servos",
+               BIPED_STAND: "BASELINE.md C3 per GPU / C5 sharded; held standing on its convex-mesh feet by joint position servos; since r05 the soles are an irregular hexagon on which MJX's 4-point manifold heuristic has no ties (DESIGN.md 6) - same vertex count and launch plan",
                BIPED_REST: "BASELINE.md C3 per GPU / C5 sharded; random torques, falls and rests on eight extra contact spheres"}.get(model_path, "custom")
         out = {
             "metric": "env-steps/sec, 4096 envs x 1000-step rollout",
