@@ -806,6 +806,9 @@ __device__ __noinline__ void build_H_mfma(int M_off, int H_off, int ld_, int n_,
   WSYNC();
 }
 
+// (defined behind the symmetric eliminations below: the generic solves use them since r05)
+template <int N, int G> constexpr bool dense_sym_ok();
+template <int N, int G> DEV float dense_sym_solve(float (&a)[N], float b, int gl);
 template <int N, int G>
 __device__ __noinline__ void spd_solve_rows(int A_off, int ld, int n, int rhs_off, int x_off, int vstride, int gl, int gb4, int rot) {
   float a[N];
@@ -828,6 +831,12 @@ __device__ __noinline__ void spd_solve_rows(int A_off, int ld, int n, int rhs_of
   }
   float b = lds[rhs_off + li * vstride];
   b = gl < n ? b : 0.0f;
+  if constexpr (dense_sym_ok<N, G>()) {
+    const float x = dense_sym_solve<N, G>(a, b, gl);
+    if (gl < n) lds[x_off + gl * vstride] = x;
+    WSYNC();
+    return;
+  }
   GJ<N, G, 0>::run(a, b, gl, gb4);
   // the matrix is now diagonal: x_i = b_i / a_ii.  a[gl] is a runtime register index, so select it.
   float d = 1.0f;
@@ -1198,6 +1207,38 @@ template <class S, int G, bool TREE, bool BCOL> DEV void sym_eliminate(float (&a
 #endif
 template <class S, int G> constexpr bool sym_elim_ok() { return S::is_static && (G <= 32 ? S::nv < G : (AMX_SYM_ELIM_64 && S::nv < 32)) && !AMX_NO_SYM_ELIM; }
 
+// ---- the generic kernels' eliminations without the crossbar (r05).  The run-time descriptor fixes neither the size nor the dof tree, so the
+// generic solves dispatch on the padded size N (spd_solve, newton_fused_dyn) and broadcast every pivot-row entry through the LDS crossbar
+// (gj_pivot: one ds_swizzle per updated column, ~450 cycles per pivot).  The matrices they are handed are bitwise symmetric like the static
+// kernels' (M is stored symmetric, J'DJ comes from sqrt(D) J on both operands, the scattered rows add the same value to both mirror entries in
+// the same order), so the symmetric DPP elimination applies as it stands: DENSE order (every column after the pivot: no tree at compile time),
+// right-hand side broadcast on its own (no mirror row).  Padding rows are identity rows, lanes past N hold zero rows.
+// MEASURED, OFF (r05): headline model on the generic kernels 54.3 -> 59.9 M env-steps/s (the eliminations are not what holds the generic kernels
+// back most: run-time loop bounds, 421 scalar spills, no fused Newton forms), and the 1,050-model sweep moved by noise - but one convex draw of the
+// test suite (seed 9) goes 8e-6 -> 1.6e-5, over its bar.  The generic kernels keep their true-row crossbar eliminations.
+#ifndef AMX_GENERIC_SYM
+#define AMX_GENERIC_SYM 0  // 1: dense symmetric DPP eliminations in the generic kernels (A/B switch)
+#endif
+template <int NN> struct DenseN {
+  static constexpr int nv = NN;
+  static constexpr int dof_parent[32] = {};
+};
+template <int N, int G> constexpr bool dense_sym_ok() {
+  return AMX_GENERIC_SYM && AMX_SYM_EXACT && !AMX_PIVOT_CLAMP && !AMX_PIVOT_VCMP && !AMX_TRUE_ROW_ELIM && !AMX_NO_SYM_ELIM && (G <= 32 ? N < G : N < 32);
+}
+// solves in place: on return b is the lane's solution component (lanes without a row: garbage, never stored)
+template <int N, int G> DEV float dense_sym_solve(float (&a)[N], float b, int gl) {
+  float aa[N + 1];
+#pragma unroll
+  for (int k = 0; k < N; ++k) aa[k] = a[k];
+  aa[N] = b;
+  float d = 1.0f;
+  int gle = gl;
+  asm volatile("" : "+v"(gle));
+  sym_eliminate<DenseN<N>, G, false, false>(aa, gle, d);
+  return fdiv(aa[N], fmaxf(d, MINVAL));
+}
+
 template <class S, int G, bool TREE>
 AMX_STATIC_SOLVE_ATTR void spd_solve_static(int A_off, int rhs_off, int x_off, int gl, int rot, int bt_off) {
   constexpr int N = S::nv, ld = S::ldm, nch = ld / 4;
@@ -1449,6 +1490,12 @@ AMX_STATIC_SOLVE_ATTR bool newton_solve_fused(int M_off, int ld_, int n_, unsign
   }
   float b = lds[rhs_off + li * DOF_E];
   b = owner ? b : 0.0f;
+  if constexpr (!S::is_static && dense_sym_ok<N, G>()) {
+    const float x = dense_sym_solve<N, G>(a, b, gl);
+    if (owner) lds[x_off + gl * DOF_E] = x;
+    WSYNC();
+    return false;
+  }
   if constexpr (S::is_static && TREE) GJTree<S, G, N - 1>::run(a, b, gl);
   else GJ<N, G, 0>::run(a, b, gl, gb4);
   float d = 1.0f;
