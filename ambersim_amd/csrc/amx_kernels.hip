@@ -1536,6 +1536,19 @@ DEV void p2_fence(float (&r)[16]) {
   asm volatile("s_nop 1" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]), "+v"(r[10]),
                "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]));
 }
+// the same for the first N registers of an eight-entry array (the registers in use: an unused one named in the statement would have to be
+// materialised - cleared - just to pass through it)
+template <int N> DEV void p2_fence_n(float (&r)[8]) {
+  static_assert(N >= 0 && N <= 8, "p2_fence_n");
+  if constexpr (N == 1) asm volatile("s_nop 1" : "+v"(r[0]));
+  if constexpr (N == 2) asm volatile("s_nop 1" : "+v"(r[0]), "+v"(r[1]));
+  if constexpr (N == 3) asm volatile("s_nop 1" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]));
+  if constexpr (N == 4) asm volatile("s_nop 1" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]));
+  if constexpr (N == 5) asm volatile("s_nop 1" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]));
+  if constexpr (N == 6) asm volatile("s_nop 1" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]));
+  if constexpr (N == 7) asm volatile("s_nop 1" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]));
+  if constexpr (N == 8) asm volatile("s_nop 1" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]));
+}
 template <class S, bool TREE>
 AMX_STATIC_SOLVE_ATTR bool newton_solve_pair2(int M_off, unsigned long long crows_, int row_base, int J_base, int rhs_off, int x_off, float dlim, int gl, int gb4, int rot,
                                                 int bt_off, float flim, float ma_v, float fs_v, int fcon_off, bool store_ok, bool early_out, bool imp_done, float scale,
@@ -1579,7 +1592,7 @@ AMX_STATIC_SOLVE_ATTR bool newton_solve_pair2(int M_off, unsigned long long crow
   // the A operand's address: entry sA of the row's Jacobian, or - the lane that carries the residual - field 2 of the row record
   const int JA = augA ? Dr + 2 : J_base + 16 * f * S::ldc + (hasA ? sA : 0), strideA = augA ? ROW_E : S::ldc;
   const unsigned tm = (crows_u | (crows_u >> 16)) & 0xFFFFu;  // row t of either pair active in some environment of the wave
-  v16acc C = {};
+  v16acc C;
   // All sixteen rows, straight-line, in two batches of eight: the operand loads of a batch are in flight together and the next
   // batch's behind this batch's instructions.  (As a loop over the active rows every row was an LDS round trip in front of its
   // 32-cycle instruction: 3.2 k cycles per Hessian for 0.5 k of matrix pipe.)  An inactive row has D = 0 in its record: its
@@ -1589,17 +1602,29 @@ AMX_STATIC_SOLVE_ATTR bool newton_solve_pair2(int M_off, unsigned long long crow
 #pragma unroll
     for (int k = 0; k < 8; ++k) { const int t = t0 + k; o[k] = Ops{lds[Dr + t * ROW_E], lds[JA + t * strideA], lds[JB + t * S::ldc]}; }
   };
-  auto issue8 = [&](const Ops (&o)[8]) {
+  // (first: the batch that starts the accumulator takes the instruction's constant 0 operand for its first row - clearing sixteen registers
+  //  with v_mov first cost as much vector time as the batch's own operand multiplies; r05)
+  auto issue8 = [&](const Ops (&o)[8], auto first) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-      C = __builtin_amdgcn_mfma_f32_16x16x1f32(o[k].d * ((hasA | augA) ? o[k].ja : 0.0f), AMX_SQRT_D ? o[k].d * (hasB ? o[k].jb : 0.0f) : (hasB ? o[k].jb : 0.0f), C, 0, 0, 0);
+    for (int k = 0; k < 8; ++k) {
+      const float av = o[k].d * ((hasA | augA) ? o[k].ja : 0.0f), bv = AMX_SQRT_D ? o[k].d * (hasB ? o[k].jb : 0.0f) : (hasB ? o[k].jb : 0.0f);
+      if (decltype(first)::value && k == 0) { const v16acc Z = {}; C = __builtin_amdgcn_mfma_f32_16x16x1f32(av, bv, Z, 0, 0, 0); }
+      else C = __builtin_amdgcn_mfma_f32_16x16x1f32(av, bv, C, 0, 0, 0);
+    }
   };
   if (tm != 0u) {
     Ops o0[8], o1[8];
     load8(0, o0);
     load8(8, o1);
-    if (tm & 0x00FFu) issue8(o0);
-    if (tm & 0xFF00u) issue8(o1);
+    if (tm & 0x00FFu) {
+      issue8(o0, std::true_type{});
+      if (tm & 0xFF00u) issue8(o1, std::false_type{});
+    } else {
+      issue8(o1, std::true_type{});
+    }
+  } else {
+    const v16acc Z = {};
+    C = Z;
   }
   PROF_CTX(pc, 25);
   if (owner) lds[dg] = d0;  // M's own diagonal back (the row loads above are done: one wave's LDS operations execute in order)
@@ -1633,36 +1658,38 @@ AMX_STATIC_SOLVE_ATTR bool newton_solve_pair2(int M_off, unsigned long long crow
   // (the planner fills the registers from 0 upward: the used ones are 0 .. NK - 1)
   // Two rounds, so that every swap works in place: all first swaps, their four adds per pair (the last readers of the results),
   // then all second swaps on the same registers, and the remaining adds.
-  float P[16], Q[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) { P[k] = 0.0f; Q[k] = 0.0f; }
+  // (P, Q: one register per PAIR of columns, entries k / 2; r05: sixteen-entry arrays passed whole through the fences had their unused half
+  //  cleared with v_mov on every Hessian)
+  constexpr int NP = (NK + 1) / 2;
+  float P[8], Q[8];
 #pragma unroll
   for (int k = 0; k < NK; k += 2) {
     const int k2 = k + 1 < NK ? k + 1 : k;  // an odd register count: the last one pairs with itself (both results come out of one swap)
     auto s1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(R[k]), __float_as_uint(R[k2]), false, false);  // (k.r0, k'.r0), (k.r1, k'.r1)
-    P[k] = __uint_as_float(s1[0]); Q[k] = __uint_as_float(s1[1]);
+    P[k / 2] = __uint_as_float(s1[0]); Q[k / 2] = __uint_as_float(s1[1]);
   }
-  p2_fence(P);
-  p2_fence(Q);
+  p2_fence_n<NP>(P);
+  p2_fence_n<NP>(Q);
 #pragma unroll
   for (int k = 0; k < NK; k += 2) {
     const int k2 = k + 1 < NK ? k + 1 : k;
     // rows 0 / 2 read k.r1 = pair 1's entries of register k; rows 1 / 3 read k'.r0 = pair 0's entries of register k'
-    if (S::p2_col[16 + k] >= 0) p2_add<S::p2_shl1, 0x5, BC0>(a[S::p2_col[16 + k] >= 0 ? S::p2_col[16 + k] : 0], Q[k]);
-    if (S::p2_col[k2] >= 0) p2_add<S::p2_shl0, 0xA, BC1>(a[S::p2_col[k2] >= 0 ? S::p2_col[k2] : 0], P[k]);
+    if (S::p2_col[16 + k] >= 0) p2_add<S::p2_shl1, 0x5, BC0>(a[S::p2_col[16 + k] >= 0 ? S::p2_col[16 + k] : 0], Q[k / 2]);
+    if (S::p2_col[k2] >= 0) p2_add<S::p2_shl0, 0xA, BC1>(a[S::p2_col[k2] >= 0 ? S::p2_col[k2] : 0], P[k / 2]);
   }
+  constexpr int NP2 = NK / 2;  // pairs with two distinct registers: the second round of swaps
 #pragma unroll
   for (int k = 0; k + 1 < NK; k += 2) {
-    auto s2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(Q[k]), __float_as_uint(P[k]), false, false);  // (k.r1, k.r0), (k'.r1, k'.r0)
-    P[k] = __uint_as_float(s2[0]); Q[k] = __uint_as_float(s2[1]);
+    auto s2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(Q[k / 2]), __float_as_uint(P[k / 2]), false, false);  // (k.r1, k.r0), (k'.r1, k'.r0)
+    P[k / 2] = __uint_as_float(s2[0]); Q[k / 2] = __uint_as_float(s2[1]);
   }
-  p2_fence(P);
-  p2_fence(Q);
+  p2_fence_n<NP2>(P);
+  p2_fence_n<NP2>(Q);
 #pragma unroll
   for (int k = 0; k + 1 < NK; k += 2) {
     // rows 1 / 3 read k.r0 = pair 0's entries of register k; rows 0 / 2 read k'.r1 = pair 1's entries of register k'
-    if (S::p2_col[k] >= 0) p2_add<S::p2_shl0, 0xA, BC1>(a[S::p2_col[k] >= 0 ? S::p2_col[k] : 0], P[k]);
-    if (S::p2_col[16 + k + 1] >= 0) p2_add<S::p2_shl1, 0x5, BC0>(a[S::p2_col[16 + k + 1] >= 0 ? S::p2_col[16 + k + 1] : 0], Q[k]);
+    if (S::p2_col[k] >= 0) p2_add<S::p2_shl0, 0xA, BC1>(a[S::p2_col[k] >= 0 ? S::p2_col[k] : 0], P[k / 2]);
+    if (S::p2_col[16 + k + 1] >= 0) p2_add<S::p2_shl1, 0x5, BC0>(a[S::p2_col[16 + k + 1] >= 0 ? S::p2_col[16 + k + 1] : 0], Q[k / 2]);
   }
   PROF_CTX(pc, 26);
   const float b = owner ? a[NS] : 0.0f;  // the gradient ma - fs - flim - J'f
