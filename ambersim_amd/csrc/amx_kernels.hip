@@ -1612,6 +1612,9 @@ AMX_STATIC_SOLVE_ATTR bool newton_solve_pair2(int M_off, unsigned long long crow
       else C = __builtin_amdgcn_mfma_f32_16x16x1f32(av, bv, C, 0, 0, 0);
     }
   };
+  if (owner) lds[dg] = d0;  // M's own diagonal back (the row loads above are done: one wave's LDS operations execute in order)
+  // No row active anywhere in the wave: nothing to add to the rows of M (one scalar branch around the whole product; r05 - merged with an
+  // all-zero accumulator the compiler cleared sixteen registers in front of the branch on every Hessian)
   if (tm != 0u) {
     Ops o0[8], o1[8];
     load8(0, o0);
@@ -1622,12 +1625,7 @@ AMX_STATIC_SOLVE_ATTR bool newton_solve_pair2(int M_off, unsigned long long crow
     } else {
       issue8(o1, std::true_type{});
     }
-  } else {
-    const v16acc Z = {};
-    C = Z;
-  }
   PROF_CTX(pc, 25);
-  if (owner) lds[dg] = d0;  // M's own diagonal back (the row loads above are done: one wave's LDS operations execute in order)
   // ---- transpose: register 4 b + r of lane (g, j) holds entry 4 g + r of column j of block b; wanted: lane (b, j) holds entries
   // 4 g' + r, g' = 0..3, of column j of ITS block.  Per r a 4 x 4 transpose of 16-lane row pieces among four registers: two
   // v_permlane16_swap (rows 0 <-> 1, 2 <-> 3 between register pairs) and two v_permlane32_swap (rows {2, 3} <-> {0, 1}).
@@ -1690,6 +1688,7 @@ AMX_STATIC_SOLVE_ATTR bool newton_solve_pair2(int M_off, unsigned long long crow
     // rows 1 / 3 read k.r0 = pair 0's entries of register k; rows 0 / 2 read k'.r1 = pair 1's entries of register k'
     if (S::p2_col[k] >= 0) p2_add<S::p2_shl0, 0xA, BC1>(a[S::p2_col[k] >= 0 ? S::p2_col[k] : 0], P[k / 2]);
     if (S::p2_col[16 + k + 1] >= 0) p2_add<S::p2_shl1, 0x5, BC0>(a[S::p2_col[16 + k + 1] >= 0 ? S::p2_col[16 + k + 1] : 0], Q[k / 2]);
+  }
   }
   PROF_CTX(pc, 26);
   const float b = owner ? a[NS] : 0.0f;  // the gradient ma - fs - flim - J'f
