@@ -325,3 +325,24 @@ def test_inline_assembly_dpp_reads_keep_their_wait_states():
     r = subprocess.run(["python3", os.path.join(ROOT, "tools", "check_dpp_hazard.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
     assert int(r.stdout.strip().splitlines()[-1].split()[0]) > 1000  # the check saw the eliminations
+
+
+def test_hazard_checker_knows_both_rules(tmp_path):
+    """The checker itself, on three hand-written snippets: a DPP read one wait state behind its producer is flagged, the same read behind an
+    `s_nop 1` is not, and - the rule r05 added after an assembly block consumed a compiler-emitted v_rsq_f32's result with no wait state,
+    silently corrupting every elimination - a transcendental's result read by the very next vector instruction is flagged too."""
+    tool = os.path.join(ROOT, "tools", "check_dpp_hazard.py")
+    def run(text):
+        f = tmp_path / "k.s"
+        f.write_text("_Zkernel:\n" + "".join("\t" + l + "\n" for l in text))
+        r = subprocess.run(["python3", tool, str(f)], capture_output=True, text=True)
+        return r.returncode, r.stdout
+    dpp = "v_fmac_f32_dpp v1, v2, v3 row_newbcast:5 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+    rc, out = run(["v_mul_f32 v2, v4, v5", "v_add_f32 v9, v9, v9", dpp])
+    assert rc == 1 and "HAZARD" in out
+    rc, out = run(["v_mul_f32 v2, v4, v5", "s_nop 1", dpp])
+    assert rc == 0, out
+    rc, out = run(["v_rsq_f32_dpp v32, v30 row_newbcast:13 row_mask:0xf bank_mask:0xf bound_ctrl:1", "v_mul_f32 v68, v31, v32"])
+    assert rc == 1 and "TRANS HAZARD" in out
+    rc, out = run(["v_rsq_f32_e32 v32, v30", "s_lshl_b64 s[0:1], s[2:3], 5", "v_mul_f32 v68, v31, v32"])
+    assert rc == 0, out
