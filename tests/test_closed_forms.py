@@ -659,3 +659,36 @@ def test_connect_weld_rows_gpu(xml):
         e1 = np.abs(xs[:, 1] - ref[:, 1]).max() / max(1.0, np.abs(ref[:, 1]).max())
         e10 = np.abs(xs[:, 10] - ref[:, 10]).max() / max(1.0, np.abs(ref[:, 10]).max())
         assert e1 < max(1e-5, 3 * floor1) and e1 < 1e-4 and e10 < max(5e-5, 3 * floor10) and e10 < 1e-3, (spec, e1, floor1, e10, floor10)
+
+
+def test_foot_mesh_mass_com_and_inertia_by_independent_integration():
+    """The headline model's feet are convex meshes whose mass, centre of mass and principal inertia the model compiler derives from the density
+    (ambersim_amd/mjcf.py: its own hull and its own polyhedral integration) - values the oracle, the kernel and every fixture then share.  Pinned
+    here by an independent route: qhull's hull of the same twelve vertices (scipy), integrated tetrahedron by tetrahedron from an interior point
+    in numpy (volume, first and second moments in closed form per tetrahedron), density 700."""
+    from scipy.spatial import ConvexHull
+    from ambersim_amd.utils.io_utils import load_mj_model_from_file
+    mj = load_mj_model_from_file("models/biped/biped_stand.xml")
+    mesh = mj.names_mesh.index("foot") if hasattr(mj.names_mesh, "index") else 0
+    V = np.asarray(mj.mesh_vert[mj.mesh_vertadr[mesh]: mj.mesh_vertadr[mesh] + mj.mesh_vertnum[mesh]], dtype=float)
+    assert V.shape == (12, 3)
+    h = ConvexHull(V)
+    assert len(h.vertices) == 12  # every vertex of the file is a hull vertex (the planner's tables count on it)
+    c0 = V[h.vertices].mean(axis=0)
+    vol, first, second = 0.0, np.zeros(3), np.zeros((3, 3))
+    for tri in h.simplices:
+        a, b, c = V[tri] - c0
+        v = abs(np.dot(a, np.cross(b, c))) / 6.0
+        s = a + b + c
+        vol += v
+        first += v * s / 4.0
+        second += v / 20.0 * (np.outer(a, a) + np.outer(b, b) + np.outer(c, c) + np.outer(s, s))
+    com = first / vol
+    second -= vol * np.outer(com, com)
+    inertia = 700.0 * (np.trace(second) * np.eye(3) - second)
+    assert abs(h.volume - vol) < 1e-12
+    feet = [mj.names_body.index(n) for n in ("l_foot", "r_foot")]
+    for b in feet:
+        assert abs(mj.body_mass[b] - 700.0 * vol) < 1e-9
+        assert np.allclose(mj.body_ipos[b], com + c0, atol=1e-9)
+        assert np.allclose(np.sort(mj.body_inertia[b]), np.sort(np.linalg.eigvalsh(inertia)), rtol=1e-8, atol=1e-12)
