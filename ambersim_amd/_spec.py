@@ -74,6 +74,7 @@ def render_record(name: str, p: dict) -> str:
     parents = [int(x) for x in p.pop("dof_parent").split(",")]
     tree_h = int(p.pop("tree_H"))
     p2_col = [int(x) for x in p.pop("p2_col").split(",")]
+    p.pop("mrow", None)  # (tooling: the compact-M row table as text; the kernels read it from the constants)
     pad = parents + [-1] * (32 - len(parents))
     return "\n".join([
         f"struct Spec_{name} {{",

@@ -126,7 +126,16 @@ extern "C" int amx_spec_index_of(const amx_model_desc *d, int poke_k, int poke_v
   Image im;
   if (plan_model(d, m, im)) return -2;
   if (poke_k >= 0 && poke_k < 32) p2_col[poke_k] = poke_v;
-  return find_spec(m, d, im);
+  int spec = find_spec(m, d, im);
+  if (spec < 0 && (m.mcomp || m.jfr)) {  // as amx_model_create: without kernels for the dense form, the regular plan
+    plan_dense_off = 1;
+    const int rc = plan_model(d, m, im);
+    plan_dense_off = 0;
+    if (rc) return -2;
+    if (poke_k >= 0 && poke_k < 32) p2_col[poke_k] = poke_v;
+    spec = find_spec(m, d, im);
+  }
+  return spec;
 }
 
 static int model_create_impl(const amx_model_desc *d, int device, amx_model **out, bool wide_plan) {
@@ -134,7 +143,16 @@ static int model_create_impl(const amx_model_desc *d, int device, amx_model **ou
   DevModel m;
   Image im;
   if (int rc = plan_model(d, m, im)) return rc;
-  const int spec = find_spec(m, d, im);
+  int spec = find_spec(m, d, im);
+  if (spec < 0 && (m.mcomp || m.jfr)) {
+    // the planner chose its dense form (r05), which only per-model kernels carry, and this library holds none for the model: the regular
+    // plan, which the generic kernels run (a per-model build of the library - put_model's default - is compiled for the dense form)
+    plan_dense_off = 1;
+    const int rc = plan_model(d, m, im);
+    plan_dense_off = 0;
+    if (rc) return rc;
+    spec = find_spec(m, d, im);
+  }
   if (wide_plan && (spec < 0 || m.G != 64)) return AMX_EUNSUPPORTED;  // only kept when the library holds static kernels for it
   if (AMX_NO_GENERIC && spec < 0) return fail(AMX_EUNSUPPORTED, "this build of the library holds only the kernels of the model it was compiled for");
   if (m.nbs == 2 && spec < 0)

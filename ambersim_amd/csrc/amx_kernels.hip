@@ -628,7 +628,9 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 // AUGN >= 0 (32-lane groups): the accumulator starts from *cinit instead of zero, and every row's Jacobian is extended by one
 // entry at index AUGN holding the row's residual Jaref (field 2 of its record), so that row / column AUGN of the product collect
 // sum_r D_r J_r[k] Jaref_r = -(J' f)[k] next to whatever cinit put there (see newton_solve_fused)
-template <int G, bool COL31 = false, int AUGN = -1>
+// JFR (planner: jfr, r05): the Jacobian block holds three rows per contact - normal, mu * tangent 1, mu * tangent 2 - and a pyramid row's entry
+// is their sum or difference, formed here: three loads and four additions per contact instead of four loads
+template <int G, bool COL31 = false, int AUGN = -1, bool JFR = false>
 DEV void jtdj_rows_mfma(unsigned long long crows, int row_base, int J_base, int ldc, int slot_base, int gl, unsigned (&lo)[4][4], unsigned (&hi)[4][4],
                         const v32f *cinit = nullptr, unsigned long long crows2 = 0ull) {
   const int j = gl & 31, h = gl >> 5;
@@ -653,10 +655,12 @@ DEV void jtdj_rows_mfma(unsigned long long crows, int row_base, int J_base, int 
       cm &= cm - 1ull;
       const int slot = CI(slot_base + 32 * c + j);
       o.has = slot >= 0;
-      const int Jr = J_base + 4 * c * ldc + (o.has ? slot : 0), Dr = row_base + 4 * c * ROW_E;
+      const int Jr = J_base + (JFR ? 3 : 4) * c * ldc + (o.has ? slot : 0), Dr = row_base + 4 * c * ROW_E;
+      if constexpr (JFR) { o.jv[0] = lds[Jr]; o.jv[1] = lds[Jr + ldc]; o.jv[2] = lds[Jr + 2 * ldc]; o.jv[3] = 0.0f; }  // normal, mu t1, mu t2: combined at issue
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        o.d[r] = lds[Dr + r * ROW_E]; o.jv[r] = lds[Jr + r * ldc];
+        o.d[r] = lds[Dr + r * ROW_E];
+        if constexpr (!JFR) o.jv[r] = lds[Jr + r * ldc];
         o.g[r] = 0.0f;
         if (COL31) o.g[r] = AMX_SQRT_D ? -lds[Dr + r * ROW_E + 2] : lds[Dr + r * ROW_E + 1];  // sqrt form: the force f = -D Jaref as (-Jaref sqrt D) sqrt D
         if (AUGN >= 0) o.g[r] = lds[Dr + r * ROW_E + 2];
@@ -669,7 +673,8 @@ DEV void jtdj_rows_mfma(unsigned long long crows, int row_base, int J_base, int 
     auto issue = [&](const Ops &o, auto first) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float v0 = o.has ? o.jv[r] : 0.0f;
+        const float jr_ = JFR ? ((r & 1) ? o.jv[0] - o.jv[1 + (r >> 1)] : o.jv[0] + o.jv[1 + (r >> 1)]) : o.jv[r];
+        const float v0 = o.has ? jr_ : 0.0f;
 #if AMX_SQRT_D
         // o.d is sqrt(D) (constraint_force_and_grad publishes it): A = B = sqrt(D) J - the same bits on both sides of every product
         const float v = o.d[r] * ((AUGN >= 0 && j == AUGN) ? o.g[r] : ((COL31 && j == 31) ? 0.0f : v0));
@@ -727,6 +732,7 @@ DEV void jtdj_rows_mfma(unsigned long long crows, int row_base, int J_base, int 
   } else {
     // one environment per wave: the single-block K = 2 instruction takes two Jacobian rows at a time (lanes 32-63 feed the
     // second), two instructions per contact
+    static_assert(!JFR || G == 32, "three-row Jacobian blocks: 32-lane groups");
     v16f C = {};
     // (two contact-row slots per lane, r04: rows 64 .. 127 = contacts 16 .. 31 arrive as a second mask)
     unsigned long long cm2 = (crows2 | (crows2 >> 1) | (crows2 >> 2) | (crows2 >> 3)) & 0x1111111111111111ull;
@@ -1239,8 +1245,36 @@ template <int N, int G> DEV float dense_sym_solve(float (&a)[N], float b, int gl
   return fdiv(aa[N], fmaxf(d, MINVAL));
 }
 
+// Row `gl` of M from the compact storage (planner: mcomp; r05) into a[0 .. N-1] - the same numbers a whole row would have given.
+//   * entries on the leading chain, j < mnb0: M[j][gl] down the whole rows' column (one four-byte load each, one address for all of them);
+//   * the others as 16-byte chunks from the row's own storage, whose pseudo-base `mdiag - gl` makes chunk c sit at + 4 c; a chunk
+//     outside the row's stored range (bit c of mwin clear) comes from the constants' zero row.
+// brow: the lane that mirrors the right-hand side as a row takes its chunks from the staged vector at bt_off and its leading entries from
+// column N of the whole rows, where the caller has put them; a lane without a row reads the zero row and the always-zero column ldm - 1.
+template <class S, int N>
+DEV void m_row_compact(float (&a)[N + 1], int M_off, int gl, int mdiag, unsigned mwin, bool owner, bool brow, int bt_off) {
+  constexpr int ld = S::ldm, nb0 = S::mnb0;
+  static_assert(!S::mcomp || ld >= N + 2, "compact M: two spare columns");
+  const int colb = M_off + (gl <= N ? gl : ld - 1);
+#pragma unroll
+  for (int j = 0; j < nb0; ++j) a[j] = lds[colb + j * ld];
+  const int rb = brow ? bt_off : (owner ? M_off + mdiag - gl : S::c_zero);
+  const unsigned win = brow ? ~0u : mwin;
+#pragma unroll
+  for (int c = nb0 / 4; c < (N + 3) / 4; ++c) {
+    const int ad = ((win >> c) & 1u) ? rb : S::c_zero;
+    const float4 v = *reinterpret_cast<const float4 *>(lds + ad + 4 * c);
+    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = 4 * c + q;
+      if (k >= nb0 && k < N) a[k] = e[q];
+    }
+  }
+}
+
 template <class S, int G, bool TREE>
-AMX_STATIC_SOLVE_ATTR void spd_solve_static(int A_off, int rhs_off, int x_off, int gl, int rot, int bt_off) {
+AMX_STATIC_SOLVE_ATTR void spd_solve_static(int A_off, int rhs_off, int x_off, int gl, int rot, int bt_off, int mdiag = 0, unsigned mwin = 0u) {
   constexpr int N = S::nv, ld = S::ldm, nch = ld / 4;
   if constexpr (sym_elim_ok<S, G>()) {
     // bt_off: an idle vector of ld floats (the M*v staging vector) through which b reaches lane N as a row; < 0: none, b is
@@ -1257,8 +1291,13 @@ AMX_STATIC_SOLVE_ATTR void spd_solve_static(int A_off, int rhs_off, int x_off, i
     const bool brow = BCOL && gl == N && bt_off >= 0;
     if (BCOL && bt_off >= 0) {
       if (gl < ld) lds[bt_off + gl] = b;
+      if (S::mcomp && gl < S::mnb0) lds[A_off + gl * ld + N] = b;  // the mirrored row's leading entries: column N of the whole rows
       WSYNC();
     }
+    if constexpr (S::mcomp) {
+      static_assert(BCOL, "compact M: 32- and 64-lane groups");
+      m_row_compact<S, N>(a, A_off, gl, mdiag, mwin, gl < N, brow, bt_off);
+    } else {
     // lanes without a matrix row load the constants' all-zero row: no select per entry
     const float4 *rowp = reinterpret_cast<const float4 *>(lds + (brow ? bt_off : (gl < N ? A_off + li * ld : S::c_zero)));
     const int rot_l = gl < N ? rot : 0;
@@ -1273,6 +1312,7 @@ AMX_STATIC_SOLVE_ATTR void spd_solve_static(int A_off, int rhs_off, int x_off, i
         const int k = 4 * c + q;
         if (k < N) a[k] = e[q];
       }
+    }
     }
     a[N] = b;
     float d = 1.0f;
@@ -1322,7 +1362,8 @@ template <class S, int N, int G, bool TREE, bool GRADCOL = false>
 AMX_STATIC_SOLVE_ATTR bool newton_solve_fused(int M_off, int ld_, int n_, unsigned long long crows_, int row_base, int J_base, int ldc_, int slot_base_,
                                                 int rhs_off, int x_off, float dlim, int gl, int gb4, int rot, int bt_off, float flim = 0.0f, float ma_v = 0.0f,
                                                 float fs_v = 0.0f, int fcon_off = 0, bool store_ok = true, bool early_out = false, bool imp_done = false,
-                                                float scale = 1.0f, float tol = 0.0f, ProfCtx *pc = nullptr, bool *group_done = nullptr, unsigned long long crows2_ = 0ull) {
+                                                float scale = 1.0f, float tol = 0.0f, ProfCtx *pc = nullptr, bool *group_done = nullptr, unsigned long long crows2_ = 0ull,
+                                                int mdiag = 0, unsigned mwin = 0u) {
   if constexpr (sym_elim_ok<S, G>() && G >= 32) {
     // crossbar-free elimination (see sym_pivot): b reaches lane N as a row through the staging vector at bt_off
     constexpr int NS = S::nv, lds_ = S::ldm, nchs = lds_ / 4;
@@ -1339,11 +1380,11 @@ AMX_STATIC_SOLVE_ATTR bool newton_solve_fused(int M_off, int ld_, int n_, unsign
     // read-modify-write, hidden behind the matrix-core loop) instead of a compare + select + add per register of the row
     int dpc = (gl >> 2) + (S::mrot ? rot : 0);
     dpc -= dpc >= nchs ? nchs : 0;
-    const int dg = M_off + li * lds_ + 4 * dpc + (gl & 3);
+    const int dg = S::mcomp ? M_off + mdiag : M_off + li * lds_ + 4 * dpc + (gl & 3);
     float d0 = 0.0f;
     if (owner) { d0 = lds[dg]; lds[dg] = d0 + dlim; }
     float b;
-    if constexpr (GRADCOL && G == 32 && AMX_MFMA_AUG && (S::ldm > S::nv) && (S::nv >= AMX_MFMA_AUG_MIN_NV)) {
+    if constexpr (GRADCOL && G == 32 && AMX_MFMA_AUG && (S::ldm > S::nv) && (S::nv >= AMX_MFMA_AUG_MIN_NV) && !S::mcomp) {
       // r03: the rows of M, the gradient and the mirrored right-hand-side row all come out of the matrix cores' accumulator.
       //  * The accumulator starts from M instead of zero.  In the 2-block instruction's layout lane l of the wave holds, for block
       //    0 (the wave's first environment) and block 1 (its second), rows 8q + 4 (l / 32) + r of column l % 32; after the
@@ -1413,7 +1454,7 @@ AMX_STATIC_SOLVE_ATTR bool newton_solve_fused(int M_off, int ld_, int n_, unsign
       static_assert(NS <= 31, "column 31 must be spare");
       const float ma = ma_v, fs = fs_v;  // M*qacc and qfrc_smooth of the lane's dof, from the caller's registers
       PROF_CTX(pc, 24);
-      jtdj_rows_mfma<G, true>(crows_u, row_base, J_base, S::ldc, S::c_slot, gl, lo, hi, nullptr, crows2_u);
+      jtdj_rows_mfma<G, true, -1, S::jfr != 0>(crows_u, row_base, J_base, S::ldc, S::c_slot, gl, lo, hi, nullptr, crows2_u);
       PROF_CTX(pc, 25);
       const float fcon = __uint_as_float(hi[3][3]) + flim;
       b = ma - fs - fcon;
@@ -1430,17 +1471,26 @@ AMX_STATIC_SOLVE_ATTR bool newton_solve_fused(int M_off, int ld_, int n_, unsign
         }
       }
     } else {
-      jtdj_rows_mfma<G>(crows_u, row_base, J_base, S::ldc, S::c_slot, gl, lo, hi, nullptr, crows2_u);
+      jtdj_rows_mfma<G, false, -1, S::jfr != 0>(crows_u, row_base, J_base, S::ldc, S::c_slot, gl, lo, hi, nullptr, crows2_u);
       b = lds[rhs_off + li * DOF_E];
     }
     b = owner ? b : 0.0f;
     if (gl < lds_) lds[bt_off + gl] = b;
+    if (S::mcomp && gl < S::mnb0) lds[M_off + gl * lds_ + NS] = b;  // the mirrored row's leading entries (m_row_compact)
     WSYNC();
     // lanes without a matrix row load the constants' all-zero row, and their J'DJ registers are zero (no slot): the row is a
     // plain sum.  The diagonal term of the lane's limit row went into M's diagonal in LDS before the loads (restored below).
+    float a[NS + 1];
+    if constexpr (S::mcomp) {
+      m_row_compact<S, NS>(a, M_off, gl, mdiag, mwin, owner, brow, bt_off);
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        const unsigned *src = ((k >> 2) & 1) ? hi[k >> 3] : lo[k >> 3];
+        a[k] += __uint_as_float(src[k & 3]);
+      }
+    } else {
     const float4 *rowp = reinterpret_cast<const float4 *>(lds + (brow ? bt_off : (owner ? M_off + li * lds_ : S::c_zero)));
     const int rot_l = owner ? rot : 0;
-    float a[NS + 1];
 #pragma unroll
     for (int c = 0; c < (NS + 3) / 4; ++c) {
       int pc = c + (S::mrot ? rot_l : 0);
@@ -1453,6 +1503,7 @@ AMX_STATIC_SOLVE_ATTR bool newton_solve_fused(int M_off, int ld_, int n_, unsign
         const int k = 4 * c + q;
         if (k < NS) a[k] = e[q] + __uint_as_float(src[q]);
       }
+    }
     }
     if (owner) lds[dg] = d0;  // M's own diagonal back (after the loads above: one wave's LDS operations execute in order)
     a[NS] = b;
@@ -2147,6 +2198,7 @@ struct Env {
   int b_parent, b_level, b_root, b_jntadr, b_jntnum, b_childadr, b_childnum, b_subend;  // body `lane` (b_subend: one past its last descendant)
   int d_body, d_jnt, d_kind, d_axis, d_root, d_jadr, d_limrow, d_frirow;      // dof `lane` (d_jadr: first dof of its joint; d_limrow / d_frirow: lane of its limit / friction-loss row)
   int m_rot, m_diag;  // row `lane` of M: chunk rotation of the row (0 unless MV::mrot), float offset of its diagonal entry inside M
+  unsigned m_win = 0u;  // compact M (MV::mcomp): bit c set when the row stores chunk c (m_row_compact)
   // Constraint rows: a lane owns TWO row slots, so that a group of G lanes carries up to 2 G rows -
   //   slot A: equality / limit row `gl` (gl < nA = neq + nlim): one or two Jacobian entries, kept in registers;
   //   slot B: contact pyramid row `gl` (gl < nB = 4 ncon): its Jacobian row lives in LDS, chain-compressed.
@@ -2204,6 +2256,10 @@ struct Env {
       const int nch = m.ldm() >> 2, i = lane < m.nv() ? lane : 0;
       m_rot = m.mrot() ? AMX_ROW_ROT(i, nch) : 0;
       m_diag = moff(i, i);
+      if (m.mcomp()) {
+        const int pk = CI(m.c_mrow() + i), clo = (pk >> 12) & 15, chi = (pk >> 16) & 15;
+        m_win = lane < m.nv() ? (2u << chi) - (1u << clo) : 0u;
+      }
     }
     aD = aAref = aJaref = aJv = cD = cAref = cJaref = cJv = rJ1 = rJ2 = aFl = 0.0f;
     c2D = c2Aref = c2Jaref = c2Jv = 0.0f; c2act = false;
@@ -2239,6 +2295,11 @@ struct Env {
   DEV float &jnt(int f, int da) const { return lds[ebD + da * DOF_E + 6 + f]; }
   // float offset of M[i][j] inside the matrix block (rows may store their 16-byte chunks rotated, see amx_plan.h)
   DEV int moff(int i, int j) const {
+    if (m.mcomp()) {  // compact storage: < 0 when the entry is not stored (it is zero: neither dof is above the other)
+      if (i >= m.mnb0() && j < m.mnb0()) { const int t = i; i = j; j = t; }  // the same number lives in the leading chain's whole row
+      const int pk = CI(m.c_mrow() + i), clo = (pk >> 12) & 15, chi = (pk >> 16) & 15;
+      return ((j >> 2) < clo || (j >> 2) > chi) ? -1 : (pk & 4095) + j - 4 * clo;
+    }
     const int nch = m.ldm() >> 2, rot = m.mrot() ? AMX_ROW_ROT(i, nch) : 0;
     return i * m.ldm() + 4 * (((j >> 2) + rot) % nch) + (j & 3);
   }
@@ -3118,9 +3179,10 @@ struct Env {
             jp = mk3(s2 ? jp.x - a1.x : jp.x, s2 ? jp.y - a1.y : jp.y, s2 ? jp.z - a1.z : jp.z);
           }
           const float jn = dot(fn_, jp), j1 = dot(ft1, jp), j2 = dot(ft2, jp);
+          if (m.jfr()) return JEnt{Jo + (3 * c) * ldc + slot, jn, mu * j1, mu * j2, 0.0f};  // three rows per contact; the pyramid rows are their sums and differences
           return JEnt{Jo + (4 * c) * ldc + slot, jn + mu * j1, jn - mu * j1, jn + mu * j2, jn - mu * j2};
         },
-        [&](int, const JEnt &r) { lds[r.at] = r.r0; lds[r.at + ldc] = r.r1; lds[r.at + 2 * ldc] = r.r2; lds[r.at + 3 * ldc] = r.r3; });
+        [&](int, const JEnt &r) { lds[r.at] = r.r0; lds[r.at + ldc] = r.r1; lds[r.at + 2 * ldc] = r.r2; if (!m.jfr()) lds[r.at + 3 * ldc] = r.r3; });
       stage_chain(qv, 1);  // for the rows' J * qvel below
     }
     WSYNC();
@@ -3213,7 +3275,7 @@ struct Env {
       const float margin = CF(prec + 21), dist = con(0, c);
       const float pos = dist - margin;
       const float invw = CF(prec + 22);  // (tw + mu^2 tw) 2 mu^2 / impratio, folded by the planner
-      const float jv = chain_dot(Jo + cr * ldc);  // qvel was staged with the Jacobian entries above
+      const float jv = contact_row_dot(cr, vch_base);  // qvel was staged with the Jacobian entries above
       if (dist < margin) {
         const int rec = prec + 12;
         const float imp = row_impedance(rec, pos);
@@ -3236,7 +3298,7 @@ struct Env {
         const float margin = CF(prec + 21), dist = con(0, c);
         const float pos = dist - margin;
         const float invw = CF(prec + 22);
-        const float jv = chain_dot(Jo + cr * ldc, vch_base2);
+        const float jv = contact_row_dot(cr, vch_base2);
         if (dist < margin) {
           const int rec = prec + 12;
           const float imp = row_impedance(rec, pos);
@@ -3262,6 +3324,21 @@ struct Env {
     const float4 *mr = reinterpret_cast<const float4 *>(lds + eb + m.e_M() + i * ldm), *vv = reinterpret_cast<const float4 *>(lds + Vo);
     float acc0 = 0, acc1 = 0;
     const int nch = ldm >> 2;
+    if constexpr (S::is_static && S::mcomp) {
+      // compact M: the row through m_row_compact, then the same multiply-adds in the same order as the whole-row form below
+      float a[S::nv + 1];
+      m_row_compact<S, S::nv>(a, eb + m.e_M(), gl, m_diag, m_win, gl < S::nv, false, 0);
+      float ax = 0.0f, ay = 0.0f;  // (the whole-row form's two packed lanes)
+#pragma unroll
+      for (int c = 0; c < (S::nv + 3) / 4; ++c) {
+        const float4 v = vv[c];
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (4 * c + q < S::nv) { if (q & 1) ay = __builtin_fmaf(a[4 * c + q], e[q], ay); else ax = __builtin_fmaf(a[4 * c + q], e[q], ax); }
+      }
+      return ax + ay;
+    } else
     if constexpr (S::is_static) {  // static chunk count: one straight block, every load in flight
 #if AMX_PK_DOT
       // packed fp32 (v_pk_fma_f32: two multiply-adds per instruction): a 16-byte load lands in two aligned register pairs, which
@@ -3357,15 +3434,29 @@ struct Env {
     }
     return a0 + a1;
   }
+  // contact pyramid row cr times the staged vector.  Three-row Jacobian blocks (MV::jfr): row 4 c + k is normal +- (mu tangent 1 | mu tangent 2),
+  // so its product is the sum or difference of two of the block's products
+  DEV float contact_row_dot(int cr, int vb) const {
+    if constexpr (S::is_static && S::jfr) {
+      // lanes 4 c .. 4 c + 3 hold the contact's four pyramid rows: lane k multiplies block row min(k, 2) - one chain_dot, as in the four-row
+      // form - and the quad exchanges the three products (DPP quad_perm): row k = normal +- tangent (k >> 1).  The callers' branches and
+      // validity tests are whole quads (4 ncon rows), and the four lanes share the pair, hence the staged vector.
+      const int c = cr >> 2, k = cr & 3;
+      const float x = chain_dot(eb + m.e_J() + (3 * c + (k < 3 ? k : 2)) * S::ldc, vb);
+      const float dn = dpp_f<0x00>(x), dt = dpp_f<0xA5>(x);  // quad_perm [0,0,0,0], [1,1,2,2]
+      return (k & 1) ? dn - dt : dn + dt;
+    }
+    return chain_dot(eb + m.e_J() + cr * m.ldc(), vb);
+  }
   DEV float row_dot_B(int vf) const {
     const bool valid = gl < nB();
-    const float a = chain_dot(eb + m.e_J() + (valid ? gl : 0) * m.ldc());  // the caller has staged v = dof field vf (mul_M_row does)
+    const float a = contact_row_dot(valid ? gl : 0, vch_base);  // the caller has staged v = dof field vf (mul_M_row does)
     return valid ? a : 0.0f;
   }
   DEV float row_dot_B2(int vf) const {
     if constexpr (NBS != 2) return 0.0f;
     const bool valid = validB2();
-    const float a = chain_dot(eb + m.e_J() + (valid ? gl + G : 0) * m.ldc(), vch_base2);
+    const float a = contact_row_dot(valid ? gl + G : 0, vch_base2);
     return valid ? a : 0.0f;
   }
   // Ma = M v, Jaref = J v - aref  (v = dof field vf)
@@ -3403,6 +3494,7 @@ struct Env {
   // grad_in_solve(): the specialised fused Newton path takes J'f of the contact rows from the matrix cores (newton_solve_fused
   // GRADCOL), so a call that is followed by newton_direction() only publishes the row records and the limit-row force
   static constexpr bool grad_in_solve() { return S::is_static && (G == 32 || (G == 64 && AMX_GRADCOL_64)) && S::fusedH && S::solver == 2 && S::nv <= 31 && sym_elim_ok<S, G>() && !AMX_NO_GRADCOL; }
+  static_assert(!(S::mcomp || S::jfr) || (grad_in_solve() && G == 32 && !S::mfma2), "the planner's dense form lives in the symmetric eliminations and the gradient-column Newton solve of 32-lane groups");
   // the two-pair Newton solve (newton_solve_pair2) also writes the search vector
   static constexpr bool search_from_solve() { return grad_in_solve() && S::mfma2 && AMX_MFMA_PAIR2; }
   float pend_flim;  // limit-row force on this lane's dof, handed from a deferring constraint_force_and_grad to newton_direction
@@ -3465,8 +3557,18 @@ struct Env {
         const int Ja = Jo + c0 * ldc + (pk0 >> 8), Fa = eb + m.e_row() + (row0 + c0) * ROW_E + 1;
         const int Jb = Jo + c1 * ldc + (pk1 >> 8), Fb = eb + m.e_row() + (row0 + c1) * ROW_E + 1;
         float ja[4], fa[4], jb[4], fb[4];
+        if constexpr (S::is_static && S::jfr) {
+          // three-row blocks: c0, c1 are the contacts' first pyramid rows (4 c), their blocks start at row 3 c
+          const int Ja3 = Ja - (c0 >> 2) * ldc, Jb3 = Jb - (c1 >> 2) * ldc;
+          const float na = lds[Ja3], ta1 = lds[Ja3 + ldc], ta2 = lds[Ja3 + 2 * ldc], nb_ = lds[Jb3], tb1 = lds[Jb3 + ldc], tb2 = lds[Jb3 + 2 * ldc];
+          ja[0] = na + ta1; ja[1] = na - ta1; ja[2] = na + ta2; ja[3] = na - ta2;
+          jb[0] = nb_ + tb1; jb[1] = nb_ - tb1; jb[2] = nb_ + tb2; jb[3] = nb_ - tb2;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { fa[k] = lds[Fa + k * ROW_E]; fb[k] = lds[Fb + k * ROW_E]; }
+        } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) { ja[k] = lds[Ja + k * ldc]; fa[k] = lds[Fa + k * ROW_E]; jb[k] = lds[Jb + k * ldc]; fb[k] = lds[Fb + k * ROW_E]; }
+        }
         const float sa = (ja[0] * fa[0] + ja[1] * fa[1]) + (ja[2] * fa[2] + ja[3] * fa[3]);
         const float sb = (jb[0] * fb[0] + jb[1] * fb[1]) + (jb[2] * fb[2] + jb[3] * fb[3]);
         acc += w0 ? sa : 0.0f;
@@ -3528,9 +3630,11 @@ struct Env {
         else if constexpr (grad_in_solve())
           stop = newton_solve_fused<S, S::nv, G, S::tree_H, true>(Mo, ldm, nv, rows, eb + m.e_row() + row0 * ROW_E, Jo, ldc, m.c_slot(), dofoff(D_GRAD), dofoff(D_MGRAD), dlim, gl, gb4, m_rot,
                                                                  eb + m.e_H(), pend_flim, r_ma, r_fs, dofoff(D_FCON), alive, early_out, imp_done, m.scale(),
-                                                                 m.tolerance(), pc, group_done, rows2);
-        else if constexpr (S::is_static)
+                                                                 m.tolerance(), pc, group_done, rows2, m_diag, m_win);
+        else if constexpr (S::is_static) {
+          static_assert(!S::mcomp && !S::jfr, "the dense form lives in the gradient-column Newton solve");
           newton_solve_fused<S, S::nv, G, S::tree_H>(Mo, ldm, nv, rows, eb + m.e_row() + row0 * ROW_E, Jo, ldc, m.c_slot(), dofoff(D_GRAD), dofoff(D_MGRAD), dlim, gl, gb4, m_rot, eb + m.e_H());
+        }
         else
           newton_fused_dyn<G>(m.nchol(), Mo, ldm, nv, rows, eb + m.e_row() + row0 * ROW_E, Jo, ldc, m.c_slot(), dofoff(D_GRAD), dofoff(D_MGRAD), dlim, gl, gb4, m_rot);
         PROF(14);
@@ -4043,7 +4147,7 @@ struct Env {
     // qacc_smooth = M^-1 qfrc_smooth.  Newton never reuses the factor: one-shot Gauss-Jordan solve;
     // CG keeps a Cholesky factor in Lb as its preconditioner.
     if (m.solver() == 2) {
-      if constexpr (S::is_static) spd_solve_static<S, G, true>(eb + m.e_M(), dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), gl, m_rot, eb + m.e_H());
+      if constexpr (S::is_static) spd_solve_static<S, G, true>(eb + m.e_M(), dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), gl, m_rot, eb + m.e_H(), m_diag, m_win);
       else spd_solve<G>(m.nchol(), eb + m.e_M(), m.ldm(), nv, dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), gl, gb4, m_rot);
     }
     else chol_solve<G>(m.nchol(), eb + m.e_M(), m.ldm(), nv, eb + m.e_Lb(), dofoff(D_FSMOOTH), dofoff(D_ASMOOTH), true, gl, gb4);
@@ -4069,7 +4173,7 @@ struct Env {
       // M + dt*diag(damping) in place: this is the last reader of M in the step and the crb pass rewrites it
       if (gl < nv) { dof(D_SEARCH, gl) = dof(D_FSMOOTH, gl) + dof(D_FCON, gl); lds[Mo + m_diag] += m.dt() * CF(m.c_dof() + gl * DOF_S + 5); }
       WSYNC();
-      if constexpr (S::is_static) spd_solve_static<S, G, true>(Mo, dofoff(D_SEARCH), dofoff(D_MV), gl, m_rot, eb + m.e_H());
+      if constexpr (S::is_static) spd_solve_static<S, G, true>(Mo, dofoff(D_SEARCH), dofoff(D_MV), gl, m_rot, eb + m.e_H(), m_diag, m_win);
       else spd_solve<G>(m.nchol(), Mo, m.ldm(), nv, dofoff(D_SEARCH), dofoff(D_MV), gl, gb4, m_rot);
     } else {
       if (gl < nv) dof(D_MV, gl) = dof(D_QACC, gl);
@@ -4340,6 +4444,9 @@ amx_forward_kernel(const DevModel m_in, int nenv, const float *__restrict__ qpos
       for (int k = gl; k < m.nb() * 3; k += G) o.xpos[(size_t)e * m.nb() * 3 + k] = env.body(k % 3, k / 3);
     if (live && o.xquat)
       for (int k = gl; k < m.nb() * 4; k += G) o.xquat[(size_t)e * m.nb() * 4 + k] = env.body(3 + k % 4, k / 4);
+    // (the contact distances too: in the planner's dense form the solver's row records take their place afterwards)
+    if (live && o.cdist)
+      for (int k = gl; k < m.ncon(); k += G) o.cdist[(size_t)e * m.ncon() + k] = env.con(0, k);
     WSYNC();
   });
   const unsigned long long gmask = G == 64 ? ~0ull : ((1ull << (G & 63)) - 1);
@@ -4356,10 +4463,9 @@ amx_forward_kernel(const DevModel m_in, int nenv, const float *__restrict__ qpos
   if (o.qM)
     for (int k = gl; k < nv * nv; k += G) {
       const int r = k / nv, c = k % nv, hi = r > c ? r : c, lo = r > c ? c : r;
-      o.qM[(size_t)e * nv * nv + k] = lds[eb + m.e_M() + env.moff(hi, lo)];
+      const int mo = env.moff(hi, lo);
+      o.qM[(size_t)e * nv * nv + k] = mo < 0 ? 0.0f : lds[eb + m.e_M() + mo];
     }
-  if (o.cdist)
-    for (int k = gl; k < m.ncon(); k += G) o.cdist[(size_t)e * m.ncon() + k] = env.con(0, k);
   if (o.nefc && gl == 0) o.nefc[e] = nactive;
 }
 

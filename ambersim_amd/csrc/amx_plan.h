@@ -85,8 +85,13 @@ static thread_local std::vector<int> p2_col;
 // at 64 lanes - one environment per wavefront - for batches too small to fill the SIMDs with two-environment waves)
 static thread_local int plan_force_lanes = 0;
 extern "C" void amx_plan_force_lanes(int g) { plan_force_lanes = g; }
+// 1: plan the DENSE form (r05; plan_model tries it for a model whose contact rows alone ask for 64 lanes): two contact rows per lane on a
+// 32-lane group, M stored compactly (mcomp) and the solver's row records and staging vector in the space of the contact points, frames and
+// geom poses, which nobody reads after make_constraint - what it takes to keep sixteen environments of a contact-rich biped in a CU's LDS
+static thread_local int plan_dense = 0;
+static thread_local int plan_dense_off = 0;  // 1: the regular plan only (amx_model_create, when the library holds no kernels for the dense form)
 
-static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
+static int plan_model_once(const amx_model_desc *d, DevModel &m, Image &im) {
   if (!d) return fail(AMX_EINVAL, "null argument");
   if (d->version != AMX_VERSION) return fail(AMX_EINVAL, "amx_model_desc version %d, library %d", d->version, AMX_VERSION);
   if (d->nbody < 1 || d->nq < 0 || d->nv < 0) return fail(AMX_EINVAL, "bad sizes");
@@ -484,6 +489,7 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
   m.nbs = 1;
   if (two_ok && m.ncon > 16) m.nbs = 2;
   if (const char *force = getenv("AMX_FORCE_NBS")) { if (atoi(force) == 2 && two_ok && m.ncon > 4) m.nbs = 2; }  // diagnostic: two slots on a narrower group
+  if (plan_dense && two_ok && m.ncon > 8) m.nbs = 2;
   if (m.ncon > 16 * m.nbs)
     return fail(AMX_ECAPACITY, "%d contact slots (connect / weld row groups included) exceed %d (4 rows each; two rows per lane of a 64-lane group only for "
                 "Newton models with nv <= 31 and ls_iterations <= 10 whose other rows are joint limits and joint equalities)", m.ncon, 16 * m.nbs);
@@ -570,10 +576,58 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
   m.ldm = ((nv + 3) / 4) * 4;
   m.mrot = 0;
   if ((m.ldm / 4) % 2 == 0) { if (m.fusedH) m.mrot = 1; else m.ldm += 4; }
+  // Compact M (dense form only; r05).  M[i][j] != 0 only when one of i, j is an ancestor of the other.  A floating-base robot's first mnb0
+  // dofs form a chain every other dof descends from: their rows are dense and stay whole.  Any other row i has entries on that chain - which
+  // are, M being symmetric, column i of the whole rows - and on the dofs >= mnb0 of its own branch, a narrow range of columns: it stores the
+  // 16-byte chunks [clo_i, chi_i] that cover that range, mwin chunks per row (amx_kernels.hip, m_row_compact: the lane reads its row's
+  // leading entries with mnb0 four-byte loads down the whole rows' column, the others as chunks, a chunk outside its range from the constants'
+  // zero row).  A 30-dof biped with four six-dof limbs: 6 x 32 + 24 x 8 = 384 floats instead of 960.  Needs two spare columns: column nv
+  // carries the right-hand side to the lane that mirrors it as a row, column ldm - 1 stays zero for the lanes without a row.
+  m.mcomp = 0; m.mnb0 = 0; m.mwin = 0;
+  int m_floats = nv * m.ldm;
+  std::vector<int> mrow_base(nv, 0), mrow_clo(nv, 0), mrow_chi(nv, m.ldm / 4 - 1);
+  if (plan_dense && m.fusedH && m.nbs == 2 && m.ldm >= nv + 2 && nv <= 32 && !getenv("AMX_DENSE_NO_MCOMP")) {
+    auto is_anc = [&](int a, int i) { for (int j = i; j >= 0; j = d->dof_parentid[j]) if (j == a) return true; return false; };  // a is i or above it
+    int nb0 = 0;
+    while (nb0 < nv && d->dof_parentid[nb0] == nb0 - 1) {
+      bool all = true;
+      for (int i = nb0 + 1; i < nv && all; i++) all = is_anc(nb0, i);
+      if (!all) break;
+      nb0++;
+    }
+    int wmax = 0;
+    for (int i = nb0; i < nv; i++) {
+      int lo = i, hi = i;
+      for (int j = nb0; j < nv; j++) if (is_anc(j, i) || is_anc(i, j)) { lo = std::min(lo, j); hi = std::max(hi, j); }
+      mrow_clo[i] = lo / 4; mrow_chi[i] = hi / 4;
+      wmax = std::max(wmax, hi / 4 - lo / 4 + 1);
+    }
+    int total = nb0 * m.ldm;
+    for (int i = nb0; i < nv; i++) total += 4 * (mrow_chi[i] - mrow_clo[i] + 1);
+    if (nb0 >= 1 && nb0 < nv && total < nv * m.ldm) {
+      m.mcomp = 1; m.mnb0 = nb0; m.mwin = wmax; m.mrot = 0;
+      int o = 0;
+      for (int i = 0; i < nv; i++) {
+        if (i < nb0) { mrow_clo[i] = 0; mrow_chi[i] = m.ldm / 4 - 1; }
+        mrow_base[i] = o;
+        o += 4 * (mrow_chi[i] - mrow_clo[i] + 1);
+      }
+      m_floats = o;
+    }
+  }
   auto moff = [&](int i, int j) {  // float offset of M[i][j] inside the matrix block
+    if (m.mcomp) {
+      if (i >= m.mnb0 && j < m.mnb0) std::swap(i, j);  // not stored in row i: the same number lives in the whole row j
+      return mrow_base[i] + (j - 4 * mrow_clo[i]);
+    }
     const int nch = m.ldm / 4, rot = m.mrot ? AMX_ROW_ROT(i, nch) : 0;
     return i * m.ldm + 4 * ((j / 4 + rot) % nch) + (j & 3);
   };
+  {
+    std::vector<int> mr(nv, 0);
+    for (int i = 0; i < nv; i++) mr[i] = mrow_base[i] | (mrow_clo[i] << 12) | (mrow_chi[i] << 16);
+    m.c_mrow = m.mcomp ? add_ints(mr) : 0;
+  }
   {
     std::vector<int> Mlist;  // one item per (dof i, ancestor-or-self j): offsets of M[i][j] and M[j][i], and the pair itself
     for (int i = 0; i < nv; i++)
@@ -692,16 +746,30 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
   m.e_geom = take(GEO_E * m.ngc);
   m.e_cx = m.ncx > 0 ? take(6 * m.cx_maxv + CX_TAIL) : 0;
   const int ntri = nv * (nv + 1) / 2;
+  const int xover_lo = m.e_con, xover_hi = off;  // contact points, frames, geom poses (and the convex scratch): dead once make_constraint has run
   off = (off + 3) & ~3;
-  m.e_M = take(nv * m.ldm);
+  m.e_M = take(m_floats);
   {
     const int r1 = off;
     m.e_body = r1;
     m.e_J = r1;
-    int o2 = r1 + std::max(4 * m.ncon * m.ldc, 1);
-    m.e_row = o2; o2 += std::max(ROW_E * m.nefc, 1);
+    // dense form: three rows per contact - the normal's and the two tangents' (the latter times the friction coefficient), of which the four
+    // pyramid rows are sums and differences (amx_kernels.hip: Env::jfr)
+    m.jfr = (plan_dense && m.fusedH && m.nbs == 2 && m.G == 32 && !m.mfma2 && !getenv("AMX_DENSE_NO_JFR")) ? 1 : 0;  // (the variables: diagnostic)
+    int o2 = r1 + std::max((m.jfr ? 3 : 4) * m.ncon * m.ldc, 1);
+    // dense form: the row records and the staging vector - first written by the solver, after make_constraint's last read of a contact
+    // point - take the place of the contact points / frames / geom poses (rewritten by the next step's kinematics and collision pass)
+    const int nrowf = std::max(ROW_E * m.nefc, 1), nstage = std::max(m.ldm, nv + 8);
+    int vstage = -1;
+    m.e_row = -1;
+    if (plan_dense && m.fusedH) {
+      int x = (xover_lo + 3) & ~3;
+      if (x + nstage <= xover_hi) { vstage = x; x += nstage; }
+      if (x + nrowf <= xover_hi) { m.e_row = x; x += nrowf; }
+    }
+    if (m.e_row < 0) { m.e_row = o2; o2 += nrowf; }
     o2 = (o2 + 3) & ~3;
-    const int vstage = o2; o2 += std::max(m.ldm, nv + 8);
+    if (vstage < 0) { vstage = o2; o2 += nstage; }
     m.e_vch = o2; o2 += std::max(np * m.ldc, 1);
     off = std::max(r1 + BODY_E * nb, o2);
     off = (off + 3) & ~3;
@@ -728,6 +796,29 @@ static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
   return AMX_OK;
 }
 
+// The plan of a model: the regular one, or - when the contact rows alone push a Newton model whose other rows are joint limits onto 64-lane
+// groups (one environment per wavefront) - the dense form (plan_dense), if that keeps more environments resident per CU.  The falls-and-rests
+// biped (16 contact slots, 30 dofs): 8 -> 16 environments per CU.  AMX_NO_DENSE=1: the regular plan (A/B switch).
+static int plan_model(const amx_model_desc *d, DevModel &m, Image &im) {
+  plan_dense = 0;
+  const int rc = plan_model_once(d, m, im);
+  if (rc != AMX_OK) return rc;
+  const char *no = getenv("AMX_NO_DENSE");
+  if (m.G == 64 && m.nbs == 1 && m.fusedH && plan_force_lanes == 0 && !plan_dense_off && !(no && atoi(no) != 0)) {
+    DevModel m2;
+    Image im2;
+    const std::vector<int> p2_keep = p2_col;
+    char err_keep[sizeof(g_err)];
+    memcpy(err_keep, g_err, sizeof(g_err));
+    plan_dense = 1;
+    const int rc2 = plan_model_once(d, m2, im2);
+    plan_dense = 0;
+    if (rc2 == AMX_OK && m2.G == 32 && (m2.wpb * (AMX_WAVE / m2.G) > m.wpb * (AMX_WAVE / m.G) || getenv("AMX_DENSE_ALWAYS"))) { m = m2; im = im2; }
+    else { p2_col = p2_keep; memcpy(g_err, err_keep, sizeof(g_err)); }
+  }
+  return AMX_OK;
+}
+
 // Tooling (not part of include/amx.h): the launch plan of a descriptor as "name=value" lines - every AMX_MODEL_INTS
 // field, then the dof tree (dof_parent) and whether each contact / equality row couples dofs of one ancestor chain only.
 // tools/gen_specs.py writes amx_specs_gen.h from this; tests/test_abi.py checks the committed header is current.
@@ -748,6 +839,9 @@ extern "C" int amx_model_plan_describe(const amx_model_desc *d, char *out, size_
   t += line;
   t += "p2_col=";
   for (int k = 0; k < 32; k++) { snprintf(line, sizeof(line), "%d%s", p2_col[k], k + 1 < 32 ? "," : ""); t += line; }
+  t += "\n";
+  t += "mrow=";  // compact M: per row "offset:first chunk:last chunk" (empty unless mcomp)
+  if (m.mcomp) for (int i = 0; i < m.nv; i++) { const int pk = im.geti(m.c_mrow + i); snprintf(line, sizeof(line), "%d:%d:%d%s", pk & 4095, (pk >> 12) & 15, (pk >> 16) & 15, i + 1 < m.nv ? "," : ""); t += line; }
   t += "\n";
   if (t.size() + 1 > cap) return fail(AMX_EINVAL, "amx_model_plan_describe: buffer of %zu bytes, %zu needed", cap, t.size() + 1);
   memcpy(out, t.c_str(), t.size() + 1);

@@ -547,7 +547,8 @@ def secondary(args, model, mj, model_path, x0_np, us_np, kern_ms, dev):
     if model_path == HEADLINE:
         # the same robot, the two other workloads: what they cost and what the robots do in them
         for name, path, what in (("C3 falls-and-rests", BIPED_REST, "random torques ~U(ctrlrange); two convex-mesh feet + eight contact spheres (pelvis, chest, shoulders, head, knees, "
-                                  "hands): the robot falls within ~150 steps and rests on the floor; 16 contact slots = 64 pyramid rows -> a 64-lane group, one environment per wavefront"),
+                                  "hands): the robot falls within ~150 steps and rests on the floor; 16 contact slots = 64 pyramid rows, two to a lane of a 32-lane group in the planner's dense form "
+                                  "(r05: compact M, three-row Jacobian blocks, sixteen environments per CU; one environment per wavefront and eight per CU before)"),
                                  ("C3 legacy feet-only", BIPED, "random torques ~U(ctrlrange); only the two convex-mesh feet collide (r01-r03 headline): after the fall the robot hangs "
                                   "below the floor from its feet")):
             try:
@@ -560,7 +561,7 @@ def secondary(args, model, mj, model_path, x0_np, us_np, kern_ms, dev):
                 out.append({"name": name, "metric": "env-steps/sec, 4096 envs x 1000-step rollout", "value": args.nenv * args.horizon * k / el, "unit": "env-steps/s",
                             "steps": k, "ms_per_step": 1e3 * el / k, "kernel_ms": kms,
                             "config": {"workload": f"{os.path.basename(path)}: {what}; {args.nenv} envs x {args.horizon} steps, Newton {mjv.opt.iterations} it / {mjv.opt.ls_iterations} ls",
-                                       "lanes_per_env": int(mdl._h.query("lanes_per_env")), "specialised_build": bool(mdl._h.query("specialised")),
+                                       "lanes_per_env": int(mdl._h.query("lanes_per_env")), "envs_per_workgroup": int(mdl._h.query("envs_per_block")), "specialised_build": bool(mdl._h.query("specialised")),
                                        "activity": activity_stats(mdl, mjv, xsv, usv), "outputs_finite": fin},
                             "roofline": roofline(mjv, args.nenv, args.horizon, kms, path),
                             "fp32_valu": fp32(mjv, None, None, args.nenv * args.horizon / (kms * 1e-3), path)})

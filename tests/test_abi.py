@@ -167,6 +167,54 @@ def test_spec_matching_compares_the_two_pair_columns(mj_models):
     assert iq >= 0 and L.amx_spec_index_of(C.byref(dq), 7, 24) == iq  # four single-contact pairs: no two-pair form, the list is not consulted
 
 
+def test_dense_plan_of_a_contact_rich_model(monkeypatch):
+    """r05: a Newton model whose contact rows alone ask for 64 lanes - the falls-and-rests biped, 16 slots - is planned in
+    the dense form when that keeps more environments in a CU: two contact rows per lane of a 32-lane group, compact M, three-row Jacobian
+    blocks, the solver's row records in the place of the contact points.  Checked here on the host: the plan's numbers; the library ships
+    kernels for it; the compact matrix holds every entry the dof tree makes non-zero exactly once per stored row and nothing overlaps;
+    AMX_NO_DENSE=1 gives the regular plan back; the headline model's plan is untouched."""
+    import ctypes as C
+    from ambersim_amd import _lib, _spec
+    from ambersim_amd._desc import build_desc
+    from ambersim_amd.utils.io_utils import load_mj_model_from_file
+    mj = load_mj_model_from_file("models/biped/biped_rest.xml")
+    p = _spec.plan(mj)
+    g = lambda k: int(p[k])
+    assert (g("G"), g("nbs"), g("mcomp"), g("jfr"), g("fusedH"), g("mfma2")) == (32, 2, 1, 1, 1, 0)
+    assert g("wpb") * (64 // g("G")) == 16 and (g("nconst") + 16 * g("env_floats")) * 4 <= 160 * 1024
+    nv, ldm, nb0 = g("nv"), g("ldm"), g("mnb0")
+    assert nb0 == 6 and ldm >= nv + 2  # the floating base; two spare columns
+    parent = list(mj.dof_parentid)
+    anc = lambda a, i: a == i or (i >= 0 and anc(a, parent[i]))
+    rows = [tuple(int(x) for x in r.split(":")) for r in p["mrow"].split(",")]
+    assert len(rows) == nv
+    used = set()
+    for i, (base, clo, chi) in enumerate(rows):
+        cells = set(range(base, base + 4 * (chi - clo + 1)))
+        assert not (cells & used) and base % 4 == 0, i
+        used |= cells
+        for j in range(nv):
+            related = anc(j, i) or anc(i, j)
+            stored = clo <= j // 4 <= chi
+            if i < nb0:
+                assert stored  # whole rows
+            elif j >= nb0 and related:
+                assert stored, (i, j)  # every non-zero entry beyond the leading chain is in the row's own chunks
+    assert max(used) + 1 == len(used) and len(used) <= g("e_J") - g("e_M") < nv * ldm  # contiguous, inside its block, smaller than whole rows
+    # the three-row Jacobian block and what follows it fit in front of the slab's end; the solver's records sit where the contact points were
+    assert g("e_J") + 3 * g("ncon") * g("ldc") <= g("e_vch") and g("e_con") <= g("e_H") < g("e_row") < g("e_M")
+    L = _lib.lib()
+    L.amx_spec_index_of.restype = C.c_int
+    d = build_desc(mj)
+    assert L.amx_spec_index_of(C.byref(d), -1, 0) >= 0  # shipped kernels for the dense form
+    monkeypatch.setenv("AMX_NO_DENSE", "1")
+    q = _spec.plan(mj)
+    assert (int(q["G"]), int(q["nbs"]), int(q["mcomp"]), int(q["jfr"])) == (64, 1, 0, 0) and int(q["wpb"]) * (64 // int(q["G"])) == 8
+    monkeypatch.delenv("AMX_NO_DENSE")
+    h = _spec.plan(load_mj_model_from_file("models/biped/biped_stand.xml"))
+    assert (int(h["G"]), int(h["nbs"]), int(h["mcomp"]), int(h["jfr"]), int(h["mrot"]), int(h["env_floats"])) == (32, 1, 0, 0, 1, 2348)
+
+
 def jit_test_model():
     """A model the library ships no specialisation for: the quadruped with two solver iterations instead of three."""
     import copy

@@ -411,7 +411,9 @@ def test_full_size_properties_physical_bipeds(dev, path, what):
     from oracle.oracle import Oracle
     mj = load_mj_model_from_file(path)
     model = mjx.put_model(mj, dev)
-    assert model._h.query("specialised") == 1 and model._h.query("lanes_per_env") == (32 if what == "stands" else 64)
+    # both on 32-lane groups, sixteen environments per workgroup (r05: the falls-and-rests biped's 64 contact rows ride two to a lane in the
+    # planner's dense form - compact M, three-row Jacobian blocks - instead of one environment per wavefront)
+    assert model._h.query("specialised") == 1 and model._h.query("lanes_per_env") == 32 and model._h.query("envs_per_block") == 16
     x0, us = make_inputs(mj, 4096, 1000, 1, 2, dev)
     xs = mjx.rollout(model, x0, us)
     assert xs.shape == (4096, 1001, mj.nq + mj.nv) and bool(torch.isfinite(xs).all())
