@@ -53,7 +53,7 @@ enum { CX_MAXV = 64, CX_MAXF = 128, CX_MAXE = 192, CX_MAXP = 16, CX_TAIL = 6 * C
   X(ldm) /* row stride of M and H: >= nv, a multiple of 4 */                                                                \
   X(mrot) /* 1: row i of M stores chunk c at position (c + i) mod ldm/4 (fused path with an even chunk count) */          \
   X(fusedH) /* 1: Newton eliminates H in registers, no H buffer (G >= 32, no equality rows) */                            \
-  X(mcomp) /* 1 (r05, the planner's dense form): M is stored compactly - rows [0, mnb0) of the leading chain every other dof descends from in full, every other row only the mwin 16-byte chunks that hold its entries on dofs >= mnb0 (its entries on the leading chain are read from those rows' columns: M is symmetric) */ X(mnb0) X(mwin) X(jfr) /* 1 (dense form): e_J holds three rows per contact [3 ncon][ldc]: normal, mu * tangent 1, mu * tangent 2 */ \
+  X(mcomp) /* 1 (r05, the planner's dense form): M is stored compactly - rows [0, mnb0) of the leading chain every other dof descends from in full, every other row only the mwin 16-byte chunks that hold its entries on dofs >= mnb0 (its entries on the leading chain are read from those rows' columns: M is symmetric) */ X(mnb0) X(mwin) X(mbs) /* row stride of the whole rows: ldm, + 4 when ldm / 4 is even (sixteen-byte loads of consecutive rows then fall into different bank slots) */ X(jfr) /* 1 (dense form): e_J holds three rows per contact [3 ncon][ldc]: normal, mu * tangent 1, mu * tangent 2 */ \
   X(mfma2) /* 1: the contacts belong to exactly two pairs (two feet): J'DJ runs chain-compressed on the 4-block 16x16 matrix instruction, one block per (environment, pair) - amx_kernels.hip, newton_solve_pair2 */ X(p2_shl0) X(p2_shl1) /* row shift that takes a pair's rows from their lanes in the other 16-lane row to their dofs' lanes */ X(p2_banks) /* four 4-bit DPP bank masks: home adds of pair 0 | of pair 1 << 4 | cross adds into pair 1's row-0 dofs << 8 | into pair 0's row-1 dofs << 12 */ \
   X(nchol) X(njac) X(nhent) X(subtree_contig) /* 1: every body's descendants are the bodies right after it (field 6 of the body record carries the end) */ X(sub_iter) /* largest subtree (bodies, itself included) below the tree roots */ X(deep_free) /* 1: a free joint below the first tree level (the chain-walking velocity pass assumes none) */ X(max_dofmem) /* most contacts any one dof takes part in */ X(max_jntnum) /* most joints on one body */ X(max_bgrp) /* most dof groups on one body (c_bgrp) */ X(jac_one_sided) /* 1: every contact Jacobian entry belongs to the chain of geom2's body alone (geom1 on a body without dofs: the ground) */                                                                                               \
   X(nbs) /* contact-row slots per lane: 1, or 2 (r04; per-model kernels of Newton models with limit / joint-equality rows besides): rows gl and gl + G */ X(cx_first) X(ncx) X(cx_maxv) /* run of convex-convex pairs (fn 6), processed one after the other by the whole lane group */         \
@@ -67,7 +67,7 @@ enum { CX_MAXV = 64, CX_MAXF = 128, CX_MAXE = 192, CX_MAXP = 16, CX_TAIL = 6 * C
   X(c_jac) /* packed contact|slot<<6|dof<<11|chain sign<<16|pair<<18 */                                                    \
   X(c_hent) /* [nhent] terms: packed dof_i|dof_j<<5|first contact row<<10|slot_i<<18|slot_j<<23 (dof_j <= dof_i) */         \
   X(c_dofmemadr) /* [nv+1] */ X(c_dofmem) /* terms: packed first contact row|slot<<8 */ X(c_conpair) /* [ncon] */           \
-  X(c_vert) X(c_rootbody) X(c_slot) /* [ncon][32]: position of dof j in the contact's dof chain, -1 if absent */ X(c_zero) /* one all-zero matrix row (ldm floats, 16-byte aligned): what the lanes without a matrix row load */ X(c_anc) /* [nb][max(nlevel-2,1)]: ancestors of a body, root first, itself and the world excluded, padded with 0 */ X(c_bgrp) /* [nb][max_bgrp]: the body's dof groups in order - first dof | count << 8 (1 or 3) | (1 << 12 unless the free joint's translations); 0: none */ X(c_vchdof) /* [npair][ldc]: dof of slot t of the pair's dof list, -1 past its end */ X(c_mrow) /* [nv] (mcomp): float offset of row i's storage inside M | first stored chunk << 12 | last << 16 */ X(c_p2) /* [32] (mfma2): per lane of an environment, the slot of the pair's dof list it feeds as A operand | as B operand << 8 (0xFF none, 0xFE the residual Jaref) */ X(c_prog) /* [AMX_WAVES_PER_BLOCK] zeros: in LDS the waves of a workgroup post their step counters here (fair sharing of a SIMD, amx_rollout_kernel) */            \
+  X(c_vert) X(c_rootbody) X(c_slot) /* [ncon][32]: position of dof j in the contact's dof chain, -1 if absent */ X(c_zero) /* one all-zero matrix row (ldm floats, 16-byte aligned): what the lanes without a matrix row load (mcomp: 160 zeros - lane i reads its zero chunks at + 4 i, every lane of a sixteen-byte load's service group in a bank slot of its own) */ X(c_anc) /* [nb][max(nlevel-2,1)]: ancestors of a body, root first, itself and the world excluded, padded with 0 */ X(c_bgrp) /* [nb][max_bgrp]: the body's dof groups in order - first dof | count << 8 (1 or 3) | (1 << 12 unless the free joint's translations); 0: none */ X(c_vchdof) /* [npair][ldc]: dof of slot t of the pair's dof list, -1 past its end */ X(c_mrow) /* [nv] (mcomp): float offset of row i's storage inside M | first stored chunk << 12 | last << 16 */ X(c_p2) /* [32] (mfma2): per lane of an environment, the slot of the pair's dof list it feeds as A operand | as B operand << 8 (0xFF none, 0xFE the residual Jaref) */ X(c_prog) /* [AMX_WAVES_PER_BLOCK] zeros: in LDS the waves of a workgroup post their step counters here (fair sharing of a SIMD, amx_rollout_kernel) */            \
   /* bases inside one environment slab (float offsets from the slab start) */                                              \
   X(e_qpos) X(e_qvel) X(e_ctrl)                                                                                            \
   X(e_body) /* records [nb][BODY_E]: xpos 0-2 xquat 3-6 cinert 7-16 (then cfrc 7-12) crb 17-26 (then cvel 17-22 cacc 23-28) */ \

@@ -1253,17 +1253,21 @@ template <int N, int G> DEV float dense_sym_solve(float (&a)[N], float b, int gl
 // column N of the whole rows, where the caller has put them; a lane without a row reads the zero row and the always-zero column ldm - 1.
 template <class S, int N>
 DEV void m_row_compact(float (&a)[N + 1], int M_off, int gl, int mdiag, unsigned mwin, bool owner, bool brow, int bt_off) {
-  constexpr int ld = S::ldm, nb0 = S::mnb0;
+  constexpr int ld = S::ldm, nb0 = S::mnb0, bs = S::mbs;
   static_assert(!S::mcomp || ld >= N + 2, "compact M: two spare columns");
   const int colb = M_off + (gl <= N ? gl : ld - 1);
 #pragma unroll
-  for (int j = 0; j < nb0; ++j) a[j] = lds[colb + j * ld];
-  const int rb = brow ? bt_off : (owner ? M_off + mdiag - gl : S::c_zero);
+  for (int j = 0; j < nb0; ++j) a[j] = lds[colb + j * bs];
+  // (zeros: every lane its own sixteen bytes of the constants' zero block - forty lanes reading ONE zero chunk were served one after the other:
+  //  LDS bank-conflict cycles 45 % of the LDS pipe's time on the first build of this form)
+  const int zb = S::c_zero + 4 * (gl & 31);
+  // (mdiag - gl is a multiple of four floats - the planner's row offsets are; said so, or the chunk loads are split into four-byte halves)
+  const int rb = brow ? bt_off : (owner ? M_off + 4 * ((mdiag - gl) >> 2) : zb);
   const unsigned win = brow ? ~0u : mwin;
 #pragma unroll
   for (int c = nb0 / 4; c < (N + 3) / 4; ++c) {
-    const int ad = ((win >> c) & 1u) ? rb : S::c_zero;
-    const float4 v = *reinterpret_cast<const float4 *>(lds + ad + 4 * c);
+    const int ad = ((win >> c) & 1u) ? rb : zb;
+    const float4 v = *reinterpret_cast<const float4 *>(__builtin_assume_aligned(lds + ad + 4 * c, 16));
     const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -1291,7 +1295,7 @@ AMX_STATIC_SOLVE_ATTR void spd_solve_static(int A_off, int rhs_off, int x_off, i
     const bool brow = BCOL && gl == N && bt_off >= 0;
     if (BCOL && bt_off >= 0) {
       if (gl < ld) lds[bt_off + gl] = b;
-      if (S::mcomp && gl < S::mnb0) lds[A_off + gl * ld + N] = b;  // the mirrored row's leading entries: column N of the whole rows
+      if (S::mcomp && gl < S::mnb0) lds[A_off + gl * S::mbs + N] = b;  // the mirrored row's leading entries: column N of the whole rows
       WSYNC();
     }
     if constexpr (S::mcomp) {
@@ -1476,7 +1480,7 @@ AMX_STATIC_SOLVE_ATTR bool newton_solve_fused(int M_off, int ld_, int n_, unsign
     }
     b = owner ? b : 0.0f;
     if (gl < lds_) lds[bt_off + gl] = b;
-    if (S::mcomp && gl < S::mnb0) lds[M_off + gl * lds_ + NS] = b;  // the mirrored row's leading entries (m_row_compact)
+    if (S::mcomp && gl < S::mnb0) lds[M_off + gl * S::mbs + NS] = b;  // the mirrored row's leading entries (m_row_compact)
     WSYNC();
     // lanes without a matrix row load the constants' all-zero row, and their J'DJ registers are zero (no slot): the row is a
     // plain sum.  The diagonal term of the lane's limit row went into M's diagonal in LDS before the loads (restored below).

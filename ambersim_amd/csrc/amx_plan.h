@@ -583,7 +583,7 @@ static int plan_model_once(const amx_model_desc *d, DevModel &m, Image &im) {
   // leading entries with mnb0 four-byte loads down the whole rows' column, the others as chunks, a chunk outside its range from the constants'
   // zero row).  A 30-dof biped with four six-dof limbs: 6 x 32 + 24 x 8 = 384 floats instead of 960.  Needs two spare columns: column nv
   // carries the right-hand side to the lane that mirrors it as a row, column ldm - 1 stays zero for the lanes without a row.
-  m.mcomp = 0; m.mnb0 = 0; m.mwin = 0;
+  m.mcomp = 0; m.mnb0 = 0; m.mwin = 0; m.mbs = m.ldm;
   int m_floats = nv * m.ldm;
   std::vector<int> mrow_base(nv, 0), mrow_clo(nv, 0), mrow_chi(nv, m.ldm / 4 - 1);
   if (plan_dense && m.fusedH && m.nbs == 2 && m.ldm >= nv + 2 && nv <= 32 && !getenv("AMX_DENSE_NO_MCOMP")) {
@@ -602,15 +602,16 @@ static int plan_model_once(const amx_model_desc *d, DevModel &m, Image &im) {
       mrow_clo[i] = lo / 4; mrow_chi[i] = hi / 4;
       wmax = std::max(wmax, hi / 4 - lo / 4 + 1);
     }
-    int total = nb0 * m.ldm;
+    int total = nb0 * (m.ldm + 4);
     for (int i = nb0; i < nv; i++) total += 4 * (mrow_chi[i] - mrow_clo[i] + 1);
     if (nb0 >= 1 && nb0 < nv && total < nv * m.ldm) {
       m.mcomp = 1; m.mnb0 = nb0; m.mwin = wmax; m.mrot = 0;
+      m.mbs = m.ldm + ((m.ldm / 4) % 2 == 0 ? 4 : 0);  // an odd number of chunks per whole row: the leading lanes' sixteen-byte loads do not collide
       int o = 0;
       for (int i = 0; i < nv; i++) {
         if (i < nb0) { mrow_clo[i] = 0; mrow_chi[i] = m.ldm / 4 - 1; }
         mrow_base[i] = o;
-        o += 4 * (mrow_chi[i] - mrow_clo[i] + 1);
+        o += i < nb0 ? m.mbs : 4 * (mrow_chi[i] - mrow_clo[i] + 1);
       }
       m_floats = o;
     }
@@ -725,8 +726,9 @@ static int plan_model_once(const amx_model_desc *d, DevModel &m, Image &im) {
   m.c_vert = im.reserve(3 * d->nconvexvert);
   for (int k = 0; k < 3 * d->nconvexvert; k++) im.setf(m.c_vert + k, d->convex_vert[k]);
   while (im.size() & 3) im.reserve(1);
-  m.c_zero = im.reserve(m.ldm);  // stays zero: Image::reserve clears
-  for (int k = 0; k < m.ldm; k++) im.setf(m.c_zero + k, 0.0f);
+  const int nzero = m.mcomp ? 4 * 32 + m.ldm : m.ldm;
+  m.c_zero = im.reserve(nzero);  // stays zero: Image::reserve clears
+  for (int k = 0; k < nzero; k++) im.setf(m.c_zero + k, 0.0f);
   m.c_prog = im.reserve(AMX_WAVES_PER_BLOCK);  // zeros; written in LDS only (the waves' step counters)
   while (im.size() & 3) im.reserve(1);  // environment slabs start 16-byte aligned
   m.nconst = im.size();
@@ -779,6 +781,13 @@ static int plan_model_once(const amx_model_desc *d, DevModel &m, Image &im) {
   m.e_Lb = d->solver == 1 ? take(ntri) : m.e_H;
   m.e_prof = 0;  // (unused since r02b: the diagnostic build keeps its counters in HBM)
   m.env_floats = (off + 3) & ~3;  // slabs keep 16-byte alignment
+  if (plan_dense && m.G == 32) {
+    // two environments per wavefront read their records lane-per-record at odd strides: with the slabs 32 banks apart (of 64) no lane of one
+    // environment meets a lane of the other in a bank, whatever the odd stride (s d = 32 mod 64 has no solution |d| < 32) - if that still fits
+    int padded = m.env_floats;
+    while ((padded & 63) != 32) padded += 4;
+    if ((m.nconst + AMX_WAVES_PER_BLOCK * 2 * padded) * (int)sizeof(float) <= 160 * 1024) m.env_floats = padded;
+  }
   // waves per workgroup: each workgroup carries one copy of the constants, so pick the size that keeps the most
   // waves resident per CU (160 KiB of LDS, at most AMX_MIN_WAVES_PER_SIMD*4 waves by registers); ties go to the larger
   int best_w = 0;  // largest workgroup (in waves) whose LDS fits; each launch picks 1..best_w (choose_wpb)

@@ -976,6 +976,169 @@ def test_two_contact_rows_per_lane(dev, nbox, force):
         os.environ.pop("AMX_FORCE_NBS", None)
 
 
+PUPPET_XML = """<mujoco model="puppet">
+  <!-- fixed-base torso on a three-hinge waist, a one-hinge head and two four-hinge arms over a floor: {nv} dofs, every dof below the waist
+       chain (the planner's leading chain is the waist: three dofs, not a multiple of four), twelve contact spheres -->
+  <compiler angle="radian" autolimits="true"/>
+  <option timestep="0.004" iterations="6" ls_iterations="8" solver="Newton" integrator="Euler"/>
+  <default>
+    <joint type="hinge" damping="0.4" armature="0.01"/>
+    <geom contype="0" conaffinity="0" density="500"/>
+    <motor ctrllimited="true" ctrlrange="-3 3"/>
+    <default class="ball"><geom type="sphere" size="0.04" contype="1" conaffinity="0" friction="0.7 0.02 0.01"/></default>
+  </default>
+  <worldbody>
+    <geom name="floor" type="plane" size="0 0 0.1" pos="0 0 0" contype="0" conaffinity="1"/>
+    <body name="w1" pos="0 0 0.5">
+      <joint name="w_yaw" axis="0 0 1" range="-1 1"/>
+      <geom type="capsule" fromto="0 0 0 0 0 -0.05" size="0.04"/>
+      <body name="w2" pos="0 0 -0.05">
+        <joint name="w_pitch" axis="0 1 0" range="-0.8 0.8"/>
+        <geom type="capsule" fromto="0 0 0 0 0 -0.05" size="0.04"/>
+        <body name="chest" pos="0 0 -0.05">
+          <joint name="w_roll" axis="1 0 0" range="-0.8 0.8"/>
+          <geom type="box" size="0.08 0.14 0.1" pos="0 0 -0.1"/>
+          <geom name="chest_l" class="ball" pos="0.05 0.1 -0.2"/>
+          <geom name="chest_r" class="ball" pos="0.05 -0.1 -0.2"/>
+          <body name="head" pos="0.1 0 -0.1">
+            <joint name="neck" axis="0 1 0" range="-1 1"/>
+            <geom name="head_ball" class="ball" size="0.07" pos="0.1 0 -0.05"/>
+            {extra}
+          </body>
+          <body name="l_up" pos="0 0.18 -0.05">
+            <joint name="l_sh1" axis="0 1 0" range="-2 2"/>
+            <geom type="sphere" size="0.035"/>
+            <body name="l_up2">
+              <joint name="l_sh2" axis="1 0 0" range="-1.5 1.5"/>
+              <geom type="capsule" fromto="0 0 0 0 0 -0.2" size="0.03"/>
+              <geom name="l_upper_ball" class="ball" pos="0 0 -0.1"/>
+              <body name="l_fore" pos="0 0 -0.2">
+                <joint name="l_elbow" axis="0 1 0" range="-2.2 0"/>
+                <geom type="capsule" fromto="0 0 0 0 0 -0.2" size="0.025"/>
+                <geom name="l_elbow_ball" class="ball"/>
+                <geom name="l_fore_ball" class="ball" pos="0 0 -0.1"/>
+                <body name="l_hand" pos="0 0 -0.2">
+                  <joint name="l_wrist" axis="1 0 0" range="-1 1"/>
+                  <geom name="l_hand_ball" class="ball" size="0.05" pos="0 0 -0.04"/>
+                </body>
+              </body>
+            </body>
+          </body>
+          <body name="r_up" pos="0 -0.18 -0.05">
+            <joint name="r_sh1" axis="0 1 0" range="-2 2"/>
+            <geom type="sphere" size="0.035"/>
+            <body name="r_up2">
+              <joint name="r_sh2" axis="1 0 0" range="-1.5 1.5"/>
+              <geom type="capsule" fromto="0 0 0 0 0 -0.2" size="0.03"/>
+              <geom name="r_upper_ball" class="ball" pos="0 0 -0.1"/>
+              <body name="r_fore" pos="0 0 -0.2">
+                <joint name="r_elbow" axis="0 1 0" range="-2.2 0"/>
+                <geom type="capsule" fromto="0 0 0 0 0 -0.2" size="0.025"/>
+                <geom name="r_elbow_ball" class="ball"/>
+                <geom name="r_fore_ball" class="ball" pos="0 0 -0.1"/>
+                <body name="r_hand" pos="0 0 -0.2">
+                  <joint name="r_wrist" axis="1 0 0" range="-1 1"/>
+                  <geom name="r_hand_ball" class="ball" size="0.05" pos="0 0 -0.04"/>
+                </body>
+              </body>
+            </body>
+          </body>
+        </body>
+      </body>
+    </body>
+  </worldbody>
+  <actuator>
+    <motor joint="w_yaw"/><motor joint="w_pitch"/><motor joint="w_roll"/><motor joint="neck"/>
+    <motor joint="l_sh1"/><motor joint="l_sh2"/><motor joint="l_elbow"/><motor joint="l_wrist"/>
+    <motor joint="r_sh1"/><motor joint="r_sh2"/><motor joint="r_elbow"/><motor joint="r_wrist"/>{extra_act}
+  </actuator>
+</mujoco>"""
+
+
+def _dense_tree_models():
+    """Three more dof trees for the planner's dense form: (name, host model, expected (mcomp, mnb0))."""
+    import re
+    import ambersim_amd
+    from ambersim_amd.mjcf import MjModel
+    out = []
+    # the quadruped with knee spheres and four spheres under the torso: 12 contact slots, 18 dofs, six-dof leading chain, three-dof legs
+    path = os.path.join(ambersim_amd.ROOT, "models", "quadruped", "quadruped.xml")
+    xml = open(path).read()
+    for leg in ("fl", "fr", "hl", "hr"):
+        xml = xml.replace(f'<geom name="{leg}_foot" class="foot" pos="0 0 -0.2"/>', f'<geom name="{leg}_foot" class="foot" pos="0 0 -0.2"/><geom name="{leg}_knee_ball" class="foot" size="0.03"/>')
+    xml = xml.replace('<geom name="torso_box" type="box" size="0.21 0.075 0.045" density="700"/>',
+                      '<geom name="torso_box" type="box" size="0.21 0.075 0.045" density="700"/>' +
+                      "".join(f'<geom name="belly{k}" class="foot" size="0.03" pos="{x} {y} -0.04"/>' for k, (x, y) in enumerate(((0.18, 0.06), (0.18, -0.06), (-0.18, 0.06), (-0.18, -0.06)))))
+    xml = re.sub(r'iterations="3" ls_iterations="5"', 'iterations="6" ls_iterations="8"', xml)
+    out.append(("quadruped, 12 slots", MjModel.from_xml_string(xml, model_dir=os.path.dirname(path)), (1, 6)))
+    # the puppet with 13 dofs (a second neck hinge): ldm = 16 >= nv + 2 - compact M on a three-dof leading chain
+    extra = '<body name="head2" pos="0.1 0 -0.05"><joint name="neck2" axis="1 0 0" range="-1 1"/><geom type="sphere" size="0.03" pos="0.05 0 0"/></body>'
+    out.append(("puppet, 13 dofs", MjModel.from_xml_string(PUPPET_XML.format(nv=13, extra=extra, extra_act='<motor joint="neck2"/>')), (1, 3)))
+    # ... and with 12 (ldm = 12: no spare columns, M stays whole): the three-row Jacobian blocks alone
+    out.append(("puppet, 12 dofs", MjModel.from_xml_string(PUPPET_XML.format(nv=12, extra="", extra_act="")), (0, 0)))
+    return out
+
+
+def test_dense_form_on_other_dof_trees(dev):
+    """The planner's dense form (r05: two contact rows per lane, compact M, three-row Jacobian blocks) beyond the falls-and-rests biped it was
+    built for: a quadruped with twelve contact slots (three-dof limbs under a six-dof leading chain), a fixed-base puppet whose leading
+    chain is a three-hinge waist (not a multiple of four: the leading entries and the first chunk share registers), and the same puppet with
+    no spare matrix columns (three-row blocks without compact M).  Each: planned dense on per-model kernels; 64 random states pushed into
+    the floor, one step within 1e-5 of the fp64 oracle (or three times the fp32 oracle's own error); forward outputs incl. the dense mass
+    matrix and the contact distances; a 100-step rollout stays finite and ends in contact."""
+    from ambersim_amd import mjx, _spec
+    from oracle.oracle import Oracle
+    for name, mj, (mcomp, nb0) in _dense_tree_models():
+        p = _spec.plan(mj)
+        assert (int(p["G"]), int(p["nbs"]), int(p["jfr"]), int(p["mcomp"]), int(p["mnb0"])) == (32, 2, 1, mcomp, nb0), (name, p["G"], p["nbs"], p["jfr"], p["mcomp"], p["mnb0"])
+        model = mjx.put_model(mj, dev, specialise=True)
+        assert model._h.query("specialised") == 1 and model._h.query("lanes_per_env") == 32 and model._h.query("envs_per_block") == 16
+        rng = np.random.default_rng(5)
+        nenv = 64
+        lo, hi = mj.jnt_range[:, 0], mj.jnt_range[:, 1]
+        q = np.tile(mj.qpos0, (nenv, 1))
+        free = mj.jnt_type[0] == 0
+        o = Oracle(mj, np.float64)
+        touching = 0
+        for k in range(nenv):
+            for j in range(mj.njnt):
+                if mj.jnt_type[j] == 3: q[k, mj.jnt_qposadr[j]] = (1.0 if free else 0.45) * rng.uniform(lo[j], hi[j])  # (the puppet: arms hanging, more or less)
+            if free:
+                quat = np.array([1.0, 0, 0, 0]) + 0.12 * rng.standard_normal(4)
+                q[k, 3:7] = quat / np.linalg.norm(quat)
+                q[k, 2] = 1.0
+                o.set_state(q[k], np.zeros(mj.nv), np.zeros(mj.nu)); o.forward()
+                q[k, 2] -= o.get("con_dist").min() + rng.uniform(0.0, 0.04)  # the lowest sphere 0 .. 40 mm in the floor
+            o.set_state(q[k], np.zeros(mj.nv), np.zeros(mj.nu)); o.forward()
+            touching += int((o.get("con_dist") < 0).sum())
+        assert touching >= nenv, (name, touching)
+        x0 = np.concatenate([q, 0.5 * rng.standard_normal((nenv, mj.nv))], axis=1).astype(np.float32)
+        us = (rng.uniform(-1, 1, (nenv, 1, mj.nu)) * np.abs(mj.actuator_ctrlrange[:, 1])).astype(np.float32)
+        xs = gpu_rollout(model, x0, us)
+        ref = o.rollout(x0, us)
+        ref32 = Oracle(mj, np.float32).rollout(x0, us).astype(np.float64)
+        e64 = np.abs(xs[:, 1] - ref[:, 1]).max(axis=1) / np.maximum(1.0, np.abs(ref[:, 1]).max(axis=1))
+        f = np.abs(ref32[:, 1] - ref[:, 1]).max(axis=1) / np.maximum(1.0, np.abs(ref[:, 1]).max(axis=1))
+        print(f"dense form, {name}: {touching} contacts touching over {nenv} envs, one-step error {e64.max():.2e} (fp32 oracle's own {f.max():.2e})")
+        assert (e64 <= np.maximum(TOL, 3 * f)).all(), (name, e64.max(), f.max())
+        # forward outputs: the mass matrix out of the compact storage, the contact distances written before the solver's records take their place
+        import ctypes as C
+        from ambersim_amd import _lib
+        qM = torch.empty((nenv, mj.nv, mj.nv), device=dev); cdist = torch.zeros((nenv, model.ncon), device=dev); qacc = torch.empty((nenv, mj.nv), device=dev)
+        tq, tv, tu = (torch.tensor(a, dtype=torch.float32, device=dev) for a in (x0[:, :mj.nq], x0[:, mj.nq:], us[:, 0]))
+        out = _lib.AmxForwardOut(qacc.data_ptr(), None, None, None, qM.data_ptr(), None, None, cdist.data_ptr(), None)
+        _lib.check(model._h.L.amx_forward(model._h.ptr, nenv, tq.data_ptr(), tv.data_ptr(), tu.data_ptr(), None, C.byref(out), None), model._h.L)
+        torch.cuda.synchronize()
+        for e in range(0, nenv, 8):
+            o.set_state(x0[e, :mj.nq], x0[e, mj.nq:], us[e, 0], np.zeros(mj.nv)); o.forward()
+            assert rel(qM[e].cpu().numpy().ravel(), o.get("qM")) < TOL, name
+            assert np.abs(cdist[e].cpu().numpy() - o.get("con_dist")).max() <= 1e-5, name
+            assert rel(qacc[e].cpu().numpy(), o.get("qacc")) < 5e-5, (name, rel(qacc[e].cpu().numpy(), o.get("qacc")))
+        usl = (rng.uniform(-1, 1, (nenv, 100, mj.nu)) * np.abs(mj.actuator_ctrlrange[:, 1])).astype(np.float32)
+        xl = gpu_rollout(model, x0, usl)
+        assert np.isfinite(xl).all(), name
+
+
 def test_biped_with_twenty_four_contact_slots(dev):
     """VERDICT r03 item 6's capacity case: the falls-and-rests biped (16 contact slots) with eight more resting spheres on its arms and legs -
     24 slots, 120 constraint rows, two contact rows per lane of a 64-lane group, per-model kernels.  One step within 1e-5 of the fp64 oracle

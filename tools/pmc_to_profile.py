@@ -6,8 +6,8 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 rnd = sys.argv[2] if len(sys.argv) > 2 else "r05"
 G, waves, passes = 32, 2048, 1001  # 4096 envs x 1000 steps, two environments per wave
-if tag == "biped_rest":
-    G, waves = 64, 4096  # sixteen contact slots: one environment per wave
+if tag == "biped_rest" and rnd < "r05":
+    G, waves = 64, 4096  # sixteen contact slots: one environment per wave (since r05: two contact rows per lane, two environments per wave - the dense form)
 model_arg = "" if tag == "biped_stand" else f" --model models/{tag.split('_')[0]}/{tag}.xml"  # biped_stand is bench.py's default workload since r04
 v = {}
 for line in open(os.path.join(root, "gpurun_out", f"pmc_{tag}_summary.csv")):

@@ -12,6 +12,7 @@ bench) timeout -k 10 900 python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.e
 stats) (cd /tmp && export TMPDIR=/tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$OUT/stats -o stats -- python3 $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary > $REPO/$OUT/stats/bench.log 2>&1)
        tail -1 $OUT/stats/bench.log | cut -c1-300 ;;
 pmc)   bash tools/pmc_collect.sh biped_stand > $OUT/pmc_biped_stand.log 2>&1; tail -45 $OUT/pmc_biped_stand.log ;;
+pmc_rest) bash tools/pmc_collect.sh biped_rest --model models/biped/biped_rest.xml > $OUT/pmc_biped_rest.log 2>&1; tail -45 $OUT/pmc_biped_rest.log ;;
 phase) AMX_LIBRARY=ambersim_amd/csrc/libamx_prof.so timeout -k 10 300 python tools/phase_profile.py models/biped/biped_stand.xml 4096 1000 > $OUT/phase_biped_stand.txt 2>&1
        AMX_LIBRARY=ambersim_amd/csrc/libamx_prof.so timeout -k 10 300 python tools/phase_profile.py models/biped/biped_stand.xml 1024 100 > $OUT/phase_biped_stand_1w.txt 2>&1
        AMX_LIBRARY=ambersim_amd/csrc/libamx_prof.so timeout -k 10 300 python tools/phase_profile.py models/biped/biped_rest.xml 4096 200 > $OUT/phase_biped_rest.txt 2>&1
