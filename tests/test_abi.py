@@ -201,7 +201,7 @@ def test_dense_plan_of_a_contact_rich_model(monkeypatch):
             elif j >= nb0 and related:
                 assert stored, (i, j)  # every non-zero entry beyond the leading chain is in the row's own chunks
     assert max(used) < g("e_J") - g("e_M") < nv * ldm  # inside its block, smaller than whole rows
-    assert g("env_floats") % 64 == 32  # the two environments of a wavefront 32 banks apart: lane-per-record reads at odd strides never meet
+    assert g("env_floats") % 64 == 32  # the two environments of a wavefront 32 banks apart (measured later: no effect either way - DESIGN.md 7)
     # the three-row Jacobian block and what follows it fit in front of the slab's end; the solver's records sit where the contact points were
     assert g("e_J") + 3 * g("ncon") * g("ldc") <= g("e_vch") and g("e_con") <= g("e_H") < g("e_row") < g("e_M")
     L = _lib.lib()
