@@ -1422,7 +1422,7 @@ AMX_STATIC_SOLVE_ATTR bool newton_solve_fused(int M_off, int ld_, int n_, unsign
         C0[4 * q + 0] = in ? vA.x : 0.0f; C0[4 * q + 1] = in ? vA.y : 0.0f; C0[4 * q + 2] = in ? vA.z : 0.0f; C0[4 * q + 3] = in ? vA.w : 0.0f;
         C0[16 + 4 * q + 0] = in ? vB.x : 0.0f; C0[16 + 4 * q + 1] = in ? vB.y : 0.0f; C0[16 + 4 * q + 2] = in ? vB.z : 0.0f; C0[16 + 4 * q + 3] = in ? vB.w : 0.0f;
       }
-      jtdj_rows_mfma<G, false, NS>(crows_u, row_base, J_base, S::ldc, S::c_slot, gl, lo, hi, &C0);
+      jtdj_rows_mfma<G, false, NS, S::jfr != 0>(crows_u, row_base, J_base, S::ldc, S::c_slot, gl, lo, hi, &C0);
       PROF_CTX(pc, 25);
       if (owner) lds[dg] = d0;  // M's own diagonal back (the loads above are done: one wave's LDS operations execute in order)
       float a[NS + 1];

@@ -148,3 +148,114 @@ def random_inputs(m, seed: int, nenv: int, nsteps: int):
     lo, hi = (m.actuator_ctrlrange[:, 0], m.actuator_ctrlrange[:, 1]) if m.nu else (np.zeros(0), np.zeros(0))
     us = rng.uniform(lo, hi, (nenv, nsteps, m.nu)) if m.nu else np.zeros((nenv, nsteps, 0))
     return x0, us
+
+
+def random_dense_mjcf(seed: int) -> str:
+    """The contact-rich family (r05): what the planner's dense form is for - a Newton model with 9 .. 16 sphere contacts against the floor,
+    joint limits, no equality / ball / friction-loss rows; a floating base or a fixed pedestal with a leading hinge chain, an optional spine
+    below it, two to five limbs of two to six hinges.  At most 30 dofs."""
+    rng = np.random.default_rng(seed + 300007)
+    dt = float(rng.choice([0.002, 0.004]))
+    out = [f'<mujoco model="dense{seed}">',
+           f'  <option timestep="{dt}" iterations="{int(rng.integers(3, 9))}" ls_iterations="{int(rng.integers(4, 11))}" solver="Newton" gravity="0 0 -9.81"/>',
+           '  <compiler angle="radian" autolimits="true"/>',
+           '  <default><joint type="hinge" damping="0.3" armature="0.01"/><geom contype="0" conaffinity="0" density="600"/>'
+           '<default class="c"><geom type="sphere" contype="1" conaffinity="0"/></default></default>',
+           '  <worldbody>', '    <geom name="floor" type="plane" size="0 0 0.1" contype="0" conaffinity="1"/>']
+    free = rng.random() < 0.7
+    budget = 30 - (6 if free else 0)
+    joints, spheres = [], [0]
+    nsph = int(rng.integers(9, 17))
+    jid = [0]
+
+    def hinge(ind):
+        ax = rng.standard_normal(3); ax /= np.linalg.norm(ax)
+        lo, hi = -rng.uniform(0.3, 1.5), rng.uniform(0.3, 1.5)
+        name = f"j{jid[0]}"; jid[0] += 1
+        joints.append(name)
+        out.append(f'{ind}<joint name="{name}" axis="{ax[0]:.4f} {ax[1]:.4f} {ax[2]:.4f}" range="{lo:.3f} {hi:.3f}" damping="{rng.uniform(0.05, 0.6):.3f}"/>')
+
+    def sphere(ind, p):
+        if spheres[0] < nsph and rng.random() < p:
+            spheres[0] += 1
+            out.append(f'{ind}<geom class="c" size="{rng.uniform(0.03, 0.07):.3f}" pos="{_v(rng, -0.04, 0.04)}" friction="{rng.uniform(0.4, 1.1):.2f}"/>')
+
+    def link(ind, length):
+        out.append(f'{ind}<geom type="capsule" fromto="0 0 0 0 0 {-length:.3f}" size="{rng.uniform(0.02, 0.04):.3f}"/>')
+
+    hz = rng.uniform(0.5, 0.9)
+    out.append(f'    <body name="root" pos="0 0 {hz if free else 0.2 + 0.3 * (hz - 0.5) / 0.4:.3f}">')  # a pedestal low enough for the limbs to reach the floor
+    ind = "      "
+    if free:
+        out.append(f'{ind}<freejoint name="rootj"/>')
+    else:
+        hinge(ind); budget -= 1
+    out.append(f'{ind}<geom type="box" size="0.1 0.08 0.06"/>')
+    sphere(ind, 0.8)
+    depth = 1
+    nspine = int(rng.integers(0, 4)) if free else int(rng.integers(1, 3))
+    for s_ in range(nspine):  # a chain every limb may hang from
+        if budget < 8: break
+        out.append(f'{ind}<body name="spine{s_}" pos="0 0 {-0.08 if s_ else -0.07:.3f}">')
+        ind += "  "; depth += 1
+        hinge(ind); budget -= 1
+        link(ind, 0.08)
+        sphere(ind, 0.5)
+    nlimb = int(rng.integers(2, 6))
+    for l_ in range(nlimb):
+        nd = int(rng.integers(2, 7))
+        if budget - nd < 0: break
+        budget -= nd
+        close = 0
+        a = rng.uniform(0, 2 * np.pi)
+        first = True
+        while nd > 0:
+            out.append(f'{ind}{"  " * close}<body name="l{l_}_{close}" pos="{0.12 * np.cos(a) if first else 0:.3f} {0.12 * np.sin(a) if first else 0:.3f} {-0.02 if first else -0.16:.3f}">')
+            close += 1
+            first = False
+            k = 2 if (nd >= 2 and rng.random() < 0.3) else 1
+            for _ in range(k): hinge(ind + "  " * close)
+            nd -= k
+            link(ind + "  " * close, 0.16)
+            sphere(ind + "  " * close, 0.9)
+        while spheres[0] < nsph and rng.random() < 0.5:
+            sphere(ind + "  " * close, 1.0)
+        for c in range(close, 0, -1): out.append(f'{ind}{"  " * (c - 1)}</body>')
+    for d_ in range(depth - 1, 0, -1): out.append("      " + "  " * (d_ - 1) + "</body>")
+    out.append("    </body>")
+    out.append("  </worldbody>")
+    out.append("  <actuator>")
+    for j in joints:
+        if rng.random() < 0.5: out.append(f'    <motor joint="{j}" gear="{rng.uniform(0.5, 3):.2f}" ctrllimited="true" ctrlrange="-1 1"/>')
+        else: out.append(f'    <position joint="{j}" kp="{rng.uniform(5, 30):.1f}" ctrllimited="true" ctrlrange="-0.5 0.5"/>')
+    out.append("  </actuator>")
+    out.append("</mujoco>")
+    return "\n".join(out)
+
+
+def random_dense_model(seed: int):
+    """Host model of the contact-rich family, or None when the draw does not need the dense form's capacity (at most 8 contacts) or exceeds it."""
+    m = MjModel.from_xml_string(random_dense_mjcf(seed))
+    if m.nv > 30 or m.ncon <= 8 or m.ncon > 16 or m.nbody > 32:
+        return None
+    return m
+
+
+def random_dense_inputs(m, oracle, seed: int, nenv: int, nsteps: int):
+    """States of the contact-rich family: random joint angles inside their ranges, random base attitude, the lowest sphere 0 .. 35 mm in the floor
+    (floating base) - so that several contacts of either row slot are active at the first step."""
+    rng = np.random.default_rng(2000 + seed)
+    q = np.tile(m.qpos0, (nenv, 1))
+    free = m.jnt_type[0] == 0
+    for k in range(nenv):
+        for j in range(m.njnt):
+            if m.jnt_type[j] == 3: q[k, m.jnt_qposadr[j]] = 0.6 * rng.uniform(m.jnt_range[j, 0], m.jnt_range[j, 1])
+        if free:
+            quat = np.array([1.0, 0, 0, 0]) + 0.3 * rng.standard_normal(4)
+            q[k, 3:7] = quat / np.linalg.norm(quat)
+            q[k, 2] = 2.0
+            oracle.set_state(q[k], np.zeros(m.nv), np.zeros(m.nu)); oracle.forward()
+            q[k, 2] -= oracle.get("con_dist").min() + rng.uniform(0.0, 0.035)
+    v = 0.5 * rng.standard_normal((nenv, m.nv))
+    us = rng.uniform(m.actuator_ctrlrange[:, 0], m.actuator_ctrlrange[:, 1], (nenv, nsteps, m.nu))
+    return np.concatenate([q, v], axis=1), us

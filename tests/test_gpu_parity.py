@@ -1139,6 +1139,33 @@ def test_dense_form_on_other_dof_trees(dev):
         assert np.isfinite(xl).all(), name
 
 
+@pytest.mark.parametrize("seed", [0, 12, 16, 24, 27, 35])
+def test_contact_rich_fuzz_family_vs_oracle(dev, seed):
+    """Draws of the contact-rich fuzz family (tests/fuzz_models.py: random_dense_model - floating or pedestal base, spine, two to five limbs,
+    9 .. 16 sphere contacts, Newton, limits) on the per-model kernels of the planner's dense form, one and five steps against the fp64 oracle
+    from states with the lowest sphere in the floor.  The sample: both 27-dof draws that run the accumulator-from-M Newton solve on three-row
+    Jacobian blocks (0, 24: NaN on the first build of the form), compact M under leading chains of two (16: 24 bodies), six (27: sixteen
+    contacts) and eight dofs (12, 35: 30 dofs).  tools/dbg/fuzz_dense.py runs forty (profiles/r05_fuzz_dense.txt)."""
+    from ambersim_amd import mjx
+    from fuzz_models import random_dense_inputs, random_dense_model
+    from oracle.oracle import Oracle
+    mj = random_dense_model(seed)
+    assert mj is not None
+    o = Oracle(mj, np.float64)
+    x0, us = random_dense_inputs(mj, o, seed, 16, 5)
+    x0, us = x0.astype(np.float32), us.astype(np.float32)
+    ref = o.rollout(x0, us)
+    ref32 = Oracle(mj, np.float32).rollout(x0, us).astype(np.float64)
+    assert np.isfinite(ref).all() and np.isfinite(ref32).all()
+    model = mjx.put_model(mj, dev, specialise=True)
+    assert model._h.query("specialised") == 1 and model._h.query("lanes_per_env") == 32
+    xs = gpu_rollout(model, x0, us)
+    r = lambda a, b: np.abs(a - b).max(axis=-1) / np.maximum(1.0, np.abs(b).max(axis=-1))
+    e1, f1, e5, f5 = r(xs[:, 1], ref[:, 1]), r(ref32[:, 1], ref[:, 1]), r(xs[:, 5], ref[:, 5]), r(ref32[:, 5], ref[:, 5])
+    print(f"contact-rich draw {seed}: nv {mj.nv}, {mj.ncon} contacts, one step {e1.max():.2e} (fp32 oracle {f1.max():.2e}), five {e5.max():.2e} ({f5.max():.2e})")
+    assert np.isfinite(xs).all() and (e1 <= np.maximum(TOL, 3 * f1)).all() and (e5 <= np.maximum(5e-5, 5 * f5)).all(), (e1.max(), f1.max(), e5.max(), f5.max())
+
+
 def test_biped_with_twenty_four_contact_slots(dev):
     """VERDICT r03 item 6's capacity case: the falls-and-rests biped (16 contact slots) with eight more resting spheres on its arms and legs -
     24 slots, 120 constraint rows, two contact rows per lane of a 64-lane group, per-model kernels.  One step within 1e-5 of the fp64 oracle
