@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak run on the GPU box: the headline rollout launched N times back to back; every launch's trajectories must be bit-identical to
-the first's (same inputs), finite, and the launch time steady.  python tools/soak.py [launches]"""
+the first's (same inputs), finite, and the launch time steady.  python tools/soak.py [launches] [model.xml]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,6 +9,7 @@ from ambersim_amd.utils.io_utils import load_mj_model_from_file
 from bench import HEADLINE, make_inputs
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 dev = torch.device("cuda", 0)
+HEADLINE = sys.argv[2] if len(sys.argv) > 2 else HEADLINE
 mj = load_mj_model_from_file(HEADLINE)
 model = mjx.put_model(mj, dev)
 x0, us = make_inputs(mj, 4096, 1000, 1, 2, dev)
