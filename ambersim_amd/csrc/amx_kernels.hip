@@ -3183,10 +3183,11 @@ struct Env {
             jp = mk3(s2 ? jp.x - a1.x : jp.x, s2 ? jp.y - a1.y : jp.y, s2 ? jp.z - a1.z : jp.z);
           }
           const float jn = dot(fn_, jp), j1 = dot(ft1, jp), j2 = dot(ft2, jp);
-          if (m.jfr()) return JEnt{Jo + (3 * c) * ldc + slot, jn, mu * j1, mu * j2, 0.0f};  // three rows per contact; the pyramid rows are their sums and differences
-          return JEnt{Jo + (4 * c) * ldc + slot, jn + mu * j1, jn - mu * j1, jn + mu * j2, jn - mu * j2};
+          // (compile-time: the generic kernels, which never run the three-row form, keep the code - and the roundings - they had)
+          if constexpr (S::is_static && S::jfr) return JEnt{Jo + (3 * c) * ldc + slot, jn, mu * j1, mu * j2, 0.0f};  // three rows per contact; the pyramid rows are their sums and differences
+          else return JEnt{Jo + (4 * c) * ldc + slot, jn + mu * j1, jn - mu * j1, jn + mu * j2, jn - mu * j2};
         },
-        [&](int, const JEnt &r) { lds[r.at] = r.r0; lds[r.at + ldc] = r.r1; lds[r.at + 2 * ldc] = r.r2; if (!m.jfr()) lds[r.at + 3 * ldc] = r.r3; });
+        [&](int, const JEnt &r) { lds[r.at] = r.r0; lds[r.at + ldc] = r.r1; lds[r.at + 2 * ldc] = r.r2; if constexpr (!(S::is_static && S::jfr)) lds[r.at + 3 * ldc] = r.r3; });
       stage_chain(qv, 1);  // for the rows' J * qvel below
     }
     WSYNC();

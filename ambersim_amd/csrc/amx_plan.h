@@ -579,10 +579,11 @@ static int plan_model_once(const amx_model_desc *d, DevModel &m, Image &im) {
   // Compact M (dense form only; r05).  M[i][j] != 0 only when one of i, j is an ancestor of the other.  A floating-base robot's first mnb0
   // dofs form a chain every other dof descends from: their rows are dense and stay whole.  Any other row i has entries on that chain - which
   // are, M being symmetric, column i of the whole rows - and on the dofs >= mnb0 of its own branch, a narrow range of columns: it stores the
-  // 16-byte chunks [clo_i, chi_i] that cover that range, mwin chunks per row (amx_kernels.hip, m_row_compact: the lane reads its row's
+  // 16-byte chunks [clo_i, chi_i] that cover that range, at most mwin of them (amx_kernels.hip, m_row_compact: the lane reads its row's
   // leading entries with mnb0 four-byte loads down the whole rows' column, the others as chunks, a chunk outside its range from the constants'
-  // zero row).  A 30-dof biped with four six-dof limbs: 6 x 32 + 24 x 8 = 384 floats instead of 960.  Needs two spare columns: column nv
-  // carries the right-hand side to the lane that mirrors it as a row, column ldm - 1 stays zero for the lanes without a row.
+  // zero block).  The falls-and-rests biped (30 dofs: base, three-dof waist, head, two four-dof arms, two six-dof legs): 6 x 36 + 264 = 480
+  // floats instead of 960.  Needs two spare columns: column nv carries the right-hand side to the lane that mirrors it as a row, column
+  // ldm - 1 stays zero for the lanes without a row.
   m.mcomp = 0; m.mnb0 = 0; m.mwin = 0; m.mbs = m.ldm;
   int m_floats = nv * m.ldm;
   std::vector<int> mrow_base(nv, 0), mrow_clo(nv, 0), mrow_chi(nv, m.ldm / 4 - 1);
@@ -782,8 +783,9 @@ static int plan_model_once(const amx_model_desc *d, DevModel &m, Image &im) {
   m.e_prof = 0;  // (unused since r02b: the diagnostic build keeps its counters in HBM)
   m.env_floats = (off + 3) & ~3;  // slabs keep 16-byte alignment
   if (plan_dense && m.G == 32) {
-    // two environments per wavefront read their records lane-per-record at odd strides: with the slabs 32 banks apart (of 64) no lane of one
-    // environment meets a lane of the other in a bank, whatever the odd stride (s d = 32 mod 64 has no solution |d| < 32) - if that still fits
+    // the two environments of a wavefront 32 banks apart (of 64), where that still fits.  (Meant to keep their lane-per-record reads at odd
+    // strides out of each other's banks; measured afterwards on the headline kernel - slabs 16, 32, 44 banks apart - it makes no difference:
+    // a 64-lane four-byte access is served half a wave at a time.  Harmless; kept so that the committed plan records stay as measured.)
     int padded = m.env_floats;
     while ((padded & 63) != 32) padded += 4;
     if ((m.nconst + AMX_WAVES_PER_BLOCK * 2 * padded) * (int)sizeof(float) <= 160 * 1024) m.env_floats = padded;
