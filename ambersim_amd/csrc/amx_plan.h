@@ -583,11 +583,12 @@ static int plan_model_once(const amx_model_desc *d, DevModel &m, Image &im) {
   // leading entries with mnb0 four-byte loads down the whole rows' column, the others as chunks, a chunk outside its range from the constants'
   // zero block).  The falls-and-rests biped (30 dofs: base, three-dof waist, head, two four-dof arms, two six-dof legs): 6 x 36 + 264 = 480
   // floats instead of 960.  Needs two spare columns: column nv carries the right-hand side to the lane that mirrors it as a row, column
-  // ldm - 1 stays zero for the lanes without a row.
+  // ldm - 1 stays zero for the lanes without a row (ldm grows by one chunk where nv leaves fewer than two).
   m.mcomp = 0; m.mnb0 = 0; m.mwin = 0; m.mbs = m.ldm;
   int m_floats = nv * m.ldm;
   std::vector<int> mrow_base(nv, 0), mrow_clo(nv, 0), mrow_chi(nv, m.ldm / 4 - 1);
-  if (plan_dense && m.fusedH && m.nbs == 2 && m.ldm >= nv + 2 && nv <= 32 && !getenv("AMX_DENSE_NO_MCOMP")) {
+  const int ldm_c = m.ldm >= nv + 2 ? m.ldm : m.ldm + 4;  // the row length compact M would take: two spare columns (a 27- or 31-dof model gets one more chunk)
+  if (plan_dense && m.fusedH && m.nbs == 2 && nv <= 31 && !getenv("AMX_DENSE_NO_MCOMP")) {
     auto is_anc = [&](int a, int i) { for (int j = i; j >= 0; j = d->dof_parentid[j]) if (j == a) return true; return false; };  // a is i or above it
     int nb0 = 0;
     while (nb0 < nv && d->dof_parentid[nb0] == nb0 - 1) {
@@ -603,9 +604,10 @@ static int plan_model_once(const amx_model_desc *d, DevModel &m, Image &im) {
       mrow_clo[i] = lo / 4; mrow_chi[i] = hi / 4;
       wmax = std::max(wmax, hi / 4 - lo / 4 + 1);
     }
-    int total = nb0 * (m.ldm + 4);
+    int total = nb0 * (ldm_c + 4);
     for (int i = nb0; i < nv; i++) total += 4 * (mrow_chi[i] - mrow_clo[i] + 1);
     if (nb0 >= 1 && nb0 < nv && total < nv * m.ldm) {
+      m.ldm = ldm_c;
       m.mcomp = 1; m.mnb0 = nb0; m.mwin = wmax; m.mrot = 0;
       m.mbs = m.ldm + ((m.ldm / 4) % 2 == 0 ? 4 : 0);  // an odd number of chunks per whole row: the leading lanes' sixteen-byte loads do not collide
       int o = 0;

@@ -212,6 +212,15 @@ def test_dense_plan_of_a_contact_rich_model(monkeypatch):
     q = _spec.plan(mj)
     assert (int(q["G"]), int(q["nbs"]), int(q["mcomp"]), int(q["jfr"])) == (64, 1, 0, 0) and int(q["wpb"]) * (64 // int(q["G"])) == 8
     monkeypatch.delenv("AMX_NO_DENSE")
+    # a 27-dof draw of the contact-rich fuzz family: rows of seven chunks have one spare column, compact M wants two - the planner gives the
+    # rows an eighth chunk (and the model sixteen environments per CU instead of fourteen)
+    from fuzz_models import random_dense_model
+    f = _spec.plan(random_dense_model(0))
+    assert (int(f["nv"]), int(f["ldm"]), int(f["mcomp"]), int(f["jfr"]), int(f["wpb"]) * (64 // int(f["G"]))) == (27, 32, 1, 1, 16)
+    monkeypatch.setenv("AMX_DENSE_NO_MCOMP", "1")
+    f = _spec.plan(random_dense_model(0))
+    assert (int(f["ldm"]), int(f["mcomp"]), int(f["jfr"]), int(f["wpb"]) * (64 // int(f["G"]))) == (28, 0, 1, 14)
+    monkeypatch.delenv("AMX_DENSE_NO_MCOMP")
     h = _spec.plan(load_mj_model_from_file("models/biped/biped_stand.xml"))
     assert (int(h["G"]), int(h["nbs"]), int(h["mcomp"]), int(h["jfr"]), int(h["mrot"]), int(h["env_floats"])) == (32, 1, 0, 0, 1, 2348)
 

@@ -1074,8 +1074,10 @@ def _dense_tree_models():
     # the puppet with 13 dofs (a second neck hinge): ldm = 16 >= nv + 2 - compact M on a three-dof leading chain
     extra = '<body name="head2" pos="0.1 0 -0.05"><joint name="neck2" axis="1 0 0" range="-1 1"/><geom type="sphere" size="0.03" pos="0.05 0 0"/></body>'
     out.append(("puppet, 13 dofs", MjModel.from_xml_string(PUPPET_XML.format(nv=13, extra=extra, extra_act='<motor joint="neck2"/>')), (1, 3)))
-    # ... and with 12 (ldm = 12: no spare columns, M stays whole): the three-row Jacobian blocks alone
-    out.append(("puppet, 12 dofs", MjModel.from_xml_string(PUPPET_XML.format(nv=12, extra="", extra_act="")), (0, 0)))
+    # ... and with 12: rows of three chunks leave no spare column, so compact M takes a fourth (ldm = 16)
+    out.append(("puppet, 12 dofs", MjModel.from_xml_string(PUPPET_XML.format(nv=12, extra="", extra_act="")), (1, 3)))
+    # ... and the same with compact M switched off (AMX_DENSE_NO_MCOMP: whole rows): the three-row Jacobian blocks alone
+    out.append(("puppet, 12 dofs, whole M", MjModel.from_xml_string(PUPPET_XML.format(nv=12, extra="", extra_act="")), (0, 0)))
     return out
 
 
@@ -1089,6 +1091,9 @@ def test_dense_form_on_other_dof_trees(dev):
     from ambersim_amd import mjx, _spec
     from oracle.oracle import Oracle
     for name, mj, (mcomp, nb0) in _dense_tree_models():
+      os.environ.pop("AMX_DENSE_NO_MCOMP", None)
+      if "whole M" in name: os.environ["AMX_DENSE_NO_MCOMP"] = "1"  # read by the planner: at plan time here and in the per-model library's amx_model_create
+      try:
         p = _spec.plan(mj)
         assert (int(p["G"]), int(p["nbs"]), int(p["jfr"]), int(p["mcomp"]), int(p["mnb0"])) == (32, 2, 1, mcomp, nb0), (name, p["G"], p["nbs"], p["jfr"], p["mcomp"], p["mnb0"])
         model = mjx.put_model(mj, dev, specialise=True)
@@ -1137,18 +1142,22 @@ def test_dense_form_on_other_dof_trees(dev):
         usl = (rng.uniform(-1, 1, (nenv, 100, mj.nu)) * np.abs(mj.actuator_ctrlrange[:, 1])).astype(np.float32)
         xl = gpu_rollout(model, x0, usl)
         assert np.isfinite(xl).all(), name
+      finally:
+        os.environ.pop("AMX_DENSE_NO_MCOMP", None)
 
 
-@pytest.mark.parametrize("seed", [0, 12, 16, 24, 27, 35])
-def test_contact_rich_fuzz_family_vs_oracle(dev, seed):
+@pytest.mark.parametrize("seed,whole_m", [(0, False), (0, True), (12, False), (16, False), (24, True), (27, False), (35, False)])
+def test_contact_rich_fuzz_family_vs_oracle(dev, seed, whole_m, monkeypatch):
     """Draws of the contact-rich fuzz family (tests/fuzz_models.py: random_dense_model - floating or pedestal base, spine, two to five limbs,
     9 .. 16 sphere contacts, Newton, limits) on the per-model kernels of the planner's dense form, one and five steps against the fp64 oracle
     from states with the lowest sphere in the floor.  The sample: both 27-dof draws that run the accumulator-from-M Newton solve on three-row
-    Jacobian blocks (0, 24: NaN on the first build of the form), compact M under leading chains of two (16: 24 bodies), six (27: sixteen
-    contacts) and eight dofs (12, 35: 30 dofs).  tools/dbg/fuzz_dense.py runs forty (profiles/r05_fuzz_dense.txt)."""
+    Jacobian blocks - that solve reads whole rows of M, so these two run with compact M switched off (0, 24 with `whole_m`: NaN on the first
+    build of the form) -, compact M on rows that had to grow by a chunk for its two spare columns (0: 27 dofs), under leading chains of two
+    (16: 24 bodies), six (27: sixteen contacts) and eight dofs (12, 35: 30 dofs).  tools/dbg/fuzz_dense.py runs forty (profiles/r05_fuzz_dense.txt)."""
     from ambersim_amd import mjx
     from fuzz_models import random_dense_inputs, random_dense_model
     from oracle.oracle import Oracle
+    if whole_m: monkeypatch.setenv("AMX_DENSE_NO_MCOMP", "1")  # the form without compact M (the planner reads it here and in amx_model_create)
     mj = random_dense_model(seed)
     assert mj is not None
     o = Oracle(mj, np.float64)
