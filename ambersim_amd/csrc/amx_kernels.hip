@@ -2575,13 +2575,25 @@ struct Env {
       float r[10];
 #pragma unroll
       for (int k = 0; k < 10; ++k) r[k] = 0.0f;
-#pragma unroll 4
-      for (int k = 0; k < m.sub_iter(); ++k) {
+      auto add_rec = [&](int k) {
         const int d_ = b + k, src = (inner && d_ < b_subend) ? d_ : ((isb && k == 0) ? b : 0);  // a root reads just itself
         float x[10];
 #pragma unroll
         for (int q = 0; q < 10; ++q) x[q] = body(F_CINERT + q, src);
         pk_acc<10>(r, x);
+      };
+      if constexpr (S::is_static) {
+        // static trip count, four records' loads in flight at a time (a `#pragma unroll 4` on the run-time form of this loop was not honoured:
+        // one LDS round trip per record, seven to nine in a row)
+#pragma unroll
+        for (int k0 = 0; k0 < S::sub_iter; k0 += 4) {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) if (k0 + kk < S::sub_iter) add_rec(k0 + kk);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll 4
+        for (int k = 0; k < m.sub_iter(); ++k) add_rec(k);
       }
       // a root's composite = itself + the composites of its children = a group sum over the lanes of the root and of the
       // bodies right below it (registers and DPP only; the child-list loop it replaces waited on LDS for every child)
@@ -2763,12 +2775,22 @@ struct Env {
       // store; the roots then add their children's totals
       const bool isb = b > 0 && b < m.nb(), inner = isb && b_parent > 0;
       sv f = {{0, 0, 0, 0, 0, 0}};
-#pragma unroll 4
-      for (int k = 0; k < m.sub_iter(); ++k) {
+      auto add_frc = [&](int k) {
         const int d_ = b + k;
         const sv g = ld_bsv(F_CFRC, (inner && d_ < b_subend) ? d_ : ((isb && k == 0) ? b : 0));
 #pragma unroll
         for (int e = 0; e < 1; ++e) sv_acc(f, g);
+      };
+      if constexpr (S::is_static) {  // (as in crb_and_M: four records in flight at a time)
+#pragma unroll
+        for (int k0 = 0; k0 < S::sub_iter; k0 += 4) {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) if (k0 + kk < S::sub_iter) add_frc(k0 + kk);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll 4
+        for (int k = 0; k < m.sub_iter(); ++k) add_frc(k);
       }
       for (int rt = 0; rt < m.nroot(); ++rt) {  // roots: group sum over themselves and the bodies right below them
         const bool part = isb && b_root == rt && b_level <= 2;
@@ -3399,10 +3421,27 @@ struct Env {
       const float v = lds[vo + (vch_dof < 0 ? 0 : vch_dof) * vs];
       if (gl < nvch) lds[out + gl] = vch_dof < 0 ? 0.0f : v;
     }
-    for (int t = gl + G; t < nvch; t += G) {  // more slots than lanes (quadruped: 4 pairs x 9): the dof comes from the constants
-      const int d_ = CI(m.c_vchdof() + t);
-      const float v = lds[vo + (d_ < 0 ? 0 : d_) * vs];
-      lds[out + t] = d_ < 0 ? 0.0f : v;
+    // more slots than lanes (quadruped: 4 pairs x 9; the falls-and-rests biped: 10 x 13): the dof comes from the constants
+    if constexpr (S::is_static) {
+      // static round count: every round's index load, then every value load, then the stores - two LDS round trips in all.  (As a loop
+      // every round was two of its own: four rounds per call and some six calls a step were ~6 k cycles of the falls-and-rests biped's 91 k.)
+      constexpr int NV = S::npair * S::ldc, NR = (NV + G - 1) / G - 1;
+      if constexpr (NR > 0) {
+        int d_[NR];
+        float v[NR];
+#pragma unroll
+        for (int k = 0; k < NR; ++k) { const int t = gl + G * (k + 1); d_[k] = CI(S::c_vchdof + (t < NV ? t : 0)); }
+#pragma unroll
+        for (int k = 0; k < NR; ++k) v[k] = lds[vo + (d_[k] < 0 ? 0 : d_[k]) * vs];
+#pragma unroll
+        for (int k = 0; k < NR; ++k) { const int t = gl + G * (k + 1); if (t < NV) lds[out + t] = d_[k] < 0 ? 0.0f : v[k]; }
+      }
+    } else {
+      for (int t = gl + G; t < nvch; t += G) {
+        const int d_ = CI(m.c_vchdof() + t);
+        const float v = lds[vo + (d_ < 0 ? 0 : d_) * vs];
+        lds[out + t] = d_ < 0 ? 0.0f : v;
+      }
     }
   }
   // sum over the contact row's dof list of J[t] * v[dof_t]: J at Jr, v staged by stage_chain.  Every term of the row's ldc
@@ -3553,8 +3592,7 @@ struct Env {
       const bool isd = gl < m.nv();
       float acc = 0;
       const int mem0 = CI(m.c_dofmemadr() + (isd ? gl : 0)), mem1 = isd ? CI(m.c_dofmemadr() + (isd ? gl : 0) + 1) : mem0;
-#pragma unroll
-      for (int u = 0; u < m.max_dofmem(); u += 2) {
+      auto two_terms = [&](int u) {
         const int t0 = mem0 + u, t1 = t0 + 1;
         const bool w0 = t0 < mem1, w1 = t1 < mem1;
         const int pk0 = CI(m.c_dofmem() + (w0 ? t0 : 0)), pk1 = CI(m.c_dofmem() + (w1 ? t1 : 0));
@@ -3578,7 +3616,10 @@ struct Env {
         const float sb = (jb[0] * fb[0] + jb[1] * fb[1]) + (jb[2] * fb[2] + jb[3] * fb[3]);
         acc += w0 ? sa : 0.0f;
         acc += w1 ? sb : 0.0f;
-      }
+      };
+#pragma unroll
+      for (int u = 0; u < m.max_dofmem(); u += 2) two_terms(u);
+      // (tried: eight terms' loads in flight at a time behind scheduling barriers, for the sixteen-term lists of a contact-rich model - no faster)
       // limit rows have one entry each and a dof at most one limit row: without equality rows the dof lane fetches its row's
       // force through the crossbar instead of the rows scattering with LDS atomics
       if (m.neq() == 0 && nA() > 0) {
