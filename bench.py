@@ -21,9 +21,9 @@ after ~150 steps the robots hang below the floor from their feet; kept for conti
           are all-gathered once per step by ONE RCCL all-gather (north_star's exchange; `--gather traj`, the default), started
           asynchronously behind each rollout.  The rollout's workgroups fill every CU, so a collective's KERNELS cannot run
           next to it (profiles/r03_coresidency.txt); `--gather p2p` does the same exchange as peer-to-peer copies on the copy
-          engines (ambersim_amd.dist.PeerCopyGather), which can - a named alternative whose numbers sit beside the collective's in
-          `scaling_report` (rollout alone, both gather methods alone / serialised / overlapped, RCCL version, world size as the
-          backend reports it); it never carries the headline unless asked for.
+          engines (ambersim_amd.dist.PeerCopyGather), which can - a named alternative; `--p2p-report` times it beside the
+          collective in `scaling_report` (rollout alone, the gather alone / serialised / overlapped, RCCL version, world size as
+          the backend reports it).  The default run sets up RCCL only.
 
 `python bench.py --gpus N` is self-contained: with WORLD_SIZE unset and N > 1 the parent - which has not imported torch
 or touched the GPU - starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process, relays
@@ -68,6 +68,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="N=1: skip the C2 / C4 / solver-option / FP32 secondary measurements")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: wait for each all-gather before the next rollout")
+    ap.add_argument("--p2p-report", action="store_true",
+                    help="N>1 with --gather traj: also set up the peer-copy gather and time it beside the collective in scaling_report.  Opt-in "
+                         "since r05: cross-device IPC mappings have never run on hardware (no multi-GPU node in any round), and the default "
+                         "run - the driver's scaling bench - should depend on RCCL alone")
     ap.add_argument("--no-scaling-report", action="store_true", help="N>1: skip the extra rollout-only / gather-only timings")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: zero trajectories on the CPU, gloo collectives")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch only: rendezvous port (0 = pick a free one)")
@@ -274,7 +278,8 @@ def worker(args):
     red_dev = "cpu" if (dry or share) else dev  # small host-side reductions: gloo takes CPU tensors
     # the gather method: peer-to-peer copies (copy engines) or the RCCL collective (kernels)
     p2p, p2p_note = None, None
-    want_p2p = args.gather == "p2p" or (args.gather == "traj" and not args.no_scaling_report)  # the alternative is measured beside the collective
+    # the alternative is measured beside the collective when asked for (--p2p-report); ranks sharing one device have no RCCL at all
+    want_p2p = args.gather == "p2p" or (args.gather == "traj" and not args.no_scaling_report and (args.p2p_report or share))
     if world > 1 and want_p2p:  # (dry run: the same class on shared host memory - the protocol without the copy engines)
         try:
             p2p = PeerCopyGather((args.nenv, args.horizon + 1, nx), torch.float32, dev, nbuf=2)

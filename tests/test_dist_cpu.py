@@ -199,6 +199,11 @@ def test_bench_self_launch_dry_run_eight_ranks():
     out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
     assert out["n_gpus"] == 8 and out["config"]["gather"] == "traj+overlapped" and out["scaling_report"]["gathered_GB_per_rank"] > 0
     assert out["scaling_report"].get("block_order_ok") is True
+    assert "peer_copy_alone_ms" not in out["scaling_report"]  # the default run (the driver's) depends on the collective alone
+    p = subprocess.run(cmd + ["--p2p-report"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert out["config"]["gather"] == "traj+overlapped" and out["scaling_report"]["peer_copy_alone_ms"] > 0  # the alternative beside it, on request
     p = subprocess.run(cmd + ["--gather", "p2p"], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
