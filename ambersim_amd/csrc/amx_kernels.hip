@@ -3938,6 +3938,9 @@ struct Env {
     asm("v_max_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(o) : "v"(x), "v"(y), "n"(K), "v"(dep));
     return o;
   }
+#ifndef AMX_LS_CLAMP_MASK
+#define AMX_LS_CLAMP_MASK 1  // 0: a row's activity at a trial point by compare and select (r04), A/B switch
+#endif
 #ifndef AMX_LS_PACKED_X
 #define AMX_LS_PACKED_X 1  // 0: the two row slots' residuals at a trial point as two scalar multiply-adds (A/B switch)
 #endif
@@ -3967,6 +3970,27 @@ struct Env {
     const float a0A = validA ? 0.5f * aD * aJaref * aJaref : 0.0f, a0B = validB ? 0.5f * cD * cJaref * cJaref : 0.0f;
     const float a0B2 = validB2() ? 0.5f * c2D * c2Jaref * c2Jaref : 0.0f;
     const f2v jv2 = {aJv, cJv}, jr2 = {aJaref, cJaref};  // both row slots' residual at a trial point in one packed multiply-add
+#if AMX_LS_CLAMP_MASK
+    // (r05c) "the row is active at alpha" as the 0 / 1 factor directly: residual x < 0  <=>  clamp(-2^64 x) = 1 for every |x| >= 2^-64, and the
+    // scaling by a power of two commutes with the multiply-add's rounding, so one packed multiply-add with the clamp modifier on pre-scaled
+    // (-2^64 Jv, -2^64 Jaref) yields both slots' factors: 1 instruction per trial point instead of 1 + 2 compares + 2 selects.  Exact zero,
+    // -0, NaN (clamped to 0) and overflow (+-inf -> 1 / 0) decide as the compare does; a residual inside (-2^-64, 0) - a cancellation to twenty
+    // digits - would weigh its row by |x| 2^64 < 1 at that one trial point instead of 1.
+    const f2v jvS = jv2 * -0x1p64f, jrS = jr2 * -0x1p64f;
+    const float c2JvS = c2Jv * -0x1p64f, c2JrS = c2Jaref * -0x1p64f;
+    auto terms = [&](float alpha) {
+      f2v a2, m2;
+      a2.x = alpha;  // (a2.y is left undefined on purpose: op_sel_hi takes the low half twice, and a defined high half costs a v_mov per trial point)
+      asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] clamp" : "=v"(m2) : "v"(a2), "v"(jvS), "v"(jrS));
+      f2v r = pk_fma(pA, f2v{m2.x, m2.x}, pk_fma(pB, f2v{m2.y, m2.y}, gsh));
+      if constexpr (NBS == 2) {
+        float mB2;
+        asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(mB2) : "v"(alpha), "v"(c2JvS), "v"(c2JrS));
+        r = pk_fma(pB2, f2v{mB2, mB2}, r);
+      }
+      return r;
+    };
+#else
     auto terms = [&](float alpha) {  // the lane's (q1 / 2, q2) at alpha, Gauss share included
 #if AMX_LS_PACKED_X
       const f2v x2 = pk_fma(f2v{alpha, alpha}, jv2, jr2);
@@ -3982,12 +4006,30 @@ struct Env {
       }
       return r;
     };
+#endif
+#if AMX_LS_CLAMP_MASK
+    // the same factors weigh the rows' constant terms: 1 * a0 and 0 * a0 are exact and the multiply-add rounds the sum once, as the addition of the
+    // two selected terms did - the same bits
+    auto q0at = [&](float alpha) {
+      f2v a2, m2;
+      a2.x = alpha;
+      asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] clamp" : "=v"(m2) : "v"(a2), "v"(jvS), "v"(jrS));
+      float r = __builtin_fmaf(m2.x, a0A, m2.y * a0B);
+      if constexpr (NBS == 2) {
+        float mB2;
+        asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(mB2) : "v"(alpha), "v"(c2JvS), "v"(c2JrS));
+        r = __builtin_fmaf(mB2, a0B2, r);
+      }
+      return r;
+    };
+#else
     auto q0at = [&](float alpha) {
       const float xA = __builtin_fmaf(alpha, aJv, aJaref), xB = __builtin_fmaf(alpha, cJv, cJaref);
       float r = (xA < 0.0f ? a0A : 0.0f) + (xB < 0.0f ? a0B : 0.0f);
       if constexpr (NBS == 2) r += __builtin_fmaf(alpha, c2Jv, c2Jaref) < 0.0f ? a0B2 : 0.0f;
       return r;
     };
+#endif
     const float hmin = 0.5f * MINVAL;
     float hmin_r = hmin;
     asm volatile("" : "+v"(hmin_r));  // one register for the whole search (rematerialised per use it is a v_mov each time)
